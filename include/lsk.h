@@ -1,0 +1,331 @@
+/*
+ * lsk.h -- C ABI of the MI355X-native Krylov inner loop (SpMV + BLAS-1) for LegionSolvers.
+ *
+ * Every entry point is `extern "C"`, takes plain pointers and sizes, returns an `int`
+ * status (0 = LSK_OK) and enqueues its work on the HIP stream passed in; nothing here
+ * synchronises the host unless its name ends in `_host`.  Device pointers are raw HBM
+ * addresses (hipMalloc, a torch tensor's data_ptr, or a Legion/Realm GPU_FB_MEM instance).
+ *
+ * The entry points are exactly what the GPU (TOC_PROC) variants of the reference's leaf
+ * tasks bind; each comment cites the reference interface it replaces (paths are relative to
+ * the reference checkout).
+ *
+ * Index conventions follow the reference: kernel indices `k`, column indices and row
+ * indices are GLOBAL 64-bit coordinates; a shard is handed pointers to the first element
+ * of its piece plus the global coordinate of that element.
+ */
+#ifndef LSK_H_INCLUDED
+#define LSK_H_INCLUDED
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ status codes ---- */
+#define LSK_OK 0
+#define LSK_ERR_HIP (-1)       /* a HIP runtime call failed (see lsk_last_error)        */
+#define LSK_ERR_ARG (-2)       /* invalid argument (null pointer, negative size, ...)    */
+#define LSK_ERR_ALIGN (-3)     /* a pointer does not meet the documented alignment       */
+#define LSK_ERR_UNSUPPORTED (-4)
+#define LSK_ERR_COMM (-5)      /* an RCCL call failed                                    */
+#define LSK_ERR_NO_DEVICE (-6) /* no HIP device visible                                  */
+
+/* hipStream_t, passed opaquely so that this header needs no HIP include. */
+typedef void *lsk_stream_t;
+
+/* ------------------------------------------------------------- shim (runtime) ------- */
+/* Replaces src/CUDAUtilities.{hpp,cpp} and src/CudaLibs.{hpp,cu}.                       */
+
+/* Library version, "lsk <major>.<minor> gfx950". */
+const char *lsk_version(void);
+
+/* Message of the last failing call on this host thread ("" if none).
+ * Replaces the fprintf in check_cuda/check_cublas/check_cusparse
+ * (src/CUDAUtilities.cpp:13-63). */
+const char *lsk_last_error(void);
+
+/* If nonzero, a failing call prints its message to stderr and abort()s, which is the
+ * reference's error behaviour (print + assert(false), src/CUDAUtilities.cpp:13-27).
+ * Default 0: print nothing, return the status code. */
+void lsk_set_abort_on_error(int enable);
+
+/* Number of visible HIP devices. */
+int lsk_device_count(int *count);
+
+/* Make `device` current and create its per-device library state (reduction scratch).
+ * Idempotent.  Replaces LoadCUDALibsTask::task_body (src/CudaLibs.cu:11-20), which warms
+ * the stream and the cuBLAS/cuSPARSE handles of one GPU; there are no handles any more. */
+int lsk_init(int device);
+
+/* hipMalloc / hipFree wrappers: replace Legion::DeferredBuffer(..., GPU_FB_MEM, nullptr, 16)
+ * for callers without Legion (src/CSRMatrixTasks.cu:133-137, src/CuSPARSEHelpers.hpp:73-75).
+ * Returned memory is at least 256-byte aligned. */
+int lsk_malloc(void **ptr, size_t bytes);
+int lsk_free(void *ptr);
+
+/* Stream helpers: replace CUDALibraryContext::get_cuda_stream / CUDAStreamView
+ * (src/CUDAUtilities.cpp:66-75,110-122).  Streams are created at default priority. */
+int lsk_stream_create(lsk_stream_t *stream);
+int lsk_stream_destroy(lsk_stream_t stream);
+int lsk_stream_synchronize(lsk_stream_t stream);
+/* Synchronise the stream and report any pending asynchronous error: CHECK_CUDA_STREAM
+ * (src/CUDAUtilities.hpp:25-29), which the reference runs at task exit in debug builds. */
+int lsk_stream_check(lsk_stream_t stream);
+
+int lsk_memcpy_h2d(void *dst_dev, const void *src_host, size_t bytes, lsk_stream_t stream);
+int lsk_memcpy_d2h(void *dst_host, const void *src_dev, size_t bytes, lsk_stream_t stream);
+int lsk_memcpy_d2d(void *dst_dev, const void *src_dev, size_t bytes, lsk_stream_t stream);
+
+/* ------------------------------------------------------------- get_alpha ------------ */
+/* alpha from 0..4 resolved futures, in the reference's exact operation order
+ * (src/LegionUtilities.cpp:72-97): 0 -> 1; 1 -> f0; 2 -> f0/f1; 3 -> (f0*f1)/f2;
+ * 4 -> (f0*f1)/(f2*f3).  Host function. nf outside 0..4 returns LSK_ERR_ARG. */
+int lsk_get_alpha_f32(int nf, const float *f, float *alpha);
+int lsk_get_alpha_f64(int nf, const double *f, double *alpha);
+
+/* ------------------------------------------------------------- BLAS-1, host alpha --- */
+/* x <- alpha * x.            ScalTask::cuda_task_body (src/LinearAlgebraTasks.cu:14-56),
+ *                            CPU semantics src/LinearAlgebraTasks.cpp:37-43.            */
+int lsk_scal_f32(int64_t n, float alpha, float *x, lsk_stream_t stream);
+int lsk_scal_f64(int64_t n, double alpha, double *x, lsk_stream_t stream);
+
+/* y <- fma(alpha, x, y).     AxpyTask::cuda_task_body (src/LinearAlgebraTasks.cu:59-113),
+ *                            CPU semantics src/LinearAlgebraTasks.cpp:80-87.            */
+int lsk_axpy_f32(int64_t n, float alpha, const float *x, float *y, lsk_stream_t stream);
+int lsk_axpy_f64(int64_t n, double alpha, const double *x, double *y, lsk_stream_t stream);
+
+/* y <- fma(alpha, y, x).     xpay_kernel + XpayTask::cuda_task_body
+ *                            (src/LinearAlgebraTasks.cu:118-176), CPU semantics
+ *                            src/LinearAlgebraTasks.cpp:124-131.                        */
+int lsk_xpay_f32(int64_t n, float alpha, const float *x, float *y, lsk_stream_t stream);
+int lsk_xpay_f64(int64_t n, double alpha, const double *x, double *y, lsk_stream_t stream);
+
+/* N-dimensional xpay over a dense rect with per-array element strides, the case the
+ * reference's xpay_kernel handles through Pitches::unflatten + affine accessors
+ * (src/Pitches.hpp:27-113, src/LinearAlgebraTasks.cu:118-131).  dim in 1..3;
+ * extent[d] points along dimension d; x_stride/y_stride in elements. */
+int lsk_xpay_nd_f32(int dim, const int64_t *extent, float alpha, const float *x,
+                    const int64_t *x_stride, float *y, const int64_t *y_stride,
+                    lsk_stream_t stream);
+int lsk_xpay_nd_f64(int dim, const int64_t *extent, double alpha, const double *x,
+                    const int64_t *x_stride, double *y, const int64_t *y_stride,
+                    lsk_stream_t stream);
+
+/* x[i] <- value / dst <- src: the IndexFillLauncher / IndexCopyLauncher the reference's
+ * PartitionedVector issues (src/PartitionedVector.cpp:151-191). */
+int lsk_fill_f32(int64_t n, float value, float *x, lsk_stream_t stream);
+int lsk_fill_f64(int64_t n, double value, double *x, lsk_stream_t stream);
+int lsk_copy_f32(int64_t n, const float *src, float *dst, lsk_stream_t stream);
+int lsk_copy_f64(int64_t n, const double *src, double *dst, lsk_stream_t stream);
+
+/* ------------------------------------------------------------- dot / nrm2 ----------- */
+/* Bytes of device workspace lsk_dot_* / lsk_nrm2_* need for a vector of n elements. */
+size_t lsk_dot_workspace_bytes(int64_t n);
+
+/* *result_dev <- sum_i v[i]*w[i], left on the device; deterministic (fixed partial tree).
+ * DotTask::cuda_task_body (src/LinearAlgebraTasks.cu:179-238) minus its stream sync.
+ * `workspace` may be NULL: then the per-device scratch made by lsk_init is used, and
+ * calls that overlap on one GPU (different streams) would race on it.
+ * n == 0 writes 0 (the reference returns 0 for an empty domain, .cu:213-214). */
+int lsk_dot_f32(int64_t n, const float *v, const float *w, float *result_dev,
+                void *workspace, size_t workspace_bytes, lsk_stream_t stream);
+int lsk_dot_f64(int64_t n, const double *v, const double *w, double *result_dev,
+                void *workspace, size_t workspace_bytes, lsk_stream_t stream);
+
+/* Same, returning the value to the host after synchronising the stream: the reference's
+ * exact task-body contract (returns ENTRY_T by value, src/LinearAlgebraTasks.cu:222-237). */
+int lsk_dot_host_f32(int64_t n, const float *v, const float *w, float *result_host,
+                     lsk_stream_t stream);
+int lsk_dot_host_f64(int64_t n, const double *v, const double *w, double *result_host,
+                     lsk_stream_t stream);
+
+/* *result_dev <- sqrt(sum_i v[i]^2) in one pass over v.  The reference has no nrm2 task:
+ * its solvers compute dot(v,v) followed by SqrtScalarTask (src/GMRESSolver.hpp:101-103,
+ * src/UtilityTasks.cpp:78-84); this fuses the two. */
+int lsk_nrm2_f32(int64_t n, const float *v, float *result_dev, void *workspace,
+                 size_t workspace_bytes, lsk_stream_t stream);
+int lsk_nrm2_f64(int64_t n, const double *v, double *result_dev, void *workspace,
+                 size_t workspace_bytes, lsk_stream_t stream);
+
+/* ------------------------------------------------- device-resident scalars ---------- */
+/* A Legion::Future<ENTRY_T> becomes one ENTRY_T in HBM written by a stream-ordered kernel,
+ * so a dot result can feed the next axpy without a host round trip (the reference blocks
+ * in Future::get_result inside get_alpha, src/LegionUtilities.cpp:77-92). */
+
+/* Scalar task bodies (src/UtilityTasks.cpp:34-99) as one-thread kernels. */
+#define LSK_SOP_NEG 0   /* out = -a        NegateScalarTask   */
+#define LSK_SOP_ADD 1   /* out = a + b     AddScalarTask      */
+#define LSK_SOP_SUB 2   /* out = a - b     SubtractScalarTask */
+#define LSK_SOP_MUL 3   /* out = a * b     MultiplyScalarTask */
+#define LSK_SOP_DIV 4   /* out = a / b     DivideScalarTask   */
+#define LSK_SOP_SQRT 5  /* out = sqrt(a)   SqrtScalarTask     */
+#define LSK_SOP_RSQRT 6 /* out = 1/sqrt(a) RSqrtScalarTask    */
+#define LSK_SOP_COPY 7  /* out = a                            */
+int lsk_scalar_op_f32(int op, const float *a, const float *b, float *out, lsk_stream_t stream);
+int lsk_scalar_op_f64(int op, const double *a, const double *b, double *out, lsk_stream_t stream);
+
+/* out <- in[0] + in[1] + ... + in[count-1], added left to right: folds the per-piece dot
+ * results of one index launch as Legion's REDOP_SUM future-map reduction does
+ * (src/PartitionedVector.cpp:353-357). */
+int lsk_sum_scalars_f32(int count, const float *in, float *out, lsk_stream_t stream);
+int lsk_sum_scalars_f64(int count, const double *in, double *out, lsk_stream_t stream);
+
+/* BLAS-1 with alpha = get_alpha(nf futures) evaluated on the device from f0..f3
+ * (device pointers; unused ones NULL), same rule and operation order as lsk_get_alpha_*. */
+int lsk_scal_dev_f32(int64_t n, int nf, const float *f0, const float *f1, const float *f2,
+                     const float *f3, float *x, lsk_stream_t stream);
+int lsk_scal_dev_f64(int64_t n, int nf, const double *f0, const double *f1, const double *f2,
+                     const double *f3, double *x, lsk_stream_t stream);
+int lsk_axpy_dev_f32(int64_t n, int nf, const float *f0, const float *f1, const float *f2,
+                     const float *f3, const float *x, float *y, lsk_stream_t stream);
+int lsk_axpy_dev_f64(int64_t n, int nf, const double *f0, const double *f1, const double *f2,
+                     const double *f3, const double *x, double *y, lsk_stream_t stream);
+int lsk_xpay_dev_f32(int64_t n, int nf, const float *f0, const float *f1, const float *f2,
+                     const float *f3, const float *x, float *y, lsk_stream_t stream);
+int lsk_xpay_dev_f64(int64_t n, int nf, const double *f0, const double *f1, const double *f2,
+                     const double *f3, const double *x, double *y, lsk_stream_t stream);
+
+/* ------------------------------------------------------------- CSR SpMV ------------- */
+/* y[r] <- beta*y[r] + sum_{k in rects[r]} val[k] * x[col[k]]   for the shard's rows,
+ * beta in {0, 1}.
+ *
+ * Replaces CSRMatvecTask::cuda_task_body (src/CSRMatrixTasks.cu:14-156: rect->indptr
+ * rebasing kernel + cusparseCreateCsr + cusparseSpMV, beta = 0) and keeps the CPU body's
+ * semantics (src/CSRMatrixTasks.cpp:73-91: accumulate, entries whose column lies outside
+ * the input domain are skipped), selected by `beta`.
+ *
+ *  rows        rows in this shard (volume of the output piece)
+ *  nnz         kernel entries in this shard (volume of the kernel piece)
+ *  rects       rows pairs {lo, hi}, hi inclusive, GLOBAL kernel indices: the reference's
+ *              Legion::Rect<1,long long> rowptr field (16 bytes per row, 16-byte aligned)
+ *  k_base      global kernel index of col[0] / val[0]  (kernel_domain.lo())
+ *  col, val    the shard's kernel piece: column ids (global) and entries
+ *  x           the ghost instance of the input vector; x[0] is global column x_lo and the
+ *              instance covers x_lo..x_hi inclusive (input_domain.bounds)
+ *  y           first row of the shard's output piece
+ *
+ * Rows need not tile the piece contiguously (any {lo,hi} inside the piece is handled);
+ * contiguous row blocks take the fast streaming path.  Empty rows have hi == lo - 1. */
+int lsk_csr_spmv_f32(int64_t rows, int64_t nnz, const int64_t *rects, int64_t k_base,
+                     const int64_t *col, const float *val, const float *x, int64_t x_lo,
+                     int64_t x_hi, float *y, int beta, lsk_stream_t stream);
+int lsk_csr_spmv_f64(int64_t rows, int64_t nnz, const int64_t *rects, int64_t k_base,
+                     const int64_t *col, const double *val, const double *x, int64_t x_lo,
+                     int64_t x_hi, double *y, int beta, lsk_stream_t stream);
+
+/* indptr[i] = rects[i].lo - rects[0].lo for i < rows; indptr[rows] = rects[rows-1].hi + 1
+ * - rects[0].lo.  Bit-exact restatement of convertGlobalRowptrToLocalIndPtr
+ * (src/CuSPARSEHelpers.hpp:9-31) for callers that want a classic CSR offset array; the
+ * SpMV above does not need it. */
+int lsk_rects_to_indptr_i64(int64_t rows, const int64_t *rects, int64_t *indptr,
+                            lsk_stream_t stream);
+
+/* ------------------------------------------------------------- COO SpMV ------------- */
+/* y[row[k]] += val[k] * x[col[k]] for every k of the piece with row[k] in y_lo..y_hi and
+ * col[k] in x_lo..x_hi (global, inclusive).  y[0] is global row y_lo, x[0] global column
+ * x_lo.  Accumulates (beta = 1): the caller zero-fills y first, as SquarePlanner::matvec
+ * does (src/SquarePlanner.hpp:340-357).
+ *
+ * Replaces COOMatvecTask::cuda_task_body (src/COOMatrixTasks.cu:12-146: cusparseCreateCoo +
+ * cusparseSpMV on shifted x and y pointers) with the CPU body's guards
+ * (src/COOMatrixTasks.cpp:67-74).  Any entry order is accepted; row-sorted input runs
+ * fastest (runs of equal rows are summed on chip before one atomic add). */
+int lsk_coo_spmv_f32(int64_t nnz, const int64_t *row, const int64_t *col, const float *val,
+                     const float *x, int64_t x_lo, int64_t x_hi, float *y, int64_t y_lo,
+                     int64_t y_hi, lsk_stream_t stream);
+int lsk_coo_spmv_f64(int64_t nnz, const int64_t *row, const int64_t *col, const double *val,
+                     const double *x, int64_t x_lo, int64_t x_hi, double *y, int64_t y_lo,
+                     int64_t y_hi, lsk_stream_t stream);
+
+/* ------------------------------------------------ set-up helpers (device side) ------ */
+/* out[0] = min idx[i], out[1] = max idx[i] (out = {INT64_MAX, INT64_MIN} when n == 0):
+ * the bounding interval of create_partition_by_image over a column field
+ * (src/CSRMatrix.cpp:112-132, src/COOMatrix.cpp), i.e. the ghost range of a shard. */
+int lsk_index_bounds_i64(int64_t n, const int64_t *idx, int64_t *out_minmax,
+                         lsk_stream_t stream);
+
+/* Linearised stencil matrices, bit-identical to FillLinearizedCSRStencilTask /
+ * FillLinearizedCOOStencilTask with IndexOrder::ROW_MAJOR (src/StencilGenerator.cpp:129-242,
+ * 379-517): grid bounds [0,extent[d]) in `dim` (1..3) dimensions, row id = row-major
+ * linearisation, `noffsets` (<= 32) offsets already sorted lexicographically with their
+ * coefficients; an entry exists where point+offset stays inside the grid.
+ *
+ * lsk_stencil_count: counts[r - row_lo] = entries of row r, for r in row_lo..row_hi.
+ * lsk_stencil_fill_csr: given rects (global k, from a prefix sum of the counts) writes
+ *   col[k - k_base], val[k - k_base] for the rows row_lo..row_hi.
+ * lsk_stencil_fill_coo: same, plus row[k - k_base]. */
+int lsk_stencil_count(int dim, const int64_t *extent, int noffsets, const int64_t *offsets,
+                      int64_t row_lo, int64_t row_hi, int64_t *counts, lsk_stream_t stream);
+int lsk_stencil_fill_csr_f32(int dim, const int64_t *extent, int noffsets,
+                             const int64_t *offsets, const float *coeffs, int64_t row_lo,
+                             int64_t row_hi, const int64_t *rects, int64_t k_base,
+                             int64_t *col, float *val, lsk_stream_t stream);
+int lsk_stencil_fill_csr_f64(int dim, const int64_t *extent, int noffsets,
+                             const int64_t *offsets, const double *coeffs, int64_t row_lo,
+                             int64_t row_hi, const int64_t *rects, int64_t k_base,
+                             int64_t *col, double *val, lsk_stream_t stream);
+int lsk_stencil_fill_coo_f32(int dim, const int64_t *extent, int noffsets,
+                             const int64_t *offsets, const float *coeffs, int64_t row_lo,
+                             int64_t row_hi, const int64_t *rects, int64_t k_base,
+                             int64_t *row, int64_t *col, float *val, lsk_stream_t stream);
+int lsk_stencil_fill_coo_f64(int dim, const int64_t *extent, int noffsets,
+                             const int64_t *offsets, const double *coeffs, int64_t row_lo,
+                             int64_t row_hi, const int64_t *rects, int64_t k_base,
+                             int64_t *row, int64_t *col, double *val, lsk_stream_t stream);
+
+/* rects[i] = {base + prefix[i], base + prefix[i] + counts[i] - 1} where prefix is the
+ * exclusive prefix sum of counts given as `prefix_incl[i] = counts[0]+...+counts[i]`
+ * (the row_begin/row_end rule of src/StencilGenerator.cpp:494-511). */
+int lsk_rects_from_counts_i64(int64_t rows, const int64_t *counts, const int64_t *prefix_incl,
+                              int64_t base, int64_t *rects, lsk_stream_t stream);
+
+/* ------------------------------------------------------------- task ids ------------- */
+/* Task-id arithmetic of src/TaskBaseClasses.hpp (origin 500000, NUM_META_TASK_IDS = 1,
+ * block size 3*27*64 = 5184; entry index float 0 / double 1; index-type index int 0 /
+ * unsigned 1 / long long 2).  Host functions, bit-exact. */
+int64_t lsk_task_id_t(int block_id, int entry_index);                 /* :100-103 */
+int64_t lsk_task_id_di(int block_id, int dim, int index_type_index);  /* :161-165 */
+int64_t lsk_task_id_tdi(int block_id, int entry_index, int dim, int index_type_index); /* :236-242 */
+int64_t lsk_task_id_tdddiii(int block_id, int entry_index, int n1, int n2, int n3, int i1,
+                            int i2, int i3);                          /* :330-350 */
+
+/* ------------------------------------------------------------- RCCL layer ----------- */
+/* One communicator per process (one process or one Legion GPU processor per MI355X).  The
+ * reference has no NCCL/MPI call sites: the dot all-reduce is Legion's REDOP_SUM future
+ * map (src/PartitionedVector.cpp:353-357) and the halo gather is the READ_ONLY ghost
+ * partition requirement (src/CSRMatrix.cpp:202-211); these calls do both on the task's
+ * stream over xGMI. */
+typedef struct lsk_comm *lsk_comm_t;
+#define LSK_UNIQUE_ID_BYTES 128
+int lsk_comm_unique_id(void *id_out /* LSK_UNIQUE_ID_BYTES */);
+int lsk_comm_init_rank(lsk_comm_t *comm, int nranks, int rank, const void *id);
+int lsk_comm_destroy(lsk_comm_t comm);
+int lsk_comm_rank(lsk_comm_t comm, int *rank, int *nranks);
+/* In-place sum over ranks of `count` scalars at buf (device). */
+int lsk_allreduce_sum_f32(lsk_comm_t comm, float *buf, int count, lsk_stream_t stream);
+int lsk_allreduce_sum_f64(lsk_comm_t comm, double *buf, int count, lsk_stream_t stream);
+/* Point-to-point halo exchange, grouped into one RCCL group: for i < nsend send
+ * send_count[i] elements at send_ptr[i] to send_peer[i]; same for receives. */
+int lsk_halo_exchange_f32(lsk_comm_t comm, int nsend, const int *send_peer,
+                          const float *const *send_ptr, const int64_t *send_count, int nrecv,
+                          const int *recv_peer, float *const *recv_ptr,
+                          const int64_t *recv_count, lsk_stream_t stream);
+int lsk_halo_exchange_f64(lsk_comm_t comm, int nsend, const int *send_peer,
+                          const double *const *send_ptr, const int64_t *send_count, int nrecv,
+                          const int *recv_peer, double *const *recv_ptr,
+                          const int64_t *recv_count, lsk_stream_t stream);
+/* recv[rank*count .. ] <- every rank's `count` elements at send (x all-gather for
+ * unstructured matrices whose ghost range is all of x). */
+int lsk_allgather_f32(lsk_comm_t comm, const float *send, float *recv, int64_t count,
+                      lsk_stream_t stream);
+int lsk_allgather_f64(lsk_comm_t comm, const double *send, double *recv, int64_t count,
+                      lsk_stream_t stream);
+
+#ifdef __cplusplus
+} /* extern "C" */
+#endif
+
+#endif /* LSK_H_INCLUDED */

@@ -1,0 +1,149 @@
+"""ctypes binding of liblsk.so (the C ABI declared in include/lsk.h).
+
+There is no CPU fallback: if the library is missing, importing the product path raises.
+torch is imported first on purpose: liblsk.so needs libamdhip64.so.7 / librccl.so.1, and the
+dynamic loader must hand it the copies torch already mapped, so that pointers and streams made
+by torch are valid inside the library (one HIP runtime per process).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import re
+
+import torch  # noqa: F401  (must precede the CDLL below, see module docstring)
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG_DIR, "liblsk.so")
+HEADER_PATH = os.path.join(os.path.dirname(PKG_DIR), "include", "lsk.h")
+
+LSK_OK = 0
+UNIQUE_ID_BYTES = 128
+
+SOP_NEG, SOP_ADD, SOP_SUB, SOP_MUL, SOP_DIV, SOP_SQRT, SOP_RSQRT, SOP_COPY = range(8)
+
+
+class LskError(RuntimeError):
+    """A C-ABI call returned a non-zero status; the message is lsk_last_error()."""
+
+    def __init__(self, code: int, message: str):
+        super().__init__(f"lsk error {code}: {message}")
+        self.code = code
+
+
+_i = ctypes.c_int
+_i64 = ctypes.c_int64
+_sz = ctypes.c_size_t
+_p = ctypes.c_void_p
+_f32 = ctypes.c_float
+_f64 = ctypes.c_double
+
+
+def _typed(suffix_types, make):
+    out = {}
+    for suf, ct in suffix_types:
+        out.update(make(suf, ct))
+    return out
+
+
+_FT = (("f32", _f32), ("f64", _f64))
+
+# name -> (restype, argtypes)
+PROTOTYPES = {
+    "lsk_version": (ctypes.c_char_p, []),
+    "lsk_last_error": (ctypes.c_char_p, []),
+    "lsk_set_abort_on_error": (None, [_i]),
+    "lsk_device_count": (_i, [ctypes.POINTER(_i)]),
+    "lsk_init": (_i, [_i]),
+    "lsk_malloc": (_i, [ctypes.POINTER(_p), _sz]),
+    "lsk_free": (_i, [_p]),
+    "lsk_stream_create": (_i, [ctypes.POINTER(_p)]),
+    "lsk_stream_destroy": (_i, [_p]),
+    "lsk_stream_synchronize": (_i, [_p]),
+    "lsk_stream_check": (_i, [_p]),
+    "lsk_memcpy_h2d": (_i, [_p, _p, _sz, _p]),
+    "lsk_memcpy_d2h": (_i, [_p, _p, _sz, _p]),
+    "lsk_memcpy_d2d": (_i, [_p, _p, _sz, _p]),
+    "lsk_dot_workspace_bytes": (_sz, [_i64]),
+    "lsk_rects_to_indptr_i64": (_i, [_i64, _p, _p, _p]),
+    "lsk_index_bounds_i64": (_i, [_i64, _p, _p, _p]),
+    "lsk_stencil_count": (_i, [_i, _p, _i, _p, _i64, _i64, _p, _p]),
+    "lsk_rects_from_counts_i64": (_i, [_i64, _p, _p, _i64, _p, _p]),
+    "lsk_task_id_t": (_i64, [_i, _i]),
+    "lsk_task_id_di": (_i64, [_i, _i, _i]),
+    "lsk_task_id_tdi": (_i64, [_i, _i, _i, _i]),
+    "lsk_task_id_tdddiii": (_i64, [_i] * 8),
+    "lsk_comm_unique_id": (_i, [_p]),
+    "lsk_comm_init_rank": (_i, [ctypes.POINTER(_p), _i, _i, _p]),
+    "lsk_comm_destroy": (_i, [_p]),
+    "lsk_comm_rank": (_i, [_p, ctypes.POINTER(_i), ctypes.POINTER(_i)]),
+}
+PROTOTYPES.update(_typed(_FT, lambda s, t: {
+    f"lsk_get_alpha_{s}": (_i, [_i, _p, _p]),
+    f"lsk_scal_{s}": (_i, [_i64, t, _p, _p]),
+    f"lsk_axpy_{s}": (_i, [_i64, t, _p, _p, _p]),
+    f"lsk_xpay_{s}": (_i, [_i64, t, _p, _p, _p]),
+    f"lsk_xpay_nd_{s}": (_i, [_i, _p, t, _p, _p, _p, _p, _p]),
+    f"lsk_fill_{s}": (_i, [_i64, t, _p, _p]),
+    f"lsk_copy_{s}": (_i, [_i64, _p, _p, _p]),
+    f"lsk_dot_{s}": (_i, [_i64, _p, _p, _p, _p, _sz, _p]),
+    f"lsk_dot_host_{s}": (_i, [_i64, _p, _p, _p, _p]),
+    f"lsk_nrm2_{s}": (_i, [_i64, _p, _p, _p, _sz, _p]),
+    f"lsk_scalar_op_{s}": (_i, [_i, _p, _p, _p, _p]),
+    f"lsk_sum_scalars_{s}": (_i, [_i, _p, _p, _p]),
+    f"lsk_scal_dev_{s}": (_i, [_i64, _i, _p, _p, _p, _p, _p, _p]),
+    f"lsk_axpy_dev_{s}": (_i, [_i64, _i, _p, _p, _p, _p, _p, _p, _p]),
+    f"lsk_xpay_dev_{s}": (_i, [_i64, _i, _p, _p, _p, _p, _p, _p, _p]),
+    f"lsk_csr_spmv_{s}": (_i, [_i64, _i64, _p, _i64, _p, _p, _p, _i64, _i64, _p, _i, _p]),
+    f"lsk_coo_spmv_{s}": (_i, [_i64, _p, _p, _p, _p, _i64, _i64, _p, _i64, _i64, _p]),
+    f"lsk_stencil_fill_csr_{s}": (_i, [_i, _p, _i, _p, _p, _i64, _i64, _p, _i64, _p, _p, _p]),
+    f"lsk_stencil_fill_coo_{s}": (_i, [_i, _p, _i, _p, _p, _i64, _i64, _p, _i64, _p, _p, _p, _p]),
+    f"lsk_allreduce_sum_{s}": (_i, [_p, _p, _i, _p]),
+    f"lsk_halo_exchange_{s}": (_i, [_p, _i, _p, _p, _p, _i, _p, _p, _p, _p]),
+    f"lsk_allgather_{s}": (_i, [_p, _p, _p, _i64, _p]),
+}))
+
+
+def declared_symbols(header_path: str = HEADER_PATH) -> list:
+    """Names of every function include/lsk.h declares."""
+    text = open(header_path).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(lsk_[a-z0-9_]+)\s*\(", text)))
+
+
+_lib = None
+
+
+def lib() -> ctypes.CDLL:
+    """The loaded library; raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: the HIP extension is not built and there is no CPU "
+                "fallback. Run `python -m legionsolvers_amd.build` (or __graft_entry__.build()).")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (restype, argtypes) in PROTOTYPES.items():
+            fn = getattr(handle, name)
+            fn.restype = restype
+            fn.argtypes = argtypes
+        _lib = handle
+    return _lib
+
+
+def check(code: int) -> None:
+    if code != LSK_OK:
+        raise LskError(code, lib().lsk_last_error().decode(errors="replace"))
+
+
+def suffix(dtype: torch.dtype) -> str:
+    if dtype == torch.float64:
+        return "f64"
+    if dtype == torch.float32:
+        return "f32"
+    raise TypeError(f"entry type {dtype} is not supported (float32 / float64 only)")
+
+
+def call(name: str, *args) -> None:
+    """Call a status-returning entry point and raise on failure."""
+    check(getattr(lib(), name)(*args))

@@ -1,0 +1,123 @@
+"""Leaf-operation backend: every vector, matrix and scalar operation of the host mirror ends
+in one method here, and each method is one call through the C ABI of include/lsk.h on raw
+device pointers and the current torch stream.
+
+`HipBackend` is the only backend the package contains.  It refuses to exist without a GPU
+and the built library: there is no CPU fallback in the product path.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Sequence, Tuple
+
+import torch
+
+from . import _lib
+
+
+def _ptr(t) -> ctypes.c_void_p:
+    return ctypes.c_void_p(0 if t is None else t.data_ptr())
+
+
+class HipBackend:
+    name = "hip"
+
+    def __init__(self, device: torch.device):
+        if not torch.cuda.is_available():
+            raise RuntimeError("HipBackend needs a GPU: torch.cuda.is_available() is False and "
+                               "there is no CPU fallback")
+        self.lib = _lib.lib()
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError(f"HipBackend needs a cuda (HIP) device, got {self.device}")
+        index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self.device = torch.device("cuda", index)
+        torch.cuda.set_device(index)
+        _lib.check(self.lib.lsk_init(index))
+        # Partial sums of dot/nrm2: private to this backend so that other users of the
+        # library's per-device scratch cannot race with it.
+        self._ws_bytes = int(self.lib.lsk_dot_workspace_bytes(0))
+        self._ws = torch.empty(self._ws_bytes, dtype=torch.uint8, device=self.device)
+
+    # -- plumbing ------------------------------------------------------------------------
+    def stream(self) -> ctypes.c_void_p:
+        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def empty(self, n: int, dtype: torch.dtype) -> torch.Tensor:
+        return torch.empty(int(n), dtype=dtype, device=self.device)
+
+    def new_scalar(self, value, dtype: torch.dtype) -> torch.Tensor:
+        return torch.full((1,), value, dtype=dtype, device=self.device)
+
+    def synchronize(self) -> None:
+        torch.cuda.current_stream(self.device).synchronize()
+
+    # -- BLAS-1 ----------------------------------------------------------------------------
+    @staticmethod
+    def _futs(futs: Sequence[torch.Tensor]):
+        if len(futs) > 4:
+            raise ValueError("alpha takes at most 4 futures")
+        ptrs = [_ptr(f) for f in futs] + [ctypes.c_void_p(0)] * (4 - len(futs))
+        return ctypes.c_int(len(futs)), ptrs
+
+    def fill(self, x: torch.Tensor, value) -> None:
+        _lib.call(f"lsk_fill_{_lib.suffix(x.dtype)}", x.numel(), value, _ptr(x), self.stream())
+
+    def copy(self, dst: torch.Tensor, src: torch.Tensor) -> None:
+        _lib.call(f"lsk_copy_{_lib.suffix(dst.dtype)}", dst.numel(), _ptr(src), _ptr(dst), self.stream())
+
+    def scal(self, x: torch.Tensor, futs) -> None:
+        nf, p = self._futs(futs)
+        _lib.call(f"lsk_scal_dev_{_lib.suffix(x.dtype)}", x.numel(), nf, *p, _ptr(x), self.stream())
+
+    def axpy(self, y: torch.Tensor, futs, x: torch.Tensor) -> None:
+        nf, p = self._futs(futs)
+        _lib.call(f"lsk_axpy_dev_{_lib.suffix(y.dtype)}", y.numel(), nf, *p, _ptr(x), _ptr(y), self.stream())
+
+    def xpay(self, y: torch.Tensor, futs, x: torch.Tensor) -> None:
+        nf, p = self._futs(futs)
+        _lib.call(f"lsk_xpay_dev_{_lib.suffix(y.dtype)}", y.numel(), nf, *p, _ptr(x), _ptr(y), self.stream())
+
+    def dot(self, v: torch.Tensor, w: torch.Tensor, out: torch.Tensor) -> None:
+        _lib.call(f"lsk_dot_{_lib.suffix(v.dtype)}", v.numel(), _ptr(v), _ptr(w), _ptr(out),
+                  _ptr(self._ws), self._ws_bytes, self.stream())
+
+    def sum_scalars(self, inp: torch.Tensor, out: torch.Tensor) -> None:
+        _lib.call(f"lsk_sum_scalars_{_lib.suffix(inp.dtype)}", inp.numel(), _ptr(inp), _ptr(out), self.stream())
+
+    def scalar_op(self, op: int, a: torch.Tensor, b, out: torch.Tensor) -> None:
+        _lib.call(f"lsk_scalar_op_{_lib.suffix(a.dtype)}", op, _ptr(a), _ptr(b), _ptr(out), self.stream())
+
+    # -- SpMV ------------------------------------------------------------------------------
+    def csr_spmv(self, rows: int, nnz: int, rects: torch.Tensor, k_base: int, col: torch.Tensor,
+                 val: torch.Tensor, x: torch.Tensor, x_lo: int, x_hi: int, y: torch.Tensor,
+                 beta: int) -> None:
+        _lib.call(f"lsk_csr_spmv_{_lib.suffix(val.dtype)}", rows, nnz, _ptr(rects), k_base, _ptr(col),
+                  _ptr(val), _ptr(x), x_lo, x_hi, _ptr(y), beta, self.stream())
+
+    def coo_spmv(self, nnz: int, row: torch.Tensor, col: torch.Tensor, val: torch.Tensor,
+                 x: torch.Tensor, x_lo: int, x_hi: int, y: torch.Tensor, y_lo: int, y_hi: int) -> None:
+        _lib.call(f"lsk_coo_spmv_{_lib.suffix(val.dtype)}", nnz, _ptr(row), _ptr(col), _ptr(val),
+                  _ptr(x), x_lo, x_hi, _ptr(y), y_lo, y_hi, self.stream())
+
+    # -- set-up ------------------------------------------------------------------------------
+    def index_bounds(self, idx: torch.Tensor) -> Tuple[int, int]:
+        """(min, max) of an index field; (0, -1) when it is empty.  Synchronises."""
+        if idx.numel() == 0:
+            return (0, -1)
+        out = torch.empty(2, dtype=torch.int64, device=self.device)
+        _lib.call("lsk_index_bounds_i64", idx.numel(), _ptr(idx), _ptr(out), self.stream())
+        lo, hi = out.tolist()
+        return int(lo), int(hi)
+
+    def rect_bounds(self, rects: torch.Tensor) -> Tuple[int, int]:
+        """Bounding kernel interval of a block of row rects (rows, 2): the image-range of
+        create_partition_by_image_range (src/CSRMatrix.cpp:89-109); (0, -1) if all rows are
+        empty.  Set-up time only; synchronises."""
+        if rects.numel() == 0:
+            return (0, -1)
+        lo, hi = rects[:, 0], rects[:, 1]
+        live = hi >= lo
+        if not bool(live.any()):
+            return (0, -1)
+        return int(lo[live].min().item()), int(hi[live].max().item())

@@ -1,0 +1,114 @@
+"""Cross-rank data movement of the Krylov path: the scalar all-reduce behind `dot` and the
+halo gather of `x` behind `matvec`.
+
+In the reference both are implicit in Legion (a REDOP_SUM future map,
+src/PartitionedVector.cpp:353-357; a READ_ONLY requirement on the ghost partition,
+src/CSRMatrix.cpp:202-211).  Here one process drives one MI355X and `torch.distributed`
+carries them: backend "nccl" is RCCL over xGMI on the GPUs, "gloo" runs the same code on CPU
+tensors for tests.  The plan arithmetic (who sends which interval to whom) is pure host code.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+@dataclass(frozen=True)
+class Transfer:
+    """`count` elements starting at global index `start`, exchanged with rank `peer`."""
+    peer: int
+    start: int
+    count: int
+
+
+@dataclass
+class HaloPlan:
+    """For one (matrix, rank): the pieces of x to receive into the halo and to send away."""
+    own: Tuple[int, int]      # interval this rank owns
+    ghost: Tuple[int, int]    # interval its kernel pieces read (superset of what is needed)
+    recvs: List[Transfer]
+    sends: List[Transfer]
+
+    @property
+    def pad_lo(self) -> int:
+        return max(self.own[0] - self.ghost[0], 0) if self.ghost[1] >= self.ghost[0] else 0
+
+    @property
+    def pad_hi(self) -> int:
+        return max(self.ghost[1] - self.own[1], 0) if self.ghost[1] >= self.ghost[0] else 0
+
+
+def _intersect(a: Tuple[int, int], b: Tuple[int, int]) -> Tuple[int, int]:
+    return max(a[0], b[0]), min(a[1], b[1])
+
+
+def build_halo_plan(rank: int, owns: Sequence[Tuple[int, int]],
+                    ghosts: Sequence[Tuple[int, int]]) -> HaloPlan:
+    """owns[q] / ghosts[q]: owned and ghost intervals of every rank q (inclusive; an empty
+    interval has hi < lo).  Rank `rank` receives from q the part of its ghost interval that q
+    owns, and sends to q the part of q's ghost interval that it owns itself."""
+    me_own, me_ghost = owns[rank], ghosts[rank]
+    recvs, sends = [], []
+    for q in range(len(owns)):
+        if q == rank:
+            continue
+        lo, hi = _intersect(me_ghost, owns[q])
+        if hi >= lo:
+            recvs.append(Transfer(q, lo, hi - lo + 1))
+        lo, hi = _intersect(ghosts[q], me_own)
+        if hi >= lo:
+            sends.append(Transfer(q, lo, hi - lo + 1))
+    return HaloPlan(me_own, me_ghost, recvs, sends)
+
+
+class Communicator:
+    """Thin wrapper over a torch.distributed process group (or a single process)."""
+
+    def __init__(self, group: Optional[dist.ProcessGroup] = None):
+        self.group = group
+        if dist.is_available() and dist.is_initialized():
+            self.rank = dist.get_rank(group)
+            self.world_size = dist.get_world_size(group)
+        else:
+            self.rank, self.world_size = 0, 1
+
+    # -- set-up time (host values) -----------------------------------------------------
+    def all_gather_object(self, obj):
+        if self.world_size == 1:
+            return [obj]
+        out = [None] * self.world_size
+        dist.all_gather_object(out, obj, group=self.group)
+        return out
+
+    def barrier(self):
+        if self.world_size > 1:
+            dist.barrier(group=self.group)
+
+    # -- per step, on the tensors' device and stream -------------------------------------
+    def all_reduce_sum(self, t: torch.Tensor) -> None:
+        """In-place sum over ranks (the dot all-reduce; 1..k scalars)."""
+        if self.world_size > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+
+    def exchange(self, sends: Sequence[Tuple[int, torch.Tensor]],
+                 recvs: Sequence[Tuple[int, torch.Tensor]]) -> None:
+        """Grouped point-to-point exchange: (peer, contiguous tensor view) pairs.  Receives
+        are posted in ascending peer order and sends likewise, so that both sides of every
+        pair agree on the order of the operations between them."""
+        if self.world_size == 1 or (not sends and not recvs):
+            return
+        ops = []
+        for peer, t in sorted(recvs, key=lambda it: it[0]):
+            ops.append(dist.P2POp(dist.irecv, t, self._global_rank(peer), group=self.group))
+        for peer, t in sorted(sends, key=lambda it: it[0]):
+            ops.append(dist.P2POp(dist.isend, t, self._global_rank(peer), group=self.group))
+        for work in dist.batch_isend_irecv(ops):
+            work.wait()
+
+    def _global_rank(self, group_rank: int) -> int:
+        if self.group is None:
+            return group_rank
+        return dist.get_global_rank(self.group, group_rank)

@@ -1,0 +1,37 @@
+"""Context: what the reference threads through every class as `(Legion::Context, Runtime*)`.
+
+It names this process's GPU, the leaf backend that launches on it, and the communicator that
+joins it to the other shards' processes.  One process drives one MI355X.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from .comm import Communicator
+
+
+class Context:
+    def __init__(self, device: Optional[torch.device] = None, group=None, backend=None):
+        self.comm = Communicator(group)
+        if backend is None:
+            from .backend import HipBackend
+            if device is None:
+                if not torch.cuda.is_available():
+                    raise RuntimeError("no GPU visible: the Krylov path has no CPU fallback")
+                device = torch.device("cuda", torch.cuda.current_device())
+            backend = HipBackend(device)
+        self.backend = backend
+        self.device = backend.device
+
+    @property
+    def rank(self) -> int:
+        return self.comm.rank
+
+    @property
+    def world_size(self) -> int:
+        return self.comm.world_size
+
+    def synchronize(self) -> None:
+        self.backend.synchronize()

@@ -1,0 +1,468 @@
+// BLAS-1 leaf kernels for gfx950: scal / axpy / xpay / fill / copy, dot / nrm2, the scalar
+// "future" ops, and the N-D strided xpay.  All are HBM-bound streams: 16 bytes per lane per
+// access, four independent accesses in flight per lane, grid capped at 8 workgroups per CU
+// and grid-strided.
+//
+// Arithmetic follows the reference's CPU leaf tasks (src/LinearAlgebraTasks.cpp:37-43,
+// 80-87, 124-131): scal is one multiply, axpy is fma(alpha, x, y), xpay is fma(alpha, y, x),
+// so element results are bit-identical to the CPU path.
+#include "lsk_common.hpp"
+
+namespace {
+
+using lsk::kBlock;
+
+enum Op { OP_SCAL = 0, OP_AXPY = 1, OP_XPAY = 2, OP_FILL = 3, OP_COPY = 4 };
+
+// alpha either by value (nf < 0) or as 0..4 device-resident futures combined with the
+// get_alpha rule (src/LegionUtilities.cpp:72-97).
+template <typename T>
+struct Alpha {
+    int nf;
+    T host;
+    const T *f0, *f1, *f2, *f3;
+};
+
+template <typename T>
+__device__ __forceinline__ T resolve_alpha(const Alpha<T> &a) {
+    switch (a.nf) {
+    case 0: return static_cast<T>(1);
+    case 1: return *a.f0;
+    case 2: return *a.f0 / *a.f1;
+    case 3: return (*a.f0 * *a.f1) / *a.f2;
+    case 4: return (*a.f0 * *a.f1) / (*a.f2 * *a.f3);
+    default: return a.host;
+    }
+}
+
+template <typename T> struct Vec;
+template <> struct Vec<double> { using type = double2; static constexpr int N = 2; };
+template <> struct Vec<float> { using type = float4; static constexpr int N = 4; };
+
+__device__ __forceinline__ double fma_t(double a, double b, double c) { return __builtin_fma(a, b, c); }
+__device__ __forceinline__ float fma_t(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
+template <typename T, int OP>
+__device__ __forceinline__ T apply(T alpha, T x, T y) {
+    if constexpr (OP == OP_SCAL) return alpha * y;
+    if constexpr (OP == OP_AXPY) return fma_t(alpha, x, y);
+    if constexpr (OP == OP_XPAY) return fma_t(alpha, y, x);
+    if constexpr (OP == OP_FILL) return alpha;
+    return x; // OP_COPY
+}
+
+template <typename T, int OP>
+__device__ __forceinline__ double2 apply_v(T alpha, double2 x, double2 y) {
+    return double2{apply<double, OP>(alpha, x.x, y.x), apply<double, OP>(alpha, x.y, y.y)};
+}
+template <typename T, int OP>
+__device__ __forceinline__ float4 apply_v(T alpha, float4 x, float4 y) {
+    return float4{apply<float, OP>(alpha, x.x, y.x), apply<float, OP>(alpha, x.y, y.y),
+                  apply<float, OP>(alpha, x.z, y.z), apply<float, OP>(alpha, x.w, y.w)};
+}
+
+constexpr bool reads_x(int op) { return op == OP_AXPY || op == OP_XPAY || op == OP_COPY; }
+constexpr bool reads_y(int op) { return op == OP_SCAL || op == OP_AXPY || op == OP_XPAY; }
+
+// E = element type of one access: the 16-byte vector when every pointer is 16-byte aligned,
+// else the scalar.  x and y are not declared restrict: y == x is a legal call.
+template <typename T, int OP, typename E, int EN>
+__global__ __launch_bounds__(kBlock) void ew_kernel(int64_t n, Alpha<T> a, const T *x, T *y) {
+    const T alpha = resolve_alpha(a);
+    const int64_t ne = n / EN;
+    const E *xe = reinterpret_cast<const E *>(x);
+    E *ye = reinterpret_cast<E *>(y);
+    const int64_t stride = int64_t(gridDim.x) * kBlock;
+    int64_t i = int64_t(blockIdx.x) * kBlock + threadIdx.x;
+    const bool first = (i == 0);
+
+    for (; i + 3 * stride < ne; i += 4 * stride) {
+        E xv[4], yv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if constexpr (reads_x(OP)) xv[u] = xe[i + u * stride]; else xv[u] = E{};
+            if constexpr (reads_y(OP)) yv[u] = ye[i + u * stride]; else yv[u] = E{};
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if constexpr (EN == 1) ye[i + u * stride] = apply<T, OP>(alpha, xv[u], yv[u]);
+            else ye[i + u * stride] = apply_v<T, OP>(alpha, xv[u], yv[u]);
+        }
+    }
+    for (; i < ne; i += stride) {
+        E xv{}, yv{};
+        if constexpr (reads_x(OP)) xv = xe[i];
+        if constexpr (reads_y(OP)) yv = ye[i];
+        if constexpr (EN == 1) ye[i] = apply<T, OP>(alpha, xv, yv);
+        else ye[i] = apply_v<T, OP>(alpha, xv, yv);
+    }
+    if (EN > 1 && first) { // the n % EN trailing elements
+        for (int64_t j = ne * EN; j < n; ++j) {
+            T xs = T(0), ys = T(0);
+            if constexpr (reads_x(OP)) xs = x[j];
+            if constexpr (reads_y(OP)) ys = y[j];
+            y[j] = apply<T, OP>(alpha, xs, ys);
+        }
+    }
+}
+
+inline int stream_grid(int64_t accesses) {
+    int64_t blocks = lsk::ceil_div(accesses, int64_t(kBlock) * 4);
+    if (blocks < 1) blocks = 1;
+    if (blocks > lsk::kMaxGridBlocks) blocks = lsk::kMaxGridBlocks;
+    return static_cast<int>(blocks);
+}
+
+template <typename T, int OP>
+int launch_ew(const char *name, int64_t n, Alpha<T> a, const T *x, T *y, lsk_stream_t stream) {
+    if (n < 0) return lsk::fail(LSK_ERR_ARG, "%s: negative length %lld", name, (long long)n);
+    if (n == 0) return LSK_OK; // "If there are no points to process, exit." (.cu:40-41)
+    if (!y || (reads_x(OP) && !x)) return lsk::fail(LSK_ERR_ARG, "%s: null vector", name);
+    if (a.nf > 4) return lsk::fail(LSK_ERR_ARG, "%s: %d futures (0..4 allowed)", name, a.nf);
+    const T *fs[4] = {a.f0, a.f1, a.f2, a.f3};
+    for (int i = 0; i < a.nf; ++i)
+        if (!fs[i]) return lsk::fail(LSK_ERR_ARG, "%s: future %d is null", name, i);
+    using V = typename Vec<T>::type;
+    constexpr int VN = Vec<T>::N;
+    const bool vec = lsk::aligned16(y) && (!reads_x(OP) || lsk::aligned16(x));
+    hipStream_t s = lsk::as_stream(stream);
+    if (vec) {
+        ew_kernel<T, OP, V, VN><<<stream_grid(n / VN + 1), kBlock, 0, s>>>(n, a, x, y);
+    } else {
+        ew_kernel<T, OP, T, 1><<<stream_grid(n), kBlock, 0, s>>>(n, a, x, y);
+    }
+    LSK_LAUNCH_CHECK();
+    return LSK_OK;
+}
+
+template <typename T>
+Alpha<T> host_alpha(T v) { return Alpha<T>{-1, v, nullptr, nullptr, nullptr, nullptr}; }
+
+template <typename T>
+Alpha<T> dev_alpha(int nf, const T *f0, const T *f1, const T *f2, const T *f3) {
+    return Alpha<T>{nf < 0 ? 5 : nf, T(0), f0, f1, f2, f3}; // nf < 0 is rejected as > 4
+}
+
+// ------------------------------------------------------------------ dot / nrm2 -------
+
+enum Finish { FIN_NONE = 0, FIN_SQRT = 1 };
+
+template <typename T>
+__device__ __forceinline__ T finish(T v, int fin) {
+    if (fin == FIN_SQRT) return sqrt(v);
+    return v;
+}
+
+// Sum of the block's values, valid in thread 0.  Order: butterfly inside each wave, then
+// waves 0..3 left to right; fixed for a given launch shape, so results are reproducible.
+template <typename T>
+__device__ __forceinline__ T block_sum(T v) {
+    __shared__ T s_wave[kBlock / lsk::kWave];
+    v = lsk::wave_sum(v);
+    const int lane = threadIdx.x % lsk::kWave, wave = threadIdx.x / lsk::kWave;
+    if (lane == 0) s_wave[wave] = v;
+    __syncthreads();
+    T total = T(0);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int w = 0; w < kBlock / lsk::kWave; ++w) total += s_wave[w];
+    }
+    return total;
+}
+
+template <typename T> __device__ __forceinline__ T dot_v(double2 a, double2 b, T acc) {
+    acc = fma_t(a.x, b.x, acc);
+    return fma_t(a.y, b.y, acc);
+}
+template <typename T> __device__ __forceinline__ T dot_v(float4 a, float4 b, T acc) {
+    acc = fma_t(a.x, b.x, acc);
+    acc = fma_t(a.y, b.y, acc);
+    acc = fma_t(a.z, b.z, acc);
+    return fma_t(a.w, b.w, acc);
+}
+template <typename T> __device__ __forceinline__ T dot_v(T a, T b, T acc) { return fma_t(a, b, acc); }
+
+// SAME: w is v (dot(v,v), nrm2): the vector is read once.
+template <typename T, typename E, int EN, bool SAME>
+__global__ __launch_bounds__(kBlock) void dot_kernel(int64_t n, const T *__restrict__ v,
+                                                     const T *__restrict__ w,
+                                                     T *__restrict__ out, int fin) {
+    const int64_t ne = n / EN;
+    const E *ve = reinterpret_cast<const E *>(v);
+    const E *we = reinterpret_cast<const E *>(w);
+    const int64_t stride = int64_t(gridDim.x) * kBlock;
+    int64_t i = int64_t(blockIdx.x) * kBlock + threadIdx.x;
+    const bool first = (i == 0);
+    T acc[4] = {T(0), T(0), T(0), T(0)};
+    for (; i + 3 * stride < ne; i += 4 * stride) {
+        E a[4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            a[u] = ve[i + u * stride];
+            if constexpr (!SAME) b[u] = we[i + u * stride];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc[u] = dot_v<T>(a[u], SAME ? a[u] : b[u], acc[u]);
+    }
+    for (; i < ne; i += stride) {
+        E a = ve[i];
+        E b = a;
+        if constexpr (!SAME) b = we[i];
+        acc[0] = dot_v<T>(a, b, acc[0]);
+    }
+    if (EN > 1 && first) {
+        for (int64_t j = ne * EN; j < n; ++j) acc[1] = fma_t(v[j], SAME ? v[j] : w[j], acc[1]);
+    }
+    const T total = block_sum((acc[0] + acc[1]) + (acc[2] + acc[3]));
+    if (threadIdx.x == 0) out[blockIdx.x] = (gridDim.x == 1) ? finish(total, fin) : total;
+}
+
+// Second stage: one workgroup folds the per-block partials in a fixed order.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void fold_kernel(int count, const T *__restrict__ partials,
+                                                      T *__restrict__ out, int fin) {
+    T acc = T(0);
+    for (int i = threadIdx.x; i < count; i += kBlock) acc += partials[i];
+    const T total = block_sum(acc);
+    if (threadIdx.x == 0) *out = finish(total, fin);
+}
+
+template <typename T>
+__global__ void store_scalar_kernel(T *out, T value) { *out = value; }
+
+template <typename T>
+int launch_dot(const char *name, int64_t n, const T *v, const T *w, T *result, void *workspace,
+               size_t workspace_bytes, int fin, lsk_stream_t stream) {
+    if (n < 0) return lsk::fail(LSK_ERR_ARG, "%s: negative length %lld", name, (long long)n);
+    if (!result) return lsk::fail(LSK_ERR_ARG, "%s: null result", name);
+    hipStream_t s = lsk::as_stream(stream);
+    if (n == 0) { // empty domain -> 0 (src/LinearAlgebraTasks.cu:213-214)
+        store_scalar_kernel<T><<<1, 1, 0, s>>>(result, T(0));
+        LSK_LAUNCH_CHECK();
+        return LSK_OK;
+    }
+    if (!v || !w) return lsk::fail(LSK_ERR_ARG, "%s: null vector", name);
+    using V = typename Vec<T>::type;
+    constexpr int VN = Vec<T>::N;
+    const bool same = (v == w);
+    const bool vec = lsk::aligned16(v) && lsk::aligned16(w);
+    const int blocks = vec ? stream_grid(n / VN + 1) : stream_grid(n);
+    T *partials = result;
+    if (blocks > 1) {
+        const size_t need = size_t(blocks) * sizeof(T);
+        if (workspace) {
+            if (workspace_bytes < need)
+                return lsk::fail(LSK_ERR_ARG, "%s: workspace of %zu bytes, %zu needed", name,
+                                 workspace_bytes, need);
+            partials = static_cast<T *>(workspace);
+        } else {
+            lsk::DeviceState *st = nullptr;
+            int rc = lsk::device_state(&st);
+            if (rc != LSK_OK) return rc;
+            partials = static_cast<T *>(st->scratch);
+        }
+    }
+    if (vec) {
+        if (same) dot_kernel<T, V, VN, true><<<blocks, kBlock, 0, s>>>(n, v, w, partials, fin);
+        else dot_kernel<T, V, VN, false><<<blocks, kBlock, 0, s>>>(n, v, w, partials, fin);
+    } else {
+        if (same) dot_kernel<T, T, 1, true><<<blocks, kBlock, 0, s>>>(n, v, w, partials, fin);
+        else dot_kernel<T, T, 1, false><<<blocks, kBlock, 0, s>>>(n, v, w, partials, fin);
+    }
+    LSK_LAUNCH_CHECK();
+    if (blocks > 1) {
+        fold_kernel<T><<<1, kBlock, 0, s>>>(blocks, partials, result, fin);
+        LSK_LAUNCH_CHECK();
+    }
+    return LSK_OK;
+}
+
+template <typename T>
+int dot_host(const char *name, int64_t n, const T *v, const T *w, T *result_host,
+             lsk_stream_t stream) {
+    if (!result_host) return lsk::fail(LSK_ERR_ARG, "%s: null result", name);
+    *result_host = T(0);
+    if (n == 0) return LSK_OK;
+    lsk::DeviceState *st = nullptr;
+    int rc = lsk::device_state(&st);
+    if (rc != LSK_OK) return rc;
+    // Last slot of the scratch holds the result; the partials use the slots before it.
+    T *result_dev = reinterpret_cast<T *>(static_cast<char *>(st->scratch) + lsk::kScratchBytes) - 1;
+    rc = launch_dot<T>(name, n, v, w, result_dev, st->scratch, lsk::kScratchBytes - 16, FIN_NONE,
+                       stream);
+    if (rc != LSK_OK) return rc;
+    hipStream_t s = lsk::as_stream(stream);
+    LSK_HIP(hipMemcpyAsync(result_host, result_dev, sizeof(T), hipMemcpyDeviceToHost, s));
+    LSK_HIP(hipStreamSynchronize(s)); // the reference's cudaStreamSynchronize, .cu:235
+    return LSK_OK;
+}
+
+// ------------------------------------------------------------------ scalar ops -------
+
+template <typename T>
+__global__ void scalar_op_kernel(int op, const T *a, const T *b, T *out) {
+    const T x = *a;
+    T r;
+    switch (op) {
+    case LSK_SOP_NEG: r = -x; break;
+    case LSK_SOP_ADD: r = x + *b; break;
+    case LSK_SOP_SUB: r = x - *b; break;
+    case LSK_SOP_MUL: r = x * *b; break;
+    case LSK_SOP_DIV: r = x / *b; break;
+    case LSK_SOP_SQRT: r = sqrt(x); break;
+    case LSK_SOP_RSQRT: r = static_cast<T>(1) / sqrt(x); break; // as RSqrtScalarTask, not rsqrt()
+    default: r = x; break;
+    }
+    *out = r;
+}
+
+template <typename T>
+int launch_scalar_op(int op, const T *a, const T *b, T *out, lsk_stream_t stream) {
+    if (op < LSK_SOP_NEG || op > LSK_SOP_COPY)
+        return lsk::fail(LSK_ERR_ARG, "lsk_scalar_op: unknown op %d", op);
+    const bool binary = (op >= LSK_SOP_ADD && op <= LSK_SOP_DIV);
+    if (!a || !out || (binary && !b)) return lsk::fail(LSK_ERR_ARG, "lsk_scalar_op: null operand");
+    scalar_op_kernel<T><<<1, 1, 0, lsk::as_stream(stream)>>>(op, a, b, out);
+    LSK_LAUNCH_CHECK();
+    return LSK_OK;
+}
+
+template <typename T>
+__global__ void sum_scalars_kernel(int count, const T *in, T *out) {
+    T acc = in[0];
+    for (int i = 1; i < count; ++i) acc = acc + in[i];
+    *out = acc;
+}
+
+template <typename T>
+int launch_sum_scalars(int count, const T *in, T *out, lsk_stream_t stream) {
+    if (count < 1) return lsk::fail(LSK_ERR_ARG, "lsk_sum_scalars: count %d < 1", count);
+    if (!in || !out) return lsk::fail(LSK_ERR_ARG, "lsk_sum_scalars: null operand");
+    sum_scalars_kernel<T><<<1, 1, 0, lsk::as_stream(stream)>>>(count, in, out);
+    LSK_LAUNCH_CHECK();
+    return LSK_OK;
+}
+
+// ------------------------------------------------------------------ N-D xpay ---------
+
+struct NdShape {
+    int64_t extent[3];
+    int64_t xs[3];
+    int64_t ys[3];
+};
+
+// One element per lane in row-major order of the (reordered) extents; the host orders the
+// dimensions so that the innermost one has the smallest y stride.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void xpay_nd_kernel(int64_t volume, NdShape sh, T alpha,
+                                                         const T *x, T *y) {
+    const int64_t stride = int64_t(gridDim.x) * kBlock;
+    for (int64_t i = int64_t(blockIdx.x) * kBlock + threadIdx.x; i < volume; i += stride) {
+        const int64_t c2 = i % sh.extent[2];
+        const int64_t r = i / sh.extent[2];
+        const int64_t c1 = r % sh.extent[1];
+        const int64_t c0 = r / sh.extent[1];
+        const int64_t xo = c0 * sh.xs[0] + c1 * sh.xs[1] + c2 * sh.xs[2];
+        const int64_t yo = c0 * sh.ys[0] + c1 * sh.ys[1] + c2 * sh.ys[2];
+        y[yo] = fma_t(alpha, y[yo], x[xo]);
+    }
+}
+
+template <typename T>
+int launch_xpay_nd(int dim, const int64_t *extent, T alpha, const T *x, const int64_t *x_stride,
+                   T *y, const int64_t *y_stride, lsk_stream_t stream) {
+    if (dim < 1 || dim > 3) return lsk::fail(LSK_ERR_ARG, "lsk_xpay_nd: dim %d outside 1..3", dim);
+    if (!extent || !x_stride || !y_stride) return lsk::fail(LSK_ERR_ARG, "lsk_xpay_nd: null shape");
+    NdShape sh;
+    int64_t volume = 1;
+    // Leading unit dimensions pad the shape to 3-D.
+    for (int d = 0; d < 3; ++d) {
+        const int src = d - (3 - dim);
+        sh.extent[d] = src >= 0 ? extent[src] : 1;
+        sh.xs[d] = src >= 0 ? x_stride[src] : 0;
+        sh.ys[d] = src >= 0 ? y_stride[src] : 0;
+        if (sh.extent[d] < 0) return lsk::fail(LSK_ERR_ARG, "lsk_xpay_nd: negative extent");
+        volume *= sh.extent[d];
+    }
+    if (volume == 0) return LSK_OK;
+    if (!x || !y) return lsk::fail(LSK_ERR_ARG, "lsk_xpay_nd: null vector");
+    // Order dimensions by decreasing y stride (simple 3-element sort) for coalesced lanes.
+    for (int a = 0; a < 3; ++a)
+        for (int b = a + 1; b < 3; ++b)
+            if (sh.ys[b] > sh.ys[a]) {
+                int64_t t;
+                t = sh.extent[a]; sh.extent[a] = sh.extent[b]; sh.extent[b] = t;
+                t = sh.xs[a]; sh.xs[a] = sh.xs[b]; sh.xs[b] = t;
+                t = sh.ys[a]; sh.ys[a] = sh.ys[b]; sh.ys[b] = t;
+            }
+    xpay_nd_kernel<T><<<stream_grid(volume), kBlock, 0, lsk::as_stream(stream)>>>(volume, sh, alpha, x, y);
+    LSK_LAUNCH_CHECK();
+    return LSK_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+size_t lsk_dot_workspace_bytes(int64_t n) {
+    (void)n;
+    return size_t(lsk::kMaxGridBlocks) * sizeof(double);
+}
+
+#define LSK_BLAS1(SUFFIX, T)                                                                      \
+    int lsk_scal_##SUFFIX(int64_t n, T alpha, T *x, lsk_stream_t s) {                             \
+        return launch_ew<T, OP_SCAL>("lsk_scal_" #SUFFIX, n, host_alpha<T>(alpha), nullptr, x, s);\
+    }                                                                                             \
+    int lsk_axpy_##SUFFIX(int64_t n, T alpha, const T *x, T *y, lsk_stream_t s) {                 \
+        return launch_ew<T, OP_AXPY>("lsk_axpy_" #SUFFIX, n, host_alpha<T>(alpha), x, y, s);      \
+    }                                                                                             \
+    int lsk_xpay_##SUFFIX(int64_t n, T alpha, const T *x, T *y, lsk_stream_t s) {                 \
+        return launch_ew<T, OP_XPAY>("lsk_xpay_" #SUFFIX, n, host_alpha<T>(alpha), x, y, s);      \
+    }                                                                                             \
+    int lsk_fill_##SUFFIX(int64_t n, T value, T *x, lsk_stream_t s) {                             \
+        return launch_ew<T, OP_FILL>("lsk_fill_" #SUFFIX, n, host_alpha<T>(value), nullptr, x, s);\
+    }                                                                                             \
+    int lsk_copy_##SUFFIX(int64_t n, const T *src, T *dst, lsk_stream_t s) {                      \
+        return launch_ew<T, OP_COPY>("lsk_copy_" #SUFFIX, n, host_alpha<T>(T(0)), src, dst, s);   \
+    }                                                                                             \
+    int lsk_scal_dev_##SUFFIX(int64_t n, int nf, const T *f0, const T *f1, const T *f2,           \
+                              const T *f3, T *x, lsk_stream_t s) {                                \
+        return launch_ew<T, OP_SCAL>("lsk_scal_dev_" #SUFFIX, n, dev_alpha<T>(nf, f0, f1, f2, f3),\
+                                     nullptr, x, s);                                              \
+    }                                                                                             \
+    int lsk_axpy_dev_##SUFFIX(int64_t n, int nf, const T *f0, const T *f1, const T *f2,           \
+                              const T *f3, const T *x, T *y, lsk_stream_t s) {                    \
+        return launch_ew<T, OP_AXPY>("lsk_axpy_dev_" #SUFFIX, n, dev_alpha<T>(nf, f0, f1, f2, f3),\
+                                     x, y, s);                                                    \
+    }                                                                                             \
+    int lsk_xpay_dev_##SUFFIX(int64_t n, int nf, const T *f0, const T *f1, const T *f2,           \
+                              const T *f3, const T *x, T *y, lsk_stream_t s) {                    \
+        return launch_ew<T, OP_XPAY>("lsk_xpay_dev_" #SUFFIX, n, dev_alpha<T>(nf, f0, f1, f2, f3),\
+                                     x, y, s);                                                    \
+    }                                                                                             \
+    int lsk_xpay_nd_##SUFFIX(int dim, const int64_t *extent, T alpha, const T *x,                 \
+                             const int64_t *xs, T *y, const int64_t *ys, lsk_stream_t s) {        \
+        return launch_xpay_nd<T>(dim, extent, alpha, x, xs, y, ys, s);                            \
+    }                                                                                             \
+    int lsk_dot_##SUFFIX(int64_t n, const T *v, const T *w, T *r, void *ws, size_t wsb,           \
+                         lsk_stream_t s) {                                                        \
+        return launch_dot<T>("lsk_dot_" #SUFFIX, n, v, w, r, ws, wsb, FIN_NONE, s);               \
+    }                                                                                             \
+    int lsk_nrm2_##SUFFIX(int64_t n, const T *v, T *r, void *ws, size_t wsb, lsk_stream_t s) {    \
+        return launch_dot<T>("lsk_nrm2_" #SUFFIX, n, v, v, r, ws, wsb, FIN_SQRT, s);              \
+    }                                                                                             \
+    int lsk_dot_host_##SUFFIX(int64_t n, const T *v, const T *w, T *r, lsk_stream_t s) {          \
+        return dot_host<T>("lsk_dot_host_" #SUFFIX, n, v, w, r, s);                               \
+    }                                                                                             \
+    int lsk_scalar_op_##SUFFIX(int op, const T *a, const T *b, T *out, lsk_stream_t s) {          \
+        return launch_scalar_op<T>(op, a, b, out, s);                                             \
+    }                                                                                             \
+    int lsk_sum_scalars_##SUFFIX(int count, const T *in, T *out, lsk_stream_t s) {                \
+        return launch_sum_scalars<T>(count, in, out, s);                                          \
+    }
+
+LSK_BLAS1(f32, float)
+LSK_BLAS1(f64, double)
+#undef LSK_BLAS1
+
+} // extern "C"

@@ -1,0 +1,285 @@
+// CSR SpMV for gfx950 on the reference's own layout: per row a 16-byte {lo, hi} rect of
+// GLOBAL kernel indices, 64-bit global column ids, fp32/fp64 entries
+// (src/CSRMatrixTasks.cu:14-156, src/CuSPARSEHelpers.hpp:9-101).  No rect->indptr rebasing
+// pass, no descriptors, no workspace: one kernel launch per call.
+//
+// Work split: a workgroup (4 wave64) owns R consecutive rows.  When those rows tile one
+// contiguous run of kernel entries that fits the LDS product buffer (the normal case for a
+// CSR piece) it takes the streaming path:
+//   1. lanes load the rects (one 16-byte load per row) and publish row offsets in LDS;
+//   2. the run of entries is read front to back with 16-byte loads of col and val, four
+//      independent loads per array per lane in flight, x gathered through L2, and the
+//      products parked in LDS;
+//   3. 256/R lanes per row add that row's products out of LDS and one lane stores y.
+// Otherwise (gaps or overlaps between rects, or a run longer than the buffer) each wave
+// walks whole rows straight from HBM.  Both paths skip entries whose column lies outside
+// x_lo..x_hi, as the reference's CPU body does (src/CSRMatrixTasks.cpp:88).
+//
+// HBM bytes per call: nnz*(8 + sizeof(T)) + rows*(16 + sizeof(T)) + the x window.
+#include "lsk_common.hpp"
+
+namespace {
+
+using lsk::kBlock;
+
+template <typename T> struct Cfg;
+// Products kept per workgroup: 30 KiB of LDS (+1 KiB of row offsets), so five workgroups
+// (20 waves) fit the 160 KiB of a CU.
+template <> struct Cfg<double> { static constexpr int CAP = 3840; static constexpr int U = 2; using V = double2; };
+template <> struct Cfg<float> { static constexpr int CAP = 7680; static constexpr int U = 4; using V = float4; };
+
+__device__ __forceinline__ double fma_t(double a, double b, double c) { return __builtin_fma(a, b, c); }
+__device__ __forceinline__ float fma_t(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
+struct Rect { long long lo, hi; };
+
+template <typename T> __device__ __forceinline__ T vget(const double2 &v, int i) { return i == 0 ? v.x : v.y; }
+template <typename T> __device__ __forceinline__ T vget(const float4 &v, int i) {
+    return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w));
+}
+
+// Walk rows [r_begin, r_end) one wave per row, entries straight from HBM.  Correct for any
+// rects (gaps, overlaps, empty, long).
+template <typename T>
+__device__ void rows_by_wave(int r_begin, int r_end, const Rect *__restrict__ rects,
+                             int64_t k_base, int64_t nnz, const int64_t *__restrict__ col,
+                             const T *__restrict__ val, const T *__restrict__ x, int64_t x_lo,
+                             int64_t x_hi, T *__restrict__ y, int beta) {
+    const int lane = threadIdx.x % lsk::kWave, wave = threadIdx.x / lsk::kWave;
+    for (int r = r_begin + wave; r < r_end; r += kBlock / lsk::kWave) {
+        const Rect rc = rects[r];
+        T acc = T(0);
+        // Rects are clipped to the piece so that a malformed rect cannot fault.
+        const int64_t lo = rc.lo > k_base ? rc.lo : k_base;
+        const int64_t hi = rc.hi < k_base + nnz - 1 ? rc.hi : k_base + nnz - 1;
+        for (int64_t k = lo + lane; k <= hi; k += lsk::kWave) {
+            const int64_t c = col[k - k_base];
+            if (c >= x_lo && c <= x_hi) acc = fma_t(val[k - k_base], x[c - x_lo], acc);
+        }
+        acc = lsk::wave_sum(acc);
+        if (lane == 0) y[r] = beta ? y[r] + acc : acc;
+    }
+}
+
+// LOG_R: log2 of rows per workgroup (R = 1 << LOG_R <= 256); G = 256 / R lanes add one row.
+template <typename T, int LOG_R>
+__global__ __launch_bounds__(kBlock) void csr_spmv_kernel(
+    int64_t rows, const Rect *__restrict__ rects, int64_t k_base, int64_t nnz,
+    const int64_t *__restrict__ col, const T *__restrict__ val, const T *__restrict__ x,
+    int64_t x_lo, int64_t x_hi, T *__restrict__ y, int beta) {
+    constexpr int R = 1 << LOG_R;
+    constexpr int G = kBlock / R;
+    constexpr int CAP = Cfg<T>::CAP;
+    constexpr int U = Cfg<T>::U; // entries per 16-byte val access
+    using V = typename Cfg<T>::V;
+
+    __shared__ T s_prod[CAP];
+    __shared__ int s_off[R + 1];
+    __shared__ long long s_k0;
+
+    const unsigned tile = lsk::xcd_remap(blockIdx.x, gridDim.x);
+    const int64_t r0 = int64_t(tile) * R;
+    const int nr = static_cast<int>(rows - r0 < R ? rows - r0 : R);
+    const int tid = threadIdx.x;
+
+    // ---- 1. rects -> row offsets relative to the first entry of the tile --------------
+    Rect rc{0, -1};
+    if (tid < nr) rc = rects[r0 + tid];
+    if (tid == 0) s_k0 = rc.lo;
+    __syncthreads();
+    const long long k0 = s_k0;
+    const long long rel_lo = rc.lo - k0, rel_end = rc.hi + 1 - k0;
+    bool ok = true;
+    if (tid < nr) {
+        ok = rel_lo >= 0 && rel_end >= rel_lo && rel_end <= CAP && k0 >= k_base &&
+             rc.hi - k_base < nnz;
+        s_off[tid] = static_cast<int>(rel_lo);
+        if (tid == nr - 1) s_off[nr] = static_cast<int>(rel_end);
+    }
+    __syncthreads();
+    if (tid < nr) ok = ok && (static_cast<long long>(s_off[tid + 1]) == rel_end);
+    const bool stream = __syncthreads_and(ok);
+
+    if (!stream) {
+        rows_by_wave<T>(0, nr, rects + r0, k_base, nnz, col, val, x, x_lo, x_hi, y + r0, beta);
+        return;
+    }
+
+    // ---- 2. stream the tile's entries; products into LDS ------------------------------
+    const int nnzb = s_off[nr];
+    const int64_t *colb = col + (k0 - k_base);
+    const T *valb = val + (k0 - k_base);
+    // Entry e of the tile sits at colb[e] / valb[e].  Lane accesses are 16-byte aligned:
+    // a unit is U consecutive entries starting at a multiple of U minus `shift`, where
+    // `shift` makes the val address 16-byte aligned; col is read as U/2 aligned pairs when
+    // its parity agrees, else entry by entry.  Entries of a unit that fall outside
+    // [0, nnzb) are loaded (the aligned 16-byte word holding an entry of this tile never
+    // leaves the page that entry is on) and discarded.
+    const int shift = static_cast<int>((reinterpret_cast<uintptr_t>(valb) / sizeof(T)) % U);
+    const bool col_pairs =
+        ((reinterpret_cast<uintptr_t>(colb) / 8 + (U - shift)) % 2) == 0; // pair-aligned col
+    constexpr int UNROLL = 4;
+    if (nnzb > 0)
+    for (int base = tid * U - shift; base < nnzb; base += kBlock * U * UNROLL) {
+        V vv[UNROLL];
+        long long cc[UNROLL][U];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const int b = base + u * kBlock * U;
+            if (b < nnzb) {
+                vv[u] = *reinterpret_cast<const V *>(valb + b);
+                if (col_pairs) {
+#pragma unroll
+                    for (int p = 0; p < U; p += 2) {
+                        const int e = b + p;
+                        longlong2 c2{-1, -1};
+                        if (e + 1 >= 0 && e < nnzb) // the pair holds an entry of this tile
+                            c2 = *reinterpret_cast<const longlong2 *>(colb + e);
+                        cc[u][p] = c2.x;
+                        cc[u][p + 1] = c2.y;
+                    }
+                } else {
+#pragma unroll
+                    for (int p = 0; p < U; ++p) {
+                        const int e = b + p;
+                        cc[u][p] = (e >= 0 && e < nnzb) ? colb[e] : -1;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const int b = base + u * kBlock * U;
+            if (b < nnzb) {
+                T xv[U];
+#pragma unroll
+                for (int p = 0; p < U; ++p) {
+                    const int e = b + p;
+                    const long long c = cc[u][p];
+                    const bool live = e >= 0 && e < nnzb && c >= x_lo && c <= x_hi;
+                    xv[p] = live ? x[c - x_lo] : T(0);
+                }
+#pragma unroll
+                for (int p = 0; p < U; ++p) {
+                    const int e = b + p;
+                    if (e >= 0 && e < nnzb) {
+                        const long long c = cc[u][p];
+                        const bool live = c >= x_lo && c <= x_hi;
+                        s_prod[e] = live ? vget<T>(vv[u], p) * xv[p] : T(0);
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- 3. G lanes per row fold the products; lane 0 of the group stores y ------------
+    const int row = tid / G, g = tid % G;
+    T acc = T(0);
+    if (row < nr) {
+        const int e1 = s_off[row + 1];
+        for (int e = s_off[row] + g; e < e1; e += G) acc += s_prod[e];
+    }
+    if constexpr (G > 1) {
+#pragma unroll
+        for (int off = G / 2; off > 0; off >>= 1) acc += __shfl_xor(acc, off, lsk::kWave);
+    }
+    if (row < nr && g == 0) {
+        T *yp = y + r0 + row;
+        *yp = beta ? *yp + acc : acc;
+    }
+}
+
+template <typename T>
+int launch_csr_spmv(const char *name, int64_t rows, int64_t nnz, const int64_t *rects,
+                    int64_t k_base, const int64_t *col, const T *val, const T *x, int64_t x_lo,
+                    int64_t x_hi, T *y, int beta, lsk_stream_t stream) {
+    if (rows < 0 || nnz < 0)
+        return lsk::fail(LSK_ERR_ARG, "%s: negative size (rows %lld, nnz %lld)", name,
+                         (long long)rows, (long long)nnz);
+    if (beta != 0 && beta != 1) return lsk::fail(LSK_ERR_ARG, "%s: beta %d not in {0,1}", name, beta);
+    if (rows == 0) return LSK_OK; // "Break out if there are no rows to process." (.cu:75-76)
+    if (!rects || !y) return lsk::fail(LSK_ERR_ARG, "%s: null rects or output", name);
+    if (nnz > 0 && (!col || !val)) return lsk::fail(LSK_ERR_ARG, "%s: null kernel arrays", name);
+    if (x_hi >= x_lo && !x) return lsk::fail(LSK_ERR_ARG, "%s: null input vector", name);
+    if (!lsk::aligned16(rects))
+        return lsk::fail(LSK_ERR_ALIGN, "%s: rects must be 16-byte aligned", name);
+    if ((reinterpret_cast<uintptr_t>(col) & 7u) || (reinterpret_cast<uintptr_t>(val) & (sizeof(T) - 1)))
+        return lsk::fail(LSK_ERR_ALIGN, "%s: col/val must be naturally aligned", name);
+
+    // Rows per workgroup: as many as keep the tile's products inside the LDS buffer at the
+    // piece's mean row length, a power of two in 4..256.
+    const double mean = rows > 0 ? double(nnz) / double(rows) : 0.0;
+    const double want = mean > 0.0 ? 0.9 * Cfg<T>::CAP / mean : 256.0;
+    int log_r = 8;
+    while (log_r > 2 && double(1 << log_r) > want) --log_r;
+
+    const Rect *rc = reinterpret_cast<const Rect *>(rects);
+    hipStream_t s = lsk::as_stream(stream);
+    const int64_t blocks64 = lsk::ceil_div(rows, int64_t(1) << log_r);
+    if (blocks64 > 0x7fffffffLL) return lsk::fail(LSK_ERR_UNSUPPORTED, "%s: too many rows", name);
+    const unsigned blocks = static_cast<unsigned>(blocks64);
+#define LSK_CSR_CASE(L)                                                                       \
+    case L:                                                                                   \
+        csr_spmv_kernel<T, L><<<blocks, kBlock, 0, s>>>(rows, rc, k_base, nnz, col, val, x,   \
+                                                        x_lo, x_hi, y, beta);                 \
+        break;
+    switch (log_r) {
+        LSK_CSR_CASE(2)
+        LSK_CSR_CASE(3)
+        LSK_CSR_CASE(4)
+        LSK_CSR_CASE(5)
+        LSK_CSR_CASE(6)
+        LSK_CSR_CASE(7)
+        LSK_CSR_CASE(8)
+    }
+#undef LSK_CSR_CASE
+    LSK_LAUNCH_CHECK();
+    return LSK_OK;
+}
+
+// indptr conversion, bit-exact with convertGlobalRowptrToLocalIndPtr
+// (src/CuSPARSEHelpers.hpp:20-30).
+__global__ __launch_bounds__(kBlock) void rects_to_indptr_kernel(int64_t rows,
+                                                                 const Rect *__restrict__ rects,
+                                                                 long long *__restrict__ indptr) {
+    const int64_t stride = int64_t(gridDim.x) * kBlock;
+    const long long first = rects[0].lo;
+    for (int64_t i = int64_t(blockIdx.x) * kBlock + threadIdx.x; i < rows; i += stride) {
+        indptr[i] = rects[i].lo - first;
+        if (i == 0) indptr[rows] = rects[rows - 1].hi + 1 - first;
+    }
+}
+
+} // namespace
+
+extern "C" {
+
+int lsk_csr_spmv_f32(int64_t rows, int64_t nnz, const int64_t *rects, int64_t k_base,
+                     const int64_t *col, const float *val, const float *x, int64_t x_lo,
+                     int64_t x_hi, float *y, int beta, lsk_stream_t stream) {
+    return launch_csr_spmv<float>("lsk_csr_spmv_f32", rows, nnz, rects, k_base, col, val, x, x_lo,
+                                  x_hi, y, beta, stream);
+}
+
+int lsk_csr_spmv_f64(int64_t rows, int64_t nnz, const int64_t *rects, int64_t k_base,
+                     const int64_t *col, const double *val, const double *x, int64_t x_lo,
+                     int64_t x_hi, double *y, int beta, lsk_stream_t stream) {
+    return launch_csr_spmv<double>("lsk_csr_spmv_f64", rows, nnz, rects, k_base, col, val, x, x_lo,
+                                   x_hi, y, beta, stream);
+}
+
+int lsk_rects_to_indptr_i64(int64_t rows, const int64_t *rects, int64_t *indptr,
+                            lsk_stream_t stream) {
+    if (rows < 0) return lsk::fail(LSK_ERR_ARG, "lsk_rects_to_indptr_i64: negative rows");
+    if (rows == 0) return LSK_OK;
+    if (!rects || !indptr) return lsk::fail(LSK_ERR_ARG, "lsk_rects_to_indptr_i64: null pointer");
+    int64_t blocks = lsk::ceil_div(rows, kBlock);
+    if (blocks > lsk::kMaxGridBlocks) blocks = lsk::kMaxGridBlocks;
+    rects_to_indptr_kernel<<<static_cast<unsigned>(blocks), kBlock, 0, lsk::as_stream(stream)>>>(
+        rows, reinterpret_cast<const Rect *>(rects), reinterpret_cast<long long *>(indptr));
+    LSK_LAUNCH_CHECK();
+    return LSK_OK;
+}
+
+} // extern "C"

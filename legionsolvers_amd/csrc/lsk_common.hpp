@@ -1,0 +1,71 @@
+// Shared helpers for the HIP translation units behind include/lsk.h.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+
+#include "lsk.h"
+
+namespace lsk {
+
+// Records `code` and a printf-style message for lsk_last_error(); prints and abort()s when
+// lsk_set_abort_on_error(1) is in force.  Returns `code`.
+int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+
+int hip_fail(hipError_t status, const char *expr, const char *file, int line);
+
+#define LSK_HIP(expr)                                                                  \
+    do {                                                                               \
+        hipError_t lsk_status_ = (expr);                                               \
+        if (lsk_status_ != hipSuccess)                                                 \
+            return ::lsk::hip_fail(lsk_status_, #expr, __FILE__, __LINE__);            \
+    } while (false)
+
+// After a kernel launch: surfaces launch-configuration errors without synchronising.
+#define LSK_LAUNCH_CHECK() LSK_HIP(hipGetLastError())
+
+constexpr int kBlock = 256;          // threads per workgroup: 4 wave64
+constexpr int kWave = 64;            // CDNA wavefront width
+constexpr int kNumXcd = 8;           // MI355X accelerator complex dies
+constexpr int kMaxGridBlocks = 2048; // 256 CUs x 8 workgroups for grid-stride kernels
+
+inline hipStream_t as_stream(lsk_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// Per-device library state: the partial-sum scratch of the reductions.
+struct DeviceState {
+    void *scratch = nullptr; // kScratchBytes of HBM
+    bool ready = false;
+};
+constexpr size_t kScratchBytes = size_t(kMaxGridBlocks) * 16; // one 16-byte slot per block
+
+// State of the current device, created on first use (lsk_init does it eagerly).
+int device_state(DeviceState **out);
+
+// Workgroup -> logical tile remap that keeps tiles with neighbouring ids on one XCD: blocks
+// are dealt round-robin over the 8 XCDs, so block b lands with blocks b+8, b+16, ...;
+// giving that set a contiguous range of tiles lets the XCD's private L2 serve the input
+// vector window those tiles share.  Bijective for any grid size.
+__device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblocks) {
+    const unsigned xcd = bid % kNumXcd;
+    const unsigned q = nblocks / kNumXcd;
+    const unsigned r = nblocks % kNumXcd;
+    const unsigned first = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return first + bid / kNumXcd;
+}
+
+// Sum over the 64 lanes of a wave; every lane returns the total.
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v) {
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
+    return v;
+}
+
+} // namespace lsk

@@ -1,0 +1,276 @@
+// Device-side set-up helpers: the linearised stencil generators (what
+// FillLinearizedCSRStencilTask / FillLinearizedCOOStencilTask write, row-major order,
+// src/StencilGenerator.cpp:129-242,379-517), the row-rect builder and the image bounds of a
+// column field.  Integer work only; results are bit-identical to the reference's serial
+// per-piece walk, which starts from the grid origin for every piece and dominates set-up
+// time at 512^3 -- here every row is generated independently.
+#include <climits>
+
+#include "lsk_common.hpp"
+
+namespace {
+
+using lsk::kBlock;
+constexpr int kMaxOffsets = 32;
+
+// Grid padded to 3-D with leading unit extents; offsets padded with leading zeros.
+struct Stencil {
+    long long extent[3];
+    int noffsets;
+    long long off[kMaxOffsets][3];
+};
+
+template <typename T>
+struct Coeffs {
+    T c[kMaxOffsets];
+};
+
+__device__ __forceinline__ void decode_row(const Stencil &st, long long r, long long p[3]) {
+    p[2] = r % st.extent[2];
+    const long long q = r / st.extent[2];
+    p[1] = q % st.extent[1];
+    p[0] = q / st.extent[1];
+}
+
+__device__ __forceinline__ bool shifted_inside(const Stencil &st, const long long p[3], int o) {
+    bool in = true;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const long long s = p[d] + st.off[o][d];
+        in = in && s >= 0 && s < st.extent[d];
+    }
+    return in;
+}
+
+// linearize_row_major(point + offset) - linearize_row_major(point)
+__device__ __forceinline__ long long linear_shift(const Stencil &st, int o) {
+    return (st.off[o][0] * st.extent[1] + st.off[o][1]) * st.extent[2] + st.off[o][2];
+}
+
+__global__ __launch_bounds__(kBlock) void stencil_count_kernel(Stencil st, long long row_lo,
+                                                               long long row_hi,
+                                                               long long *__restrict__ counts) {
+    const long long stride = static_cast<long long>(gridDim.x) * kBlock;
+    for (long long r = row_lo + static_cast<long long>(blockIdx.x) * kBlock + threadIdx.x;
+         r <= row_hi; r += stride) {
+        long long p[3];
+        decode_row(st, r, p);
+        long long n = 0;
+        for (int o = 0; o < st.noffsets; ++o) n += shifted_inside(st, p, o) ? 1 : 0;
+        counts[r - row_lo] = n;
+    }
+}
+
+template <typename T, bool COO>
+__global__ __launch_bounds__(kBlock) void stencil_fill_kernel(
+    Stencil st, Coeffs<T> cf, long long row_lo, long long row_hi,
+    const long long *__restrict__ rects, long long k_base, long long *__restrict__ row_out,
+    long long *__restrict__ col, T *__restrict__ val) {
+    const long long stride = static_cast<long long>(gridDim.x) * kBlock;
+    for (long long r = row_lo + static_cast<long long>(blockIdx.x) * kBlock + threadIdx.x;
+         r <= row_hi; r += stride) {
+        long long p[3];
+        decode_row(st, r, p);
+        long long k = rects[2 * (r - row_lo)] - k_base;
+        for (int o = 0; o < st.noffsets; ++o) {
+            if (shifted_inside(st, p, o)) {
+                col[k] = r + linear_shift(st, o);
+                val[k] = cf.c[o];
+                if constexpr (COO) row_out[k] = r;
+                ++k;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void rects_from_counts_kernel(
+    long long rows, const long long *__restrict__ counts, const long long *__restrict__ prefix_incl,
+    long long base, long long *__restrict__ rects) {
+    const long long stride = static_cast<long long>(gridDim.x) * kBlock;
+    for (long long i = static_cast<long long>(blockIdx.x) * kBlock + threadIdx.x; i < rows;
+         i += stride) {
+        const long long end = base + prefix_incl[i]; // one past the row's last entry
+        rects[2 * i] = end - counts[i];
+        rects[2 * i + 1] = end - 1;
+    }
+}
+
+__global__ void bounds_init_kernel(long long *out) {
+    out[0] = LLONG_MAX;
+    out[1] = LLONG_MIN;
+}
+
+__global__ __launch_bounds__(kBlock) void index_bounds_kernel(long long n,
+                                                              const long long *__restrict__ idx,
+                                                              long long *__restrict__ out) {
+    __shared__ long long s_min[kBlock / lsk::kWave], s_max[kBlock / lsk::kWave];
+    long long lo = LLONG_MAX, hi = LLONG_MIN;
+    const long long stride = static_cast<long long>(gridDim.x) * kBlock;
+    for (long long i = static_cast<long long>(blockIdx.x) * kBlock + threadIdx.x; i < n; i += stride) {
+        const long long v = idx[i];
+        lo = v < lo ? v : lo;
+        hi = v > hi ? v : hi;
+    }
+#pragma unroll
+    for (int off = lsk::kWave / 2; off > 0; off >>= 1) {
+        const long long olo = __shfl_xor(lo, off, lsk::kWave);
+        const long long ohi = __shfl_xor(hi, off, lsk::kWave);
+        lo = olo < lo ? olo : lo;
+        hi = ohi > hi ? ohi : hi;
+    }
+    const int lane = threadIdx.x % lsk::kWave, wave = threadIdx.x / lsk::kWave;
+    if (lane == 0) {
+        s_min[wave] = lo;
+        s_max[wave] = hi;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kBlock / lsk::kWave; ++w) {
+            lo = s_min[w] < lo ? s_min[w] : lo;
+            hi = s_max[w] > hi ? s_max[w] : hi;
+        }
+        atomicMin(&out[0], lo);
+        atomicMax(&out[1], hi);
+    }
+}
+
+int grid_for(long long items) {
+    long long blocks = lsk::ceil_div(items, kBlock);
+    if (blocks < 1) blocks = 1;
+    if (blocks > lsk::kMaxGridBlocks * 4) blocks = lsk::kMaxGridBlocks * 4;
+    return static_cast<int>(blocks);
+}
+
+int make_stencil(const char *name, int dim, const int64_t *extent, int noffsets,
+                 const int64_t *offsets, Stencil *st) {
+    if (dim < 1 || dim > 3) return lsk::fail(LSK_ERR_ARG, "%s: dim %d outside 1..3", name, dim);
+    if (!extent || (noffsets > 0 && !offsets)) return lsk::fail(LSK_ERR_ARG, "%s: null shape", name);
+    if (noffsets < 0 || noffsets > kMaxOffsets)
+        return lsk::fail(LSK_ERR_ARG, "%s: %d offsets (0..%d allowed)", name, noffsets, kMaxOffsets);
+    const int pad = 3 - dim;
+    for (int d = 0; d < 3; ++d) {
+        st->extent[d] = d < pad ? 1 : extent[d - pad];
+        if (st->extent[d] < 1) return lsk::fail(LSK_ERR_ARG, "%s: extent < 1", name);
+    }
+    st->noffsets = noffsets;
+    for (int o = 0; o < noffsets; ++o)
+        for (int d = 0; d < 3; ++d) st->off[o][d] = d < pad ? 0 : offsets[o * dim + (d - pad)];
+    // The generator walks the offsets in sorted (lexicographic) order; the caller passes
+    // them sorted so that col ids ascend within a row exactly as the reference writes them.
+    for (int o = 1; o < noffsets; ++o) {
+        bool greater = false;
+        for (int d = 0; d < 3; ++d) {
+            if (st->off[o - 1][d] < st->off[o][d]) break;
+            if (st->off[o - 1][d] > st->off[o][d]) { greater = true; break; }
+        }
+        if (greater) return lsk::fail(LSK_ERR_ARG, "%s: offsets not sorted", name);
+    }
+    return LSK_OK;
+}
+
+template <typename T, bool COO>
+int launch_fill(const char *name, int dim, const int64_t *extent, int noffsets,
+                const int64_t *offsets, const T *coeffs, int64_t row_lo, int64_t row_hi,
+                const int64_t *rects, int64_t k_base, int64_t *row, int64_t *col, T *val,
+                lsk_stream_t stream) {
+    Stencil st;
+    int rc = make_stencil(name, dim, extent, noffsets, offsets, &st);
+    if (rc != LSK_OK) return rc;
+    if (row_hi < row_lo) return LSK_OK;
+    const long long total = st.extent[0] * st.extent[1] * st.extent[2];
+    if (row_lo < 0 || row_hi >= total)
+        return lsk::fail(LSK_ERR_ARG, "%s: rows %lld..%lld outside the grid", name,
+                         (long long)row_lo, (long long)row_hi);
+    if (!coeffs || !rects || !col || !val || (COO && !row))
+        return lsk::fail(LSK_ERR_ARG, "%s: null pointer", name);
+    Coeffs<T> cf;
+    for (int o = 0; o < kMaxOffsets; ++o) cf.c[o] = o < noffsets ? coeffs[o] : T(0);
+    stencil_fill_kernel<T, COO><<<grid_for(row_hi - row_lo + 1), kBlock, 0, lsk::as_stream(stream)>>>(
+        st, cf, row_lo, row_hi, reinterpret_cast<const long long *>(rects), k_base,
+        reinterpret_cast<long long *>(row), reinterpret_cast<long long *>(col), val);
+    LSK_LAUNCH_CHECK();
+    return LSK_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int lsk_stencil_count(int dim, const int64_t *extent, int noffsets, const int64_t *offsets,
+                      int64_t row_lo, int64_t row_hi, int64_t *counts, lsk_stream_t stream) {
+    Stencil st;
+    int rc = make_stencil("lsk_stencil_count", dim, extent, noffsets, offsets, &st);
+    if (rc != LSK_OK) return rc;
+    if (row_hi < row_lo) return LSK_OK;
+    const long long total = st.extent[0] * st.extent[1] * st.extent[2];
+    if (row_lo < 0 || row_hi >= total)
+        return lsk::fail(LSK_ERR_ARG, "lsk_stencil_count: rows outside the grid");
+    if (!counts) return lsk::fail(LSK_ERR_ARG, "lsk_stencil_count: null output");
+    stencil_count_kernel<<<grid_for(row_hi - row_lo + 1), kBlock, 0, lsk::as_stream(stream)>>>(
+        st, row_lo, row_hi, reinterpret_cast<long long *>(counts));
+    LSK_LAUNCH_CHECK();
+    return LSK_OK;
+}
+
+int lsk_stencil_fill_csr_f32(int dim, const int64_t *extent, int noffsets, const int64_t *offsets,
+                             const float *coeffs, int64_t row_lo, int64_t row_hi,
+                             const int64_t *rects, int64_t k_base, int64_t *col, float *val,
+                             lsk_stream_t stream) {
+    return launch_fill<float, false>("lsk_stencil_fill_csr_f32", dim, extent, noffsets, offsets,
+                                     coeffs, row_lo, row_hi, rects, k_base, nullptr, col, val, stream);
+}
+
+int lsk_stencil_fill_csr_f64(int dim, const int64_t *extent, int noffsets, const int64_t *offsets,
+                             const double *coeffs, int64_t row_lo, int64_t row_hi,
+                             const int64_t *rects, int64_t k_base, int64_t *col, double *val,
+                             lsk_stream_t stream) {
+    return launch_fill<double, false>("lsk_stencil_fill_csr_f64", dim, extent, noffsets, offsets,
+                                      coeffs, row_lo, row_hi, rects, k_base, nullptr, col, val, stream);
+}
+
+int lsk_stencil_fill_coo_f32(int dim, const int64_t *extent, int noffsets, const int64_t *offsets,
+                             const float *coeffs, int64_t row_lo, int64_t row_hi,
+                             const int64_t *rects, int64_t k_base, int64_t *row, int64_t *col,
+                             float *val, lsk_stream_t stream) {
+    return launch_fill<float, true>("lsk_stencil_fill_coo_f32", dim, extent, noffsets, offsets,
+                                    coeffs, row_lo, row_hi, rects, k_base, row, col, val, stream);
+}
+
+int lsk_stencil_fill_coo_f64(int dim, const int64_t *extent, int noffsets, const int64_t *offsets,
+                             const double *coeffs, int64_t row_lo, int64_t row_hi,
+                             const int64_t *rects, int64_t k_base, int64_t *row, int64_t *col,
+                             double *val, lsk_stream_t stream) {
+    return launch_fill<double, true>("lsk_stencil_fill_coo_f64", dim, extent, noffsets, offsets,
+                                     coeffs, row_lo, row_hi, rects, k_base, row, col, val, stream);
+}
+
+int lsk_rects_from_counts_i64(int64_t rows, const int64_t *counts, const int64_t *prefix_incl,
+                              int64_t base, int64_t *rects, lsk_stream_t stream) {
+    if (rows < 0) return lsk::fail(LSK_ERR_ARG, "lsk_rects_from_counts_i64: negative rows");
+    if (rows == 0) return LSK_OK;
+    if (!counts || !prefix_incl || !rects)
+        return lsk::fail(LSK_ERR_ARG, "lsk_rects_from_counts_i64: null pointer");
+    rects_from_counts_kernel<<<grid_for(rows), kBlock, 0, lsk::as_stream(stream)>>>(
+        rows, reinterpret_cast<const long long *>(counts),
+        reinterpret_cast<const long long *>(prefix_incl), base, reinterpret_cast<long long *>(rects));
+    LSK_LAUNCH_CHECK();
+    return LSK_OK;
+}
+
+int lsk_index_bounds_i64(int64_t n, const int64_t *idx, int64_t *out_minmax, lsk_stream_t stream) {
+    if (n < 0) return lsk::fail(LSK_ERR_ARG, "lsk_index_bounds_i64: negative length");
+    if (!out_minmax) return lsk::fail(LSK_ERR_ARG, "lsk_index_bounds_i64: null output");
+    hipStream_t s = lsk::as_stream(stream);
+    bounds_init_kernel<<<1, 1, 0, s>>>(reinterpret_cast<long long *>(out_minmax));
+    LSK_LAUNCH_CHECK();
+    if (n == 0) return LSK_OK;
+    if (!idx) return lsk::fail(LSK_ERR_ARG, "lsk_index_bounds_i64: null input");
+    int blocks = grid_for(n);
+    if (blocks > lsk::kMaxGridBlocks) blocks = lsk::kMaxGridBlocks;
+    index_bounds_kernel<<<blocks, kBlock, 0, s>>>(n, reinterpret_cast<const long long *>(idx),
+                                                  reinterpret_cast<long long *>(out_minmax));
+    LSK_LAUNCH_CHECK();
+    return LSK_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,211 @@
+// Runtime shim: error reporting, per-device state, memory/stream wrappers, get_alpha and the
+// task-id arithmetic.  Replaces src/CUDAUtilities.{hpp,cpp} and src/CudaLibs.{hpp,cu} of
+// the reference; there are no library handles to keep any more, only a reduction scratch.
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+
+#include "lsk_common.hpp"
+
+namespace {
+
+thread_local char g_error[512] = "";
+int g_abort_on_error = 0;
+
+constexpr int kMaxDevices = 64;
+lsk::DeviceState g_devices[kMaxDevices];
+std::mutex g_device_mutex;
+
+} // namespace
+
+namespace lsk {
+
+int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    std::vsnprintf(g_error, sizeof(g_error), fmt, ap);
+    va_end(ap);
+    if (g_abort_on_error) {
+        std::fprintf(stderr, "[lsk] %s\n", g_error);
+        std::abort();
+    }
+    return code;
+}
+
+int hip_fail(hipError_t status, const char *expr, const char *file, int line) {
+    // Same fields the reference prints in check_cuda (src/CUDAUtilities.cpp:13-27).
+    return fail(LSK_ERR_HIP, "HIP failure with status code %d (%s: %s) in %s at %s:%d",
+                static_cast<int>(status), hipGetErrorName(status), hipGetErrorString(status),
+                expr, file, line);
+}
+
+int device_state(DeviceState **out) {
+    int dev = -1;
+    LSK_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= kMaxDevices)
+        return fail(LSK_ERR_UNSUPPORTED, "device ordinal %d outside 0..%d", dev, kMaxDevices - 1);
+    std::lock_guard<std::mutex> lock(g_device_mutex);
+    DeviceState &st = g_devices[dev];
+    if (!st.ready) {
+        LSK_HIP(hipMalloc(&st.scratch, kScratchBytes));
+        st.ready = true;
+    }
+    *out = &st;
+    return LSK_OK;
+}
+
+} // namespace lsk
+
+extern "C" {
+
+const char *lsk_version(void) { return "lsk 0.1 gfx950"; }
+
+const char *lsk_last_error(void) { return g_error; }
+
+void lsk_set_abort_on_error(int enable) { g_abort_on_error = enable; }
+
+int lsk_device_count(int *count) {
+    if (!count) return lsk::fail(LSK_ERR_ARG, "lsk_device_count: null output");
+    int n = 0;
+    hipError_t st = hipGetDeviceCount(&n);
+    if (st == hipErrorNoDevice) {
+        (void)hipGetLastError();
+        *count = 0;
+        return LSK_OK;
+    }
+    LSK_HIP(st);
+    *count = n;
+    return LSK_OK;
+}
+
+int lsk_init(int device) {
+    int n = 0;
+    int rc = lsk_device_count(&n);
+    if (rc != LSK_OK) return rc;
+    if (n == 0) return lsk::fail(LSK_ERR_NO_DEVICE, "lsk_init: no HIP device visible");
+    if (device < 0 || device >= n)
+        return lsk::fail(LSK_ERR_ARG, "lsk_init: device %d outside 0..%d", device, n - 1);
+    LSK_HIP(hipSetDevice(device));
+    lsk::DeviceState *st = nullptr;
+    return lsk::device_state(&st);
+}
+
+int lsk_malloc(void **ptr, size_t bytes) {
+    if (!ptr) return lsk::fail(LSK_ERR_ARG, "lsk_malloc: null output");
+    *ptr = nullptr;
+    if (bytes == 0) return LSK_OK;
+    LSK_HIP(hipMalloc(ptr, bytes));
+    return LSK_OK;
+}
+
+int lsk_free(void *ptr) {
+    if (!ptr) return LSK_OK;
+    LSK_HIP(hipFree(ptr));
+    return LSK_OK;
+}
+
+int lsk_stream_create(lsk_stream_t *stream) {
+    if (!stream) return lsk::fail(LSK_ERR_ARG, "lsk_stream_create: null output");
+    hipStream_t s = nullptr;
+    // Default priority on purpose: mixed-priority streams are not used anywhere.
+    LSK_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *stream = reinterpret_cast<lsk_stream_t>(s);
+    return LSK_OK;
+}
+
+int lsk_stream_destroy(lsk_stream_t stream) {
+    if (!stream) return LSK_OK;
+    LSK_HIP(hipStreamDestroy(lsk::as_stream(stream)));
+    return LSK_OK;
+}
+
+int lsk_stream_synchronize(lsk_stream_t stream) {
+    LSK_HIP(hipStreamSynchronize(lsk::as_stream(stream)));
+    return LSK_OK;
+}
+
+int lsk_stream_check(lsk_stream_t stream) {
+    LSK_HIP(hipStreamSynchronize(lsk::as_stream(stream)));
+    LSK_HIP(hipPeekAtLastError());
+    return LSK_OK;
+}
+
+int lsk_memcpy_h2d(void *dst, const void *src, size_t bytes, lsk_stream_t stream) {
+    if (bytes == 0) return LSK_OK;
+    if (!dst || !src) return lsk::fail(LSK_ERR_ARG, "lsk_memcpy_h2d: null pointer");
+    LSK_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, lsk::as_stream(stream)));
+    return LSK_OK;
+}
+
+int lsk_memcpy_d2h(void *dst, const void *src, size_t bytes, lsk_stream_t stream) {
+    if (bytes == 0) return LSK_OK;
+    if (!dst || !src) return lsk::fail(LSK_ERR_ARG, "lsk_memcpy_d2h: null pointer");
+    LSK_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, lsk::as_stream(stream)));
+    return LSK_OK;
+}
+
+int lsk_memcpy_d2d(void *dst, const void *src, size_t bytes, lsk_stream_t stream) {
+    if (bytes == 0) return LSK_OK;
+    if (!dst || !src) return lsk::fail(LSK_ERR_ARG, "lsk_memcpy_d2d: null pointer");
+    LSK_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, lsk::as_stream(stream)));
+    return LSK_OK;
+}
+
+// ---- get_alpha (src/LegionUtilities.cpp:72-97), host side -----------------------------
+
+#define LSK_GET_ALPHA(SUFFIX, T)                                                       \
+    int lsk_get_alpha_##SUFFIX(int nf, const T *f, T *alpha) {                         \
+        if (!alpha) return lsk::fail(LSK_ERR_ARG, "lsk_get_alpha: null output");       \
+        if (nf < 0 || nf > 4)                                                          \
+            return lsk::fail(LSK_ERR_ARG, "lsk_get_alpha: %d futures (0..4 allowed)", nf); \
+        if (nf > 0 && !f) return lsk::fail(LSK_ERR_ARG, "lsk_get_alpha: null futures"); \
+        switch (nf) {                                                                  \
+        case 0: *alpha = static_cast<T>(1); break;                                     \
+        case 1: *alpha = f[0]; break;                                                  \
+        case 2: *alpha = f[0] / f[1]; break;                                           \
+        case 3: *alpha = (f[0] * f[1]) / f[2]; break;                                  \
+        default: *alpha = (f[0] * f[1]) / (f[2] * f[3]); break;                        \
+        }                                                                              \
+        return LSK_OK;                                                                 \
+    }
+LSK_GET_ALPHA(f32, float)
+LSK_GET_ALPHA(f64, double)
+#undef LSK_GET_ALPHA
+
+// ---- task ids (src/TaskBaseClasses.hpp) ----------------------------------------------
+
+namespace {
+constexpr int64_t kTaskIdOrigin = 500000; // LEGION_SOLVERS_TASK_ID_ORIGIN, LibraryOptions.hpp:25
+constexpr int64_t kNumMetaTaskIds = 1;    // LOAD_CUDA_LIBS_META_TASK_ID only, TaskIDs.hpp:9-14
+constexpr int64_t kNumEntryTypes = 3;     // TypeList<float, double, void>
+constexpr int64_t kNumIndexTypes = 4;     // TypeList<int, unsigned, long long, void>
+constexpr int64_t kMaxDim = 3;            // LEGION_SOLVERS_MAX_DIM
+constexpr int64_t kIdx1 = kNumIndexTypes, kIdx2 = kIdx1 * kNumIndexTypes,
+                  kIdx3 = kIdx2 * kNumIndexTypes;
+constexpr int64_t kDim1 = kMaxDim, kDim2 = kDim1 * kMaxDim, kDim3 = kDim2 * kMaxDim;
+constexpr int64_t kBlockSize = kNumEntryTypes * kDim3 * kIdx3; // 5184
+inline int64_t block_origin(int block_id) {
+    return kTaskIdOrigin + kNumMetaTaskIds + kBlockSize * block_id;
+}
+} // namespace
+
+int64_t lsk_task_id_t(int block_id, int entry_index) { return block_origin(block_id) + entry_index; }
+
+int64_t lsk_task_id_di(int block_id, int dim, int index_type_index) {
+    return block_origin(block_id) + kMaxDim * index_type_index + (dim - 1);
+}
+
+int64_t lsk_task_id_tdi(int block_id, int entry_index, int dim, int index_type_index) {
+    return block_origin(block_id) + kNumEntryTypes * kMaxDim * index_type_index +
+           kNumEntryTypes * (dim - 1) + entry_index;
+}
+
+int64_t lsk_task_id_tdddiii(int block_id, int entry_index, int n1, int n2, int n3, int i1,
+                            int i2, int i3) {
+    return block_origin(block_id) + kIdx3 * kNumEntryTypes * kDim2 * (n1 - 1) +
+           kIdx3 * kNumEntryTypes * kDim1 * (n2 - 1) + kIdx3 * kNumEntryTypes * 1 * (n3 - 1) +
+           kIdx2 * kNumEntryTypes * i1 + kIdx1 * kNumEntryTypes * i2 +
+           1 * kNumEntryTypes * i3 + entry_index;
+}
+
+} // extern "C"

@@ -1,0 +1,174 @@
+"""Matrix classes: the reference's AbstractMatrix / CSRMatrix / COOMatrix
+(src/AbstractMatrix.hpp, src/CSRMatrix.{hpp,cpp}, src/COOMatrix.{hpp,cpp}).
+
+A matrix object holds THIS RANK's shard in the reference's own layout:
+  CSR  rects  (rows, 2) int64   {lo, hi} inclusive GLOBAL kernel indices, one per owned row
+       col    (nnz,)    int64   global column ids        (kernel entries k_base .. k_base+nnz-1)
+       val    (nnz,)    T
+  COO  row, col (nnz,) int64 global ids, val (nnz,) T.
+The partition methods keep the reference's names; they return the per-piece kernel and ghost
+intervals that Legion's dependent partitioning would produce (as bounding intervals), computed
+on the device.  `matvec` is one leaf launch per local piece.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List, Tuple
+
+import torch
+
+from .index_space import IndexPartition, IndexSpace
+from .partitioned_vector import PartitionedVector
+
+Interval = Tuple[int, int]
+
+
+@dataclass
+class PiecePartition:
+    """One inclusive interval per LOCAL piece (colour order); hi < lo means empty."""
+    colors: range
+    intervals: List[Interval]
+
+
+class AbstractMatrix:
+    """Interface of src/AbstractMatrix.hpp as the planner uses it."""
+
+    dtype: torch.dtype
+
+    def create_kernel_partition_from_range_partition(self, range_partition: IndexPartition) -> PiecePartition:
+        raise NotImplementedError
+
+    def create_domain_partition_from_kernel_partition(self, domain_space: IndexSpace,
+                                                      kernel_partition: PiecePartition) -> PiecePartition:
+        raise NotImplementedError
+
+    def matvec(self, dst: PartitionedVector, x: torch.Tensor, x_lo: int, x_hi: int,
+               kernel_partition: PiecePartition, beta: int) -> None:
+        raise NotImplementedError
+
+    def rmatvec(self, *args, **kwargs):
+        # CSRRmatvecTask / COORmatvecTask are assert(false) in the reference
+        # (src/CSRMatrixTasks.cpp:95-100, src/COOMatrixTasks.cpp:78-83).
+        raise NotImplementedError("rmatvec is not implemented (nor in the reference)")
+
+
+class CSRMatrix(AbstractMatrix):
+    def __init__(self, ctx, rects: torch.Tensor, k_base: int, col: torch.Tensor, val: torch.Tensor,
+                 range_space: IndexSpace, row_lo: int):
+        """rects: this rank's rows row_lo .. row_lo+rows-1; col/val: the kernel entries
+        k_base .. k_base+nnz-1 those rects point into."""
+        if rects.dtype != torch.int64 or col.dtype != torch.int64:
+            raise TypeError("rects and col must be int64 (the reference's long long coordinates)")
+        if rects.dim() != 2 or rects.shape[1] != 2 or not rects.is_contiguous():
+            raise ValueError("rects must be a contiguous (rows, 2) tensor")
+        if col.numel() != val.numel():
+            raise ValueError("col and val differ in length")
+        self.ctx = ctx
+        self.rects, self.k_base, self.col, self.val = rects, int(k_base), col, val
+        self.dtype = val.dtype
+        self.range_space = range_space
+        self.row_lo = int(row_lo)
+        self.rows = rects.shape[0]
+        self.nnz = col.numel()
+
+    def create_kernel_partition_from_range_partition(self, range_partition):
+        """Image-range of the rowptr rects over each piece's rows (src/CSRMatrix.cpp:89-109)."""
+        colors = range_partition.colors_of_rank(self.ctx.rank, self.ctx.world_size)
+        out = []
+        for c in colors:
+            p = range_partition.pieces[c]
+            lo, hi = p.lo[0] - self.row_lo, p.hi[0] - self.row_lo
+            if hi < lo:
+                out.append((0, -1))
+                continue
+            if lo < 0 or hi >= self.rows:
+                raise ValueError("range piece lies outside this rank's rows")
+            out.append(self.ctx.backend.rect_bounds(self.rects[lo:hi + 1]))
+        return PiecePartition(colors, out)
+
+    def create_domain_partition_from_kernel_partition(self, domain_space, kernel_partition):
+        """Image of the column field over each kernel piece (src/CSRMatrix.cpp:112-132)."""
+        return _ghost_from_kernel(self.ctx, self.col, self.k_base, domain_space, kernel_partition)
+
+    def matvec(self, dst, x, x_lo, x_hi, kernel_partition, beta, range_partition=None):
+        """CSRMatrix::matvec (src/CSRMatrix.cpp:158-214): one csr_matvec leaf per piece."""
+        range_partition = range_partition or dst.index_partition
+        for i, c in enumerate(kernel_partition.colors):
+            p = range_partition.pieces[c]
+            rows = p.volume
+            if rows == 0:
+                continue
+            r0 = p.lo[0] - self.row_lo
+            k_lo, k_hi = kernel_partition.intervals[i]
+            nnz = max(k_hi - k_lo + 1, 0)
+            off = (k_lo - self.k_base) if nnz else 0
+            self.ctx.backend.csr_spmv(rows, nnz, self.rects[r0:r0 + rows], k_lo if nnz else self.k_base,
+                                      self.col[off:off + nnz], self.val[off:off + nnz], x, x_lo, x_hi,
+                                      dst.piece(i), beta)
+
+
+class COOMatrix(AbstractMatrix):
+    def __init__(self, ctx, row: torch.Tensor, col: torch.Tensor, val: torch.Tensor,
+                 range_space: IndexSpace):
+        """This rank's entries: every entry whose row this rank owns (the preimage of its
+        range pieces).  Row-sorted entries give one contiguous kernel piece per range piece."""
+        if row.dtype != torch.int64 or col.dtype != torch.int64:
+            raise TypeError("row and col must be int64")
+        if not (row.numel() == col.numel() == val.numel()):
+            raise ValueError("row, col and val differ in length")
+        self.ctx = ctx
+        self.row, self.col, self.val = row, col, val
+        self.dtype = val.dtype
+        self.range_space = range_space
+        self.nnz = val.numel()
+        self.row_sorted = bool((row[1:] >= row[:-1]).all()) if self.nnz > 1 else True
+
+    def create_kernel_partition_from_range_partition(self, range_partition):
+        """Preimage of the row field (src/COOMatrix.cpp:77-95).  For row-sorted entries each
+        piece is the contiguous run of its rows; otherwise every piece spans all local
+        entries and the leaf's row guard selects (src/COOMatrixTasks.cpp:71)."""
+        colors = range_partition.colors_of_rank(self.ctx.rank, self.ctx.world_size)
+        out = []
+        for c in colors:
+            p = range_partition.pieces[c]
+            if p.volume == 0 or self.nnz == 0:
+                out.append((0, -1))
+            elif self.row_sorted:
+                bounds = torch.tensor([p.lo[0], p.hi[0] + 1], dtype=torch.int64, device=self.row.device)
+                lo, hi = torch.searchsorted(self.row, bounds).tolist()
+                out.append((int(lo), int(hi) - 1))
+            else:
+                out.append((0, self.nnz - 1))
+        return PiecePartition(colors, out)
+
+    def create_domain_partition_from_kernel_partition(self, domain_space, kernel_partition):
+        return _ghost_from_kernel(self.ctx, self.col, 0, domain_space, kernel_partition)
+
+    def matvec(self, dst, x, x_lo, x_hi, kernel_partition, beta=1, range_partition=None):
+        """COOMatrix::matvec (src/COOMatrix.cpp:144-191): accumulates; dst must hold the
+        values to add to (the planner zero-fills it)."""
+        if beta != 1:
+            raise ValueError("COO matvec accumulates (beta = 1)")
+        range_partition = range_partition or dst.index_partition
+        for i, c in enumerate(kernel_partition.colors):
+            p = range_partition.pieces[c]
+            k_lo, k_hi = kernel_partition.intervals[i]
+            nnz = max(k_hi - k_lo + 1, 0)
+            if p.volume == 0 or nnz == 0:
+                continue
+            self.ctx.backend.coo_spmv(nnz, self.row[k_lo:k_lo + nnz], self.col[k_lo:k_lo + nnz],
+                                      self.val[k_lo:k_lo + nnz], x, x_lo, x_hi, dst.piece(i),
+                                      p.lo[0], p.hi[0])
+
+
+def _ghost_from_kernel(ctx, col, k_base, domain_space, kernel_partition) -> PiecePartition:
+    d_lo, d_hi = domain_space.rect.lo[0], domain_space.rect.hi[0]
+    out = []
+    for k_lo, k_hi in kernel_partition.intervals:
+        if k_hi < k_lo:
+            out.append((0, -1))
+            continue
+        lo, hi = ctx.backend.index_bounds(col[k_lo - k_base:k_hi - k_base + 1])
+        lo, hi = max(lo, d_lo), min(hi, d_hi)  # the image is taken inside the domain space
+        out.append((lo, hi) if hi >= lo else (0, -1))
+    return PiecePartition(kernel_partition.colors, out)

@@ -1,0 +1,118 @@
+"""The reference's Krylov solvers, unchanged as callers of the planner: CGSolver
+(src/CGSolver.hpp), BiCGStabSolver (src/BiCGStabSolver.hpp), GMRESSolver
+(src/GMRESSolver.hpp).  Each step() issues exactly the reference's sequence of planner
+operations; all scalars are device-resident futures, so a step enqueues without a host sync.
+"""
+from __future__ import annotations
+
+from typing import List
+
+from .scalar import Scalar
+from .square_planner import SquarePlanner
+
+SOL = 0
+RHS = 1
+
+
+class CGSolver:
+    """src/CGSolver.hpp:13-57."""
+    P, Q, R = 2, 3, 4
+
+    def __init__(self, planner: SquarePlanner):
+        self.planner = planner
+        self.residual_norm_squared: List[Scalar] = []
+        self.negative_one = Scalar(planner.get_context(), -1.0, planner.dtype)
+        planner.allocate_workspace(3)
+        planner.copy(self.P, RHS)
+        planner.copy(self.R, RHS)
+        self.residual_norm_squared.append(planner.dot(self.R, self.R))
+
+    def step(self) -> None:
+        pl = self.planner
+        pl.matvec(self.Q, self.P)
+        p_norm = pl.dot(self.P, self.Q)
+        r_norm2_old = self.residual_norm_squared[-1]
+        pl.axpy(SOL, r_norm2_old, p_norm, self.P)
+        pl.axpy(self.R, self.negative_one, r_norm2_old, p_norm, self.Q)
+        r_norm2_new = pl.dot(self.R, self.R)
+        self.residual_norm_squared.append(r_norm2_new)
+        pl.xpay(self.P, r_norm2_new, r_norm2_old, self.R)
+
+
+class BiCGStabSolver:
+    """src/BiCGStabSolver.hpp:13-84."""
+    P, R, R_TILDE, U, V = 2, 3, 4, 5, 6
+
+    def __init__(self, planner: SquarePlanner):
+        self.planner = planner
+        ctx, dt = planner.get_context(), planner.dtype
+        self.negative_one = Scalar(ctx, -1.0, dt)
+        self.zero = Scalar(ctx, 0.0, dt)
+        self.one = Scalar(ctx, 1.0, dt)
+        planner.allocate_workspace(5)
+        planner.copy(self.R, RHS)
+        planner.copy(self.R_TILDE, RHS)
+        self.rho: List[Scalar] = [self.one]
+        self.alpha: List[Scalar] = [self.zero]
+        self.omega: List[Scalar] = [self.one]
+        planner.zero_fill(self.P)
+        planner.zero_fill(self.V)
+
+    def step(self) -> None:
+        pl = self.planner
+        rho_new = pl.dot(self.R, self.R_TILDE)
+        beta = (rho_new / self.rho[-1]) * (self.alpha[-1] / self.omega[-1])
+        self.rho.append(rho_new)
+        pl.axpy(self.P, -self.omega[-1], self.V)
+        pl.xpay(self.P, beta, self.R)
+        pl.matvec(self.V, self.P)
+        temp = pl.dot(self.R_TILDE, self.V)
+        pl.axpy(self.R, self.negative_one, self.rho[-1], temp, self.V)
+        self.alpha.append(self.rho[-1] / temp)
+        pl.matvec(self.U, self.R)
+        r_anorm2 = pl.dot(self.R, self.U)
+        u_norm2 = pl.dot(self.U, self.U)
+        self.omega.append(r_anorm2 / u_norm2)
+        pl.axpy(SOL, self.alpha[-1], self.P)
+        pl.axpy(SOL, self.omega[-1], self.R)
+        pl.axpy(self.R, -self.omega[-1], self.U)
+
+
+class GMRESSolver:
+    """src/GMRESSolver.hpp:15-129.  Like the reference, the least-squares solve is not
+    there yet: the solution update uses DummyTask's coefficient 1 for every basis vector
+    (:109-126, src/UtilityTasks.cpp:96-99)."""
+
+    def __init__(self, planner: SquarePlanner, restart: int):
+        self.planner = planner
+        self.restart = int(restart)
+        ctx, dt = planner.get_context(), planner.dtype
+        self.negative_one = Scalar(ctx, -1.0, dt)
+        planner.allocate_workspace(self.restart + 1)
+        zero = Scalar(ctx, 0.0, dt)
+        self.inner_products = [[zero for _ in range(self.restart)] for _ in range(self.restart + 1)]
+        self.dummy_coefficient = Scalar(ctx, 1.0, dt)
+
+    @staticmethod
+    def krylov_basis(i: int) -> int:
+        return i + 2
+
+    def step(self) -> None:
+        pl, kb = self.planner, self.krylov_basis
+        # compute residual vector
+        pl.matvec(kb(0), SOL)
+        pl.xpay(kb(0), self.negative_one, RHS)
+        residual_norm = pl.dot(kb(0), kb(0)).rsqrt()
+        pl.scal(kb(0), residual_norm)
+        for j in range(self.restart):
+            pl.matvec(kb(j + 1), kb(j))
+            for k in range(j + 1):
+                self.inner_products[k][j] = pl.dot(kb(k), kb(j + 1))
+                pl.axpy(kb(j + 1), -self.inner_products[k][j], kb(k))
+            d = pl.dot(kb(j + 1), kb(j + 1))
+            self.inner_products[j + 1][j] = d.sqrt()
+            if j + 1 < self.restart:
+                pl.scal(kb(j + 1), d.rsqrt())
+        coeff = self.dummy_coefficient
+        for j in range(self.restart):
+            pl.axpy(SOL, coeff, kb(j))

@@ -1,0 +1,228 @@
+"""SquarePlanner: the reference's multi-space square-system planner (src/SquarePlanner.hpp).
+
+Vector index 0 is the solution, 1 the right-hand side, 2.. the workspace the solver asks
+for; every method applies one vector operation to all spaces.  On top of the reference's
+bookkeeping it does the one thing Legion does implicitly there: before a matvec it brings the
+ghost cells of x into the consuming GPU's memory (the READ_ONLY ghost-partition requirement of
+src/CSRMatrix.cpp:202-211), here with point-to-point RCCL transfers straight into the halo
+room of the source vector.
+"""
+from __future__ import annotations
+
+from typing import List, Tuple
+
+import torch
+
+from .comm import HaloPlan, build_halo_plan
+from .index_space import IndexPartition, IndexSpace
+from .matrices import AbstractMatrix, COOMatrix, PiecePartition
+from .partitioned_vector import PartitionedVector
+from .scalar import Scalar
+
+
+def _hull(intervals) -> Tuple[int, int]:
+    live = [iv for iv in intervals if iv[1] >= iv[0]]
+    if not live:
+        return (0, -1)
+    return min(iv[0] for iv in live), max(iv[1] for iv in live)
+
+
+class _MatrixEntry:
+    def __init__(self, matrix, domain_index, range_index, kernel_partition, ghost_partition, plan):
+        self.matrix = matrix
+        self.domain_index = domain_index
+        self.range_index = range_index
+        self.kernel_partition: PiecePartition = kernel_partition
+        self.ghost_partition: PiecePartition = ghost_partition
+        self.plan: HaloPlan = plan
+        self.staging = None  # ghost buffer for source vectors without halo room
+
+
+class SquarePlanner:
+    def __init__(self, ctx, dtype: torch.dtype = torch.float64):
+        self.ctx = ctx
+        self.dtype = dtype
+        self.canonical_index_spaces: List[IndexSpace] = []
+        self.canonical_index_partitions: List[IndexPartition] = []
+        self.sol_vectors: List[PartitionedVector] = []
+        self.rhs_vectors: List[PartitionedVector] = []
+        self.workspace_vectors: List[List[PartitionedVector]] = []
+        self.row_partitioned_matrices: List[_MatrixEntry] = []
+
+    def get_context(self):
+        return self.ctx
+
+    # -- registration (src/SquarePlanner.hpp:99-235) --------------------------------------
+    def _register(self, v: PartitionedVector, vectors: list) -> int:
+        if self.workspace_vectors:
+            raise RuntimeError("vectors must be added before the workspace is allocated")
+        if v.dtype != self.dtype:
+            raise TypeError("vector entry type differs from the planner's")
+        idx = len(vectors)
+        if len(self.canonical_index_spaces) > idx:
+            if self.canonical_index_spaces[idx] != v.get_index_space():
+                raise ValueError("index space differs from the canonical one of this slot")
+            if self.canonical_index_partitions[idx] != v.get_index_partition():
+                raise ValueError("partition differs from the canonical one of this slot")
+        else:
+            self.canonical_index_spaces.append(v.get_index_space())
+            self.canonical_index_partitions.append(v.get_index_partition())
+        vectors.append(v)
+        return idx
+
+    def add_sol_vector(self, v: PartitionedVector) -> int:
+        return self._register(v, self.sol_vectors)
+
+    def add_rhs_vector(self, v: PartitionedVector) -> int:
+        return self._register(v, self.rhs_vectors)
+
+    def get_num_spaces(self) -> int:
+        n = len(self.canonical_index_spaces)
+        if not (n == len(self.sol_vectors) == len(self.rhs_vectors)):
+            raise RuntimeError("every space needs one solution and one right-hand-side vector")
+        return n
+
+    def add_row_partitioned_matrix(self, matrix: AbstractMatrix, domain_index: int,
+                                   range_index: int) -> None:
+        n = self.get_num_spaces()
+        if not (0 <= domain_index < n and 0 <= range_index < n):
+            raise IndexError("matrix refers to a space the planner does not have")
+        if matrix.dtype != self.dtype:
+            raise TypeError("matrix entry type differs from the planner's")
+        range_partition = self.canonical_index_partitions[range_index]
+        domain_partition = self.canonical_index_partitions[domain_index]
+        domain_space = self.canonical_index_spaces[domain_index]
+        if domain_space.dim != 1 or self.canonical_index_spaces[range_index].dim != 1:
+            raise ValueError("matrices act on 1-D index spaces")
+        kernel_partition = matrix.create_kernel_partition_from_range_partition(range_partition)
+        ghost_partition = matrix.create_domain_partition_from_kernel_partition(
+            domain_space, kernel_partition)
+        # Who owns and who reads which interval of x: gathered once, then fixed.
+        rank, world = self.ctx.rank, self.ctx.world_size
+        mine = (domain_partition.rank_interval(rank, world), _hull(ghost_partition.intervals))
+        everyone = self.ctx.comm.all_gather_object(mine)
+        plan = build_halo_plan(rank, [e[0] for e in everyone], [e[1] for e in everyone])
+        self.row_partitioned_matrices.append(
+            _MatrixEntry(matrix, domain_index, range_index, kernel_partition, ghost_partition, plan))
+
+    def _halo_pad(self, space_index: int) -> Tuple[int, int]:
+        lo = hi = 0
+        for e in self.row_partitioned_matrices:
+            if e.domain_index == space_index:
+                lo, hi = max(lo, e.plan.pad_lo), max(hi, e.plan.pad_hi)
+        return lo, hi
+
+    def allocate_workspace(self, num_vectors: int) -> None:
+        """Workspace vectors get halo room for every matrix that reads their space, so a
+        matvec gathers ghost cells in place (src/SquarePlanner.hpp:153-188 allocates plain
+        fields; the ghost instances are Legion's)."""
+        if self.workspace_vectors:
+            raise RuntimeError("workspace already allocated")
+        n = self.get_num_spaces()
+        for j in range(num_vectors):
+            row = []
+            for i in range(n):
+                row.append(PartitionedVector(self.ctx, f"workspace_{j}_{i}",
+                                             self.canonical_index_partitions[i], self.dtype,
+                                             pad=self._halo_pad(i)))
+            self.workspace_vectors.append(row)
+
+    def get_vector(self, vec_idx: int, space_idx: int) -> PartitionedVector:
+        if vec_idx == 0:
+            return self.sol_vectors[space_idx]
+        if vec_idx == 1:
+            return self.rhs_vectors[space_idx]
+        return self.workspace_vectors[vec_idx - 2][space_idx]
+
+    def _scalar(self, s) -> Scalar:
+        return s if isinstance(s, Scalar) else Scalar(self.ctx, s, self.dtype)
+
+    # -- vector operations over all spaces (src/SquarePlanner.hpp:248-338) -----------------
+    def zero_fill(self, vec_idx: int) -> None:
+        for i in range(self.get_num_spaces()):
+            self.get_vector(vec_idx, i).zero_fill()
+
+    def copy(self, dst_index: int, src_index: int) -> None:
+        for i in range(self.get_num_spaces()):
+            self.get_vector(dst_index, i).assign(self.get_vector(src_index, i))
+
+    def scal(self, dst_index: int, alpha) -> None:
+        alpha = self._scalar(alpha)
+        for i in range(self.get_num_spaces()):
+            self.get_vector(dst_index, i).scal(alpha)
+
+    def axpy(self, dst_index: int, *args) -> None:
+        """axpy(dst, alpha, src) | axpy(dst, numer, denom, src) | axpy(dst, n1, n2, denom, src)."""
+        *scalars, src_index = args
+        scalars = [self._scalar(s) for s in scalars]
+        for i in range(self.get_num_spaces()):
+            self.get_vector(dst_index, i).axpy(*scalars, self.get_vector(src_index, i))
+
+    def xpay(self, dst_index: int, *args) -> None:
+        """xpay(dst, alpha, src) | xpay(dst, numer, denom, src)."""
+        *scalars, src_index = args
+        scalars = [self._scalar(s) for s in scalars]
+        for i in range(self.get_num_spaces()):
+            self.get_vector(dst_index, i).xpay(*scalars, self.get_vector(src_index, i))
+
+    def dot(self, v_idx: int, w_idx: int) -> Scalar:
+        """Sum over spaces of the per-space dot products (src/SquarePlanner.hpp:331-338).  The
+        per-space results cross the ranks in ONE all-reduce of num_spaces scalars and are then
+        added left to right, as the reference's chain of AddScalarTasks does."""
+        n = self.get_num_spaces()
+        be = self.ctx.backend
+        slots = be.empty(n, self.dtype)
+        for i in range(n):
+            self.get_vector(v_idx, i).dot_local(self.get_vector(w_idx, i), slots[i:i + 1])
+        self.ctx.comm.all_reduce_sum(slots)
+        if n == 1:
+            return Scalar(self.ctx, slots)
+        out = be.empty(1, self.dtype)
+        be.sum_scalars(slots, out)
+        return Scalar(self.ctx, out)
+
+    # -- matvec (src/SquarePlanner.hpp:340-357) ---------------------------------------------
+    def _gather_ghost(self, e: _MatrixEntry, src: PartitionedVector):
+        """Returns (x tensor, x_lo, x_hi): the ghost instance of `src` for matrix entry `e`,
+        after bringing in the cells other ranks own."""
+        plan = e.plan
+        own_lo, own_hi = src.own_lo, src.own_hi
+        if not plan.recvs and not plan.sends:
+            return src.owned, own_lo, own_hi
+        if src.pad_lo >= plan.pad_lo and src.pad_hi >= plan.pad_hi:
+            buf, base = src.data, own_lo - src.pad_lo      # gather in place
+        else:
+            need = plan.pad_lo + src.local_size + plan.pad_hi
+            if e.staging is None or e.staging.numel() != need:
+                e.staging = self.ctx.backend.empty(need, self.dtype)
+            buf, base = e.staging, own_lo - plan.pad_lo
+            if src.local_size:
+                self.ctx.backend.copy(buf[plan.pad_lo:plan.pad_lo + src.local_size], src.owned)
+        sends = [(t.peer, src.owned[t.start - own_lo:t.start - own_lo + t.count]) for t in plan.sends]
+        recvs = [(t.peer, buf[t.start - base:t.start - base + t.count]) for t in plan.recvs]
+        self.ctx.comm.exchange(sends, recvs)
+        x_lo = own_lo - plan.pad_lo
+        x_hi = own_hi + plan.pad_hi
+        return buf[x_lo - base:x_hi - base + 1], x_lo, x_hi
+
+    def matvec(self, dst_idx: int, src_idx: int) -> None:
+        """dst <- A src over all registered matrices.  The first CSR matrix into a range space
+        overwrites it (beta = 0), every further matrix accumulates (beta = 1); a COO matrix
+        always accumulates, onto a zero fill if it comes first.  The result equals the
+        reference's zero_fill followed by accumulating matvecs."""
+        touched = set()
+        for e in self.row_partitioned_matrices:
+            dst = self.get_vector(dst_idx, e.range_index)
+            src = self.get_vector(src_idx, e.domain_index)
+            first = e.range_index not in touched
+            touched.add(e.range_index)
+            x, x_lo, x_hi = self._gather_ghost(e, src)
+            if isinstance(e.matrix, COOMatrix):
+                if first:
+                    dst.zero_fill()
+                e.matrix.matvec(dst, x, x_lo, x_hi, e.kernel_partition, 1)
+            else:
+                e.matrix.matvec(dst, x, x_lo, x_hi, e.kernel_partition, 0 if first else 1)
+        for i in range(self.get_num_spaces()):
+            if i not in touched:
+                self.get_vector(dst_idx, i).zero_fill()

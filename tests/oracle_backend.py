@@ -1,0 +1,87 @@
+"""A leaf backend for CPU-only tests of the HOST logic (vectors, planner, halo exchange,
+all-reduce, solver sequences): same method surface as legionsolvers_amd.backend.HipBackend, but
+every leaf operation is the CPU oracle on CPU torch tensors.
+
+It lives under tests/ and is injected by tests only; the package itself has no such path.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+import oracle
+from oracle import partition as part
+
+_OPS = {0: "neg", 1: "add", 2: "sub", 3: "mul", 4: "div", 5: "sqrt", 6: "rsqrt", 7: "copy"}
+
+
+def _np(t: torch.Tensor) -> np.ndarray:
+    return t.numpy()  # shares memory with the (contiguous, CPU) tensor view
+
+
+class OracleBackend:
+    name = "oracle"
+
+    def __init__(self):
+        self.device = torch.device("cpu")
+
+    def stream(self):
+        return None
+
+    def empty(self, n, dtype):
+        return torch.zeros(int(n), dtype=dtype)
+
+    def new_scalar(self, value, dtype):
+        return torch.full((1,), value, dtype=dtype)
+
+    def synchronize(self):
+        pass
+
+    @staticmethod
+    def _alpha(futs, dtype):
+        return oracle.get_alpha([f.item() for f in futs], _np(torch.zeros(0, dtype=dtype)).dtype)
+
+    def fill(self, x, value):
+        x.fill_(value)
+
+    def copy(self, dst, src):
+        dst.copy_(src)
+
+    def scal(self, x, futs):
+        oracle.scal(self._alpha(futs, x.dtype), _np(x))
+
+    def axpy(self, y, futs, x):
+        oracle.axpy(self._alpha(futs, y.dtype), _np(x), _np(y))
+
+    def xpay(self, y, futs, x):
+        oracle.xpay(self._alpha(futs, y.dtype), _np(x), _np(y))
+
+    def dot(self, v, w, out):
+        out[0] = float(oracle.dot(_np(v), _np(w))) if v.numel() else 0.0
+
+    def sum_scalars(self, inp, out):
+        a = _np(inp)
+        acc = a[0]
+        for i in range(1, a.size):
+            acc = oracle.scalar_op("add", acc, a[i], a.dtype)
+        out[0] = float(acc)
+
+    def scalar_op(self, op, a, b, out):
+        bv = b.item() if b is not None else 0.0
+        out[0] = float(oracle.scalar_op(_OPS[op], a.item(), bv, _np(a).dtype))
+
+    def csr_spmv(self, rows, nnz, rects, k_base, col, val, x, x_lo, x_hi, y, beta):
+        oracle.csr_matvec(_np(rects), k_base, _np(col), _np(val), _np(x), x_lo, x_hi, _np(y), beta=beta)
+
+    def coo_spmv(self, nnz, row, col, val, x, x_lo, x_hi, y, y_lo, y_hi):
+        oracle.coo_matvec(_np(row), _np(col), _np(val), _np(x), x_lo, x_hi, _np(y), y_lo, y_hi)
+
+    def index_bounds(self, idx):
+        return part.bounds(_np(idx))
+
+    def rect_bounds(self, rects):
+        r = _np(rects)
+        live = r[:, 1] >= r[:, 0]
+        if not live.any():
+            return (0, -1)
+        return int(r[live, 0].min()), int(r[live, 1].max())

@@ -1,0 +1,215 @@
+"""CPU tests of the host mirror's LOGIC: partitions, halo plans, the planner and the solver
+sequences, run with the oracle leaf backend injected (tests/oracle_backend.py) -- in one
+process, and in two gloo ranks to cover the N>1 path (halo gather + dot all-reduce)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import oracle
+from oracle import solvers as S
+
+import host_cases as hc
+from oracle_backend import OracleBackend
+
+from legionsolvers_amd import (BiCGStabSolver, CGSolver, Context, GMRESSolver, IndexPartition,
+                               IndexSpace, PartitionedVector, Scalar)
+from legionsolvers_amd.comm import build_halo_plan
+from legionsolvers_amd.index_space import split_equal
+
+
+# ------------------------------------------------------------------ pure host arithmetic --
+
+def test_equal_partition_matches_oracle_rule():
+    from oracle import partition as part
+    for n in (1, 4, 20, 100, 101, 1024):
+        for p in (1, 3, 4, 8, 10):
+            assert split_equal(0, n - 1, p) == part.equal_partition(0, n - 1, p)
+    ip = IndexPartition.equal(IndexSpace((0, 0, 0), (3, 4, 4)), 10)
+    assert [p.volume for p in ip.pieces] == [0] * 6 + [25] * 4
+    assert list(ip.colors_of_rank(1, 2)) == [5, 6, 7, 8, 9]
+    with pytest.raises(ValueError):
+        ip.colors_of_rank(0, 3)
+
+
+def test_halo_plan_for_a_linearised_stencil():
+    """8 equal row blocks of a 27-point 512^3 grid: each rank reads ny*nz + nz + 1 cells beyond
+    either end of its block, from its two neighbours only."""
+    n, world, h = 512 ** 3, 8, 512 * 512 + 512 + 1
+    owns = split_equal(0, n - 1, world)
+    ghosts = [(max(lo - h, 0), min(hi + h, n - 1)) for lo, hi in owns]
+    for r in range(world):
+        plan = build_halo_plan(r, owns, ghosts)
+        assert sorted(t.peer for t in plan.recvs) == [q for q in (r - 1, r + 1) if 0 <= q < world]
+        assert sorted(t.peer for t in plan.sends) == [q for q in (r - 1, r + 1) if 0 <= q < world]
+        assert all(t.count == h for t in plan.recvs + plan.sends)
+        assert (plan.pad_lo, plan.pad_hi) == (h if r else 0, h if r < world - 1 else 0)
+    # sends of rank r to q mirror the receives of q from r
+    plans = [build_halo_plan(r, owns, ghosts) for r in range(world)]
+    for r in range(world):
+        for t in plans[r].sends:
+            assert any(u.peer == r and u.start == t.start and u.count == t.count for u in plans[t.peer].recvs)
+
+
+def test_halo_plan_all_to_all_and_empty():
+    owns = [(0, 9), (10, 19), (20, 29)]
+    full = build_halo_plan(1, owns, [(0, 29)] * 3)       # unstructured matrix: ghost = all of x
+    assert [(t.peer, t.start, t.count) for t in full.recvs] == [(0, 0, 10), (2, 20, 10)]
+    assert [(t.peer, t.start, t.count) for t in full.sends] == [(0, 10, 10), (2, 10, 10)]
+    none = build_halo_plan(0, owns, [(0, -1), (10, 19), (20, 29)])  # a rank with no entries
+    assert none.recvs == [] and none.sends == [] and none.pad_lo == none.pad_hi == 0
+
+
+# ------------------------------------------------------------------ one process ----------
+
+@pytest.fixture()
+def ctx():
+    return Context(backend=OracleBackend())
+
+
+@pytest.mark.parametrize("kind", ["csr", "coo"])
+def test_cg_single_process_matches_reference_golden(ctx, kind, goldens, krylov_golden):
+    prob = goldens["cg_problem"]
+    rects, row, col, val = oracle.laplacian_1d(prob["n"])
+    pl = hc.mirror_planner(ctx, kind, rects, row, col, val, prob["n"], prob["pieces"], np.float64)
+    solver = CGSolver(pl)
+    for _ in range(prob["iterations"]):
+        solver.step()
+    hist = [s.get_value() for s in solver.residual_norm_squared]
+    assert hist == krylov_golden["cases"][0]["residual_norm_squared"]
+    assert sorted(f"{v:g}" for v in hist) == sorted(goldens["expected_cg_output_sorted_set"])
+
+
+def test_vector_operations_test02(ctx, goldens):
+    """The Test02VectorOperations sequence through PartitionedVector, 1/2/3-D, 10 colours."""
+    for dtype in (torch.float32, torch.float64):
+        for space in (IndexSpace(0, 99), IndexSpace((0, 0), (9, 9)), IndexSpace((0, 0, 0), (3, 4, 4))):
+            ip = IndexPartition.equal(space, 10)
+            u, v, w = (PartitionedVector(ctx, n, ip, dtype) for n in "uvw")
+            u.constant_fill(1.5)
+            v.constant_fill(2.7)
+            w.assign(u)
+            w.axpy(1.0, v)
+            v.xpay(-1.0, u)
+            u.axpy(-0.5, v)
+            u.axpy(-0.5, w)
+            assert f"{u.dot(u).get_value():g}" == goldens["test02_stdout"][0]
+
+
+def test_scalar_operations_test01(ctx, goldens):
+    for dtype in (torch.float32, torch.float64):
+        two, ten = Scalar(ctx, 2.0, dtype), Scalar(ctx, 10.0, dtype)
+        value = ((two + ten) / (two + two) - two).get_value()
+        assert value == goldens["test01_scalar_chain"]["value"]
+        assert (-two).get_value() == -2.0 and Scalar(ctx, 4.0, dtype).rsqrt().get_value() == 0.5
+
+
+@pytest.mark.parametrize("solver_name", ["bicgstab", "gmres"])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_solver_sequences_match_oracle(ctx, solver_name, dtype):
+    """BiCGStab / GMRES(restart) are not pinned by a reference golden; the mirror must issue
+    the same operations as the oracle's restatement of the reference headers: identical
+    results on one process (same leaf ops, same order)."""
+    rects, row, col, val, n = hc.stencil_problem(2, (6, 7), dtype)
+    rhs = np.random.default_rng(3).standard_normal(n)
+    make = (lambda p: BiCGStabSolver(p)) if solver_name == "bicgstab" else (lambda p: GMRESSolver(p, 4))
+    make_o = (lambda p: S.BiCGStabSolver(p)) if solver_name == "bicgstab" else (lambda p: S.GMRESSolver(p, 4))
+    opl = hc.oracle_planner("csr", rects, row, col, val, n, 3, dtype, rhs)
+    mpl = hc.mirror_planner(ctx, "csr", rects, row, col, val, n, 3, dtype, rhs)
+    so, sm = make_o(opl), make(mpl)
+    for _ in range(3):
+        so.step()
+        sm.step()
+    np.testing.assert_array_equal(hc.gather_vector(ctx, mpl.get_vector(0, 0)), opl.get_vector(0, 0))
+    if solver_name == "bicgstab":
+        assert [s.get_value() for s in sm.rho] == [float(v) for v in so.rho]
+        assert [s.get_value() for s in sm.omega] == [float(v) for v in so.omega]
+
+
+def test_planner_rejects_mismatched_inputs(ctx):
+    ip4 = IndexPartition.equal(IndexSpace(0, 19), 4)
+    ip2 = IndexPartition.equal(IndexSpace(0, 19), 2)
+    a, b = PartitionedVector(ctx, "a", ip4), PartitionedVector(ctx, "b", ip2)
+    with pytest.raises(ValueError):
+        a.axpy(1.0, b)
+    with pytest.raises(TypeError):
+        a.axpy(1.0, PartitionedVector(ctx, "c", ip4, torch.float32))
+    with pytest.raises(TypeError):
+        a.axpy(1.0, 2.0, 3.0, 4.0, a)
+    from legionsolvers_amd import SquarePlanner
+    pl = SquarePlanner(ctx)
+    pl.add_sol_vector(a)
+    with pytest.raises(ValueError):
+        pl.add_rhs_vector(b)
+
+
+# ------------------------------------------------------------------ two gloo ranks ---------
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ctx = Context(backend=OracleBackend())
+        assert (ctx.rank, ctx.world_size) == (rank, world)
+        results = {}
+        # (a) Test05/06 over 2 ranks x 2 pieces: halo gather between neighbours + all-reduce
+        for kind in ("csr", "coo"):
+            rects, row, col, val = oracle.laplacian_1d(100)
+            pl = hc.mirror_planner(ctx, kind, rects, row, col, val, 100, 4, np.float64)
+            assert pl.row_partitioned_matrices[0].plan.recvs, "ranks must exchange ghost cells"
+            solver = CGSolver(pl)
+            for _ in range(10):
+                solver.step()
+            results[f"cg_{kind}"] = [s.get_value() for s in solver.residual_norm_squared]
+            results[f"cg_{kind}_sol"] = hc.gather_vector(ctx, pl.get_vector(0, 0))
+        # (b) two systems, 27-point stencil, BiCGStab: wide halos, batched multi-space dots
+        rects, row, col, val, n = hc.stencil_problem(4, (6, 4, 5))
+        rhs = np.random.default_rng(5).standard_normal(n)
+        pl = hc.mirror_planner(ctx, "csr", rects, row, col, val, n, 2, np.float64, rhs, spaces=2)
+        solver = BiCGStabSolver(pl)
+        for _ in range(3):
+            solver.step()
+        results["bicgstab_sol"] = hc.gather_vector(ctx, pl.get_vector(0, 1))
+        # (c) GMRES reads SOL, a vector without halo room: staged ghost buffer
+        pl = hc.mirror_planner(ctx, "coo", rects, row, col, val, n, 4, np.float64, rhs)
+        solver = GMRESSolver(pl, 3)
+        solver.step()
+        solver.step()
+        results["gmres_sol"] = hc.gather_vector(ctx, pl.get_vector(0, 0))
+        if rank == 0:
+            torch.save(results, os.path.join(out_dir, "results.pt"))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo_matches_oracle(tmp_path, krylov_golden):
+    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    res = torch.load(os.path.join(tmp_path, "results.pt"), weights_only=False)
+    golden = krylov_golden["cases"][0]
+    for kind in ("csr", "coo"):
+        np.testing.assert_allclose(res[f"cg_{kind}"], golden["residual_norm_squared"], rtol=1e-12)
+        np.testing.assert_allclose(res[f"cg_{kind}_sol"], golden["x_final"], rtol=1e-10)
+    rects, row, col, val, n = hc.stencil_problem(4, (6, 4, 5))
+    rhs = np.random.default_rng(5).standard_normal(n)
+    opl = hc.oracle_planner("csr", rects, row, col, val, n, 2, np.float64, rhs, spaces=2)
+    so = S.BiCGStabSolver(opl)
+    for _ in range(3):
+        so.step()
+    np.testing.assert_allclose(res["bicgstab_sol"], opl.get_vector(0, 1), rtol=1e-9, atol=1e-12)
+    opl = hc.oracle_planner("coo", rects, row, col, val, n, 4, np.float64, rhs)
+    so = S.GMRESSolver(opl, 3)
+    so.step()
+    so.step()
+    np.testing.assert_allclose(res["gmres_sol"], opl.get_vector(0, 0), rtol=1e-9, atol=1e-12)
