@@ -1,0 +1,177 @@
+#!/usr/bin/env python3
+"""Headline benchmark: CG iterations/s and CSR SpMV GB/s (fp64) on BenchmarkStencil's 3-D
+27-point stencil at 512^3, on N MI355X of one node.
+
+    python bench.py --gpus 1 --steps 50 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A step is one CGSolver::step() over the whole (fixed-size) problem, which is split into N
+equal row blocks, one per rank (strong scaling).  Inputs (matrix, rhs = 1, x0 = 0) are generated
+on the device and resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
+
+Besides the contract's fields the line carries:
+  roofline      the CSR SpMV kernel against the HBM roof: algorithmic bytes of one launch
+                (nnz*16 + rows*32 on this rank) / its mean duration from HIP events
+  cpu_baseline  the CPU oracle's CG step (OpenMP over row blocks) on a bounded 27-point sample,
+                rank 0 at N = 1 only
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+from legionsolvers_amd import Context, IndexPartition, IndexSpace, PartitionedVector  # noqa: E402
+from legionsolvers_amd import benchmark_stencil as bs  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak
+
+
+def spmv_kernel_time(ctx, matrix, planner, reps: int) -> float:
+    """Mean seconds of one CSR SpMV launch on this rank (the kernel alone, no halo traffic),
+    from HIP events recorded on the launch stream."""
+    entry = planner.row_partitioned_matrices[0]
+    src = planner.get_vector(2, 0)  # P
+    dst = planner.get_vector(3, 0)  # Q
+    x, x_lo, x_hi = src.data, src.own_lo - src.pad_lo, src.own_hi + src.pad_hi
+    for _ in range(3):
+        matrix.matvec(dst, x, x_lo, x_hi, entry.kernel_partition, 0)
+    start = torch.cuda.Event(enable_timing=True)
+    stop = torch.cuda.Event(enable_timing=True)
+    ctx.synchronize()
+    start.record()
+    for _ in range(reps):
+        matrix.matvec(dst, x, x_lo, x_hi, entry.kernel_partition, 0)
+    stop.record()
+    stop.synchronize()
+    return start.elapsed_time(stop) * 1e-3 / reps
+
+
+def cpu_baseline(full_rows: int):
+    """CG iterations/s of the CPU oracle, measured on a 256^3 sample of the same 27-point
+    operator and scaled by rows to the full problem."""
+    import numpy as np
+    import oracle
+    n1 = int(os.environ.get("LSK_CPU_SAMPLE", "256"))
+    cores = min(len(os.sched_getaffinity(0)), int(os.environ.get("OMP_NUM_THREADS", "16")), 16)
+    cores = oracle.set_threads(cores)
+    offs, cfs = oracle.benchmark_stencil_offsets(4)
+    rects, _, col, val = oracle.linearized_stencil((n1, n1, n1), offs, cfs)
+    rows = n1 ** 3
+    sol = np.zeros(rows)
+    r = np.ones(rows)
+    p = np.ones(rows)
+    q = np.zeros(rows)
+    rr = float(rows)
+    rr = oracle.cg_step_mt(rects, col, val, sol, p, q, r, rr, cores)  # warm-up
+    steps = 3
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        rr = oracle.cg_step_mt(rects, col, val, sol, p, q, r, rr, cores)
+    dt = (time.perf_counter() - t0) / steps
+    return {
+        "value": (1.0 / dt) * rows / full_rows,
+        "unit": "iters/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": f"{steps} CG steps of the CPU oracle (OpenMP, {cores} row blocks) on the 27-pt "
+                  f"stencil at {n1}^3 ({rows} rows, {val.size} entries); {dt * 1e3:.1f} ms/step there, "
+                  f"scaled by rows to 512^3",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--n", type=int, default=512, help="grid points per dimension")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world, local_rank = bs.init_distributed()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE is {world}: launch one rank per GPU")
+    ctx = Context(torch.device("cuda", local_rank))
+    n1 = args.n
+    rows = n1 ** 3
+
+    # single-system CG: the metric
+    matrix, planner, solver = bs.build_problem(ctx, 4, n1, n1, n1, world, 1, torch.float64, num_systems=1)
+    nnz_total = (3 * n1 - 2) ** 3
+    seconds = bs.timed_steps(ctx, solver, args.warmup, args.steps)
+    iters_per_s = args.steps / seconds
+    rr = solver.residual_norm_squared[-1].get_value()
+
+    # the dominant kernel against its roofline (this rank's launch)
+    t_spmv = spmv_kernel_time(ctx, matrix, planner, reps=20)
+    algo_bytes = matrix.nnz * 16 + matrix.rows * 32
+    achieved = algo_bytes / t_spmv / 1e9
+    t_max = torch.tensor([t_spmv], dtype=torch.float64, device=ctx.device)
+    if world > 1:
+        dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
+    spmv_gbps_job = (nnz_total * 16 + rows * 32) / float(t_max.item()) / 1e9
+    traffic = None
+    traffic_file = os.path.join(REPO, "profiles", "spmv_hbm_traffic.json")
+    if world == 1 and n1 == 512 and os.path.exists(traffic_file):
+        traffic = json.load(open(traffic_file)).get("bytes_per_launch")
+
+    # the reference's own set-up: two identical systems per step
+    del solver, planner
+    _, planner2, solver2 = bs.build_problem(ctx, 4, n1, n1, n1, world, 1, torch.float64, num_systems=2,
+                                            matrix=matrix)
+    seconds2 = bs.timed_steps(ctx, solver2, 2, max(args.steps // 5, 2))
+    two_system = max(args.steps // 5, 2) / seconds2
+
+    line = {
+        "metric": "CG iters/sec (fp64) on 3D 27-pt stencil 512^3, single system",
+        "value": iters_per_s,
+        "unit": "iters/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": seconds / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {
+            "workload": f"BenchmarkStencil -dim 4 -nx {n1} -ny {n1} -nz {n1} -solver 1 -vp {world}: "
+                        "3-D 27-pt stencil, fp64 CSR with int64 indices and 16-byte row rects, "
+                        "rhs=1, x0=0, one row block per GPU",
+            "rows": rows, "nnz": nnz_total, "pieces": world,
+        },
+        "spmv_gbps": spmv_gbps_job,
+        "two_system_iters_per_s": two_system,
+        "residual_norm_squared_last": rr,
+        "roofline": {
+            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+            "kernel": "csr_spmv_kernel<double,7>", "ms_per_launch": t_spmv * 1e3,
+            "algorithmic_bytes_per_launch": algo_bytes,
+        },
+    }
+    if ctx.rank == 0 and world == 1 and not args.no_cpu_baseline:
+        del solver2, planner2, matrix
+        torch.cuda.empty_cache()
+        line["cpu_baseline"] = cpu_baseline(rows)
+    if ctx.rank == 0:
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -160,6 +160,12 @@ def rects_to_indptr(rects: np.ndarray) -> np.ndarray:
     return out
 
 
+def set_threads(n: int) -> int:
+    """Worker threads of the OpenMP (_mt) functions; returns the count in force."""
+    lib().oracle_set_threads(int(n))
+    return int(lib().oracle_get_max_threads())
+
+
 def cg_step_mt(rects, col, val, sol, p, q, r, rr_old, shards: int):
     """One single-system CG step over `shards` row blocks with OpenMP (CPU-baseline timing)."""
     dt = val.dtype

@@ -12,8 +12,13 @@
  * ("one worker per shard"): used only for CPU-baseline timing.
  */
 #include <math.h>
+#include <omp.h>
 #include <stdint.h>
 #include <stdlib.h>
+
+/* Worker threads of the _mt functions (CPU-baseline timing). */
+void oracle_set_threads(int n) { omp_set_num_threads(n > 0 ? n : 1); }
+int oracle_get_max_threads(void) { return omp_get_max_threads(); }
 
 /* ---- get_alpha: src/LegionUtilities.cpp:72-97 ---------------------------------------- */
 #define GET_ALPHA(SUF, T)                                                     \

@@ -1,0 +1,271 @@
+"""GPU parity tests of the BLAS-1 leaf kernels, called through the C ABI and compared with
+the CPU oracle.  Elementwise ops and scalar ops: bit-exact.  dot / nrm2: the summation order
+differs from the sequential CPU loop; tolerance 1e-13 (fp64) / 2e-6 (fp32) relative to
+sum |v_i w_i| against the exactly rounded sum, the sequential loop's own n*eps error bound
+against the oracle, and bit-reproducible run to run."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from legionsolvers_amd import _lib
+
+pytestmark = pytest.mark.gpu
+
+DT = {"f32": (np.float32, torch.float32), "f64": (np.float64, torch.float64)}
+SIZES = [0, 1, 2, 3, 63, 64, 255, 256, 257, 1023, 4099, 65536 + 5, (1 << 20) + 3]
+
+
+def P(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint8)
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _init(gpu_ctx):
+    return gpu_ctx
+
+
+@pytest.mark.parametrize("suf", ["f32", "f64"])
+@pytest.mark.parametrize("offset", [0, 1])
+def test_elementwise_bit_exact(suf, offset):
+    """scal / axpy / xpay, host alpha; `offset` shifts the vectors off 16-byte alignment."""
+    npdt, _ = DT[suf]
+    rng = np.random.default_rng(11)
+    for n in SIZES:
+        x = rng.standard_normal(n + offset).astype(npdt)
+        y = rng.standard_normal(n + offset).astype(npdt)
+        alpha = npdt(rng.standard_normal())
+        for op in ("scal", "axpy", "xpay"):
+            print(f"case {op}_{suf} n={n} offset={offset}", flush=True)
+            want = y.copy()
+            if op == "scal":
+                oracle.scal(alpha, want[offset:])
+            else:
+                getattr(oracle, op)(alpha, np.ascontiguousarray(x[offset:]), want[offset:])
+            xd, yd = dev(x), dev(y)
+            if op == "scal":
+                _lib.call(f"lsk_scal_{suf}", n, float(alpha), P(yd[offset:]), stream())
+            else:
+                _lib.call(f"lsk_{op}_{suf}", n, float(alpha), P(xd[offset:]), P(yd[offset:]), stream())
+            got = yd.cpu().numpy()
+            assert np.array_equal(bits(got), bits(want)), f"{op} n={n}"
+
+
+@pytest.mark.parametrize("suf", ["f32", "f64"])
+def test_elementwise_device_alpha_bit_exact(suf):
+    """alpha = get_alpha(0..4 device futures), evaluated on the GPU in the reference's order."""
+    npdt, _ = DT[suf]
+    rng = np.random.default_rng(12)
+    n = 10007
+    for nf in range(5):
+        f = (rng.standard_normal(4) + 2.0).astype(npdt)
+        alpha = oracle.get_alpha(f[:nf], npdt)
+        fd = dev(f)
+        ptrs = [P(fd[i:i + 1]) if i < nf else ctypes.c_void_p(0) for i in range(4)]
+        for op in ("scal", "axpy", "xpay"):
+            print(f"case {op}_dev_{suf} nf={nf}", flush=True)
+            x = rng.standard_normal(n).astype(npdt)
+            y = rng.standard_normal(n).astype(npdt)
+            want = y.copy()
+            xd, yd = dev(x), dev(y)
+            if op == "scal":
+                oracle.scal(alpha, want)
+                _lib.call(f"lsk_scal_dev_{suf}", n, nf, *ptrs, P(yd), stream())
+            else:
+                getattr(oracle, op)(alpha, x, want)
+                _lib.call(f"lsk_{op}_dev_{suf}", n, nf, *ptrs, P(xd), P(yd), stream())
+            assert np.array_equal(bits(yd.cpu().numpy()), bits(want)), f"{op} nf={nf}"
+    assert _lib.lib().lsk_axpy_dev_f64(4, 5, *([ctypes.c_void_p(0)] * 4), P(fd), P(fd), stream()) == -2
+    assert _lib.lib().lsk_axpy_dev_f64(4, 2, P(fd), *([ctypes.c_void_p(0)] * 3), P(fd), P(fd), stream()) == -2
+
+
+@pytest.mark.parametrize("suf", ["f32", "f64"])
+def test_fill_copy_and_aliasing(suf):
+    npdt, tdt = DT[suf]
+    for n in (0, 1, 5, 1000, 70001):
+        for off in (0, 1):
+            print(f"case fill/copy {suf} n={n} off={off}", flush=True)
+            buf = torch.full((n + off + 2,), -7.0, dtype=tdt, device="cuda")
+            _lib.call(f"lsk_fill_{suf}", n, 2.5, P(buf[off:]), stream())
+            host = buf.cpu().numpy()
+            assert np.all(host[off:off + n] == 2.5) and np.all(host[:off] == -7) and np.all(host[off + n:] == -7)
+            src = dev(np.arange(n + off, dtype=npdt))
+            dst = torch.zeros(n + 1, dtype=tdt, device="cuda")
+            _lib.call(f"lsk_copy_{suf}", n, P(src[off:]), P(dst), stream())
+            assert np.array_equal(dst.cpu().numpy()[:n], np.arange(off, n + off, dtype=npdt))
+    # y == x is a legal call: y = fma(alpha, y, y)
+    x = np.random.default_rng(1).standard_normal(4097).astype(npdt)
+    want = x.copy()
+    oracle.axpy(npdt(0.5), x.copy(), want)
+    xd = dev(x)
+    _lib.call(f"lsk_axpy_{suf}", x.size, 0.5, P(xd), P(xd), stream())
+    assert np.array_equal(bits(xd.cpu().numpy()), bits(want))
+
+
+@pytest.mark.parametrize("suf", ["f32", "f64"])
+def test_dot_and_nrm2(suf):
+    npdt, tdt = DT[suf]
+    tol = 1e-13 if suf == "f64" else 2e-6
+    rng = np.random.default_rng(13)
+    ws_bytes = int(_lib.lib().lsk_dot_workspace_bytes(0))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device="cuda")
+    for n in SIZES + [(1 << 22) + 11]:
+        for off in (0, 1):
+            print(f"case dot_{suf} n={n} off={off}", flush=True)
+            v = rng.standard_normal(n + off).astype(npdt)
+            w = rng.standard_normal(n + off).astype(npdt)
+            vd, wd = dev(v), dev(w)
+            out = torch.full((3,), 99.0, dtype=tdt, device="cuda")
+            _lib.call(f"lsk_dot_{suf}", n, P(vd[off:]), P(wd[off:]), P(out[0:1]), P(ws), ws_bytes, stream())
+            _lib.call(f"lsk_dot_{suf}", n, P(vd[off:]), P(wd[off:]), P(out[1:2]), None, 0, stream())
+            _lib.call(f"lsk_nrm2_{suf}", n, P(vd[off:]), P(out[2:3]), P(ws), ws_bytes, stream())
+            got = out.cpu().numpy()
+            v64, w64 = v[off:].astype(np.float64), w[off:].astype(np.float64)
+            exact = float(v64 @ w64)
+            scale = float(np.abs(v64 * w64).sum()) + 1e-300
+            # against the exactly rounded value: the GPU's tree sum is accurate to a few ulps
+            assert abs(float(got[0]) - exact) <= tol * scale, (n, got[0], exact)
+            # against the oracle's left-to-right sum, whose own rounding error is bounded by
+            # n*eps*sum|v w| (and is what separates the two for long fp32 vectors)
+            want = float(oracle.dot(np.ascontiguousarray(v[off:]), np.ascontiguousarray(w[off:])))
+            assert abs(float(got[0]) - want) <= (tol + n * float(np.finfo(npdt).eps)) * scale
+            assert got[0].tobytes() == got[1].tobytes()          # reproducible, any workspace
+            exact_nrm = float(np.sqrt(v64 @ v64))
+            assert abs(float(got[2]) - exact_nrm) <= tol * (exact_nrm + 1e-300) * 4
+            host = np.zeros(1, dtype=npdt)
+            _lib.call(f"lsk_dot_host_{suf}", n, P(vd[off:]), P(wd[off:]), host.ctypes.data, stream())
+            assert host[0].tobytes() == got[0].tobytes()
+    # dot(v, v) takes the read-once path and equals dot of two equal copies
+    v = rng.standard_normal(100003).astype(npdt)
+    vd, vd2 = dev(v), dev(v)
+    out = torch.zeros(2, dtype=tdt, device="cuda")
+    _lib.call(f"lsk_dot_{suf}", v.size, P(vd), P(vd), P(out[0:1]), None, 0, stream())
+    _lib.call(f"lsk_dot_{suf}", v.size, P(vd), P(vd2), P(out[1:2]), None, 0, stream())
+    got = out.cpu().numpy()
+    assert got[0].tobytes() == got[1].tobytes()
+    # a caller-supplied workspace that is too small is refused, not overrun
+    small = torch.empty(8, dtype=torch.uint8, device="cuda")
+    big = dev(np.ones(1 << 20, dtype=npdt))
+    rc = getattr(_lib.lib(), f"lsk_dot_{suf}")(1 << 20, P(big), P(big), P(out), P(small), 8, stream())
+    assert rc == -2 and b"workspace" in _lib.lib().lsk_last_error()
+
+
+@pytest.mark.parametrize("suf", ["f32", "f64"])
+def test_scalar_ops_bit_exact(suf):
+    """The scalar task bodies (src/UtilityTasks.cpp:34-99) on the device: IEEE division and
+    square root, so bit-equal to the host."""
+    npdt, tdt = DT[suf]
+    rng = np.random.default_rng(14)
+    names = ["neg", "add", "sub", "mul", "div", "sqrt", "rsqrt", "copy"]
+    a = np.abs(rng.standard_normal(200)).astype(npdt) * npdt(1e3) + npdt(1e-3)
+    b = (rng.standard_normal(200)).astype(npdt) + npdt(3)
+    ad, bd = dev(a), dev(b)
+    out = torch.zeros(200, dtype=tdt, device="cuda")
+    for op, name in enumerate(names):
+        print(f"case scalar_op {name} {suf}", flush=True)
+        for i in range(200):
+            _lib.call(f"lsk_scalar_op_{suf}", op, P(ad[i:i + 1]), P(bd[i:i + 1]), P(out[i:i + 1]), stream())
+        got = out.cpu().numpy()
+        want = np.array([oracle.scalar_op(name, a[i], b[i], npdt) for i in range(200)], dtype=npdt)
+        assert np.array_equal(bits(got), bits(want)), name
+    # sum_scalars folds left to right
+    vals = rng.standard_normal(17).astype(npdt)
+    acc = vals[0]
+    for v in vals[1:]:
+        acc = oracle.scalar_op("add", acc, v, npdt)
+    res = torch.zeros(1, dtype=tdt, device="cuda")
+    vals_d = dev(vals)
+    _lib.call(f"lsk_sum_scalars_{suf}", 17, P(vals_d), P(res), stream())
+    assert res.cpu().numpy()[0].tobytes() == np.asarray(acc, dtype=npdt).tobytes()
+
+
+@pytest.mark.parametrize("suf", ["f32", "f64"])
+def test_xpay_nd_bit_exact(suf):
+    """N-D xpay over strided instances (what xpay_kernel does through Pitches + accessors),
+    including Legion's default column-major (first dimension fastest) layout."""
+    npdt, _ = DT[suf]
+    rng = np.random.default_rng(15)
+    cases = [
+        ((100,), (1,), (1,)),
+        ((10, 10), (1, 10), (1, 10)),            # column-major
+        ((10, 10), (10, 1), (1, 10)),            # x row-major, y column-major
+        ((4, 5, 5), (1, 4, 20), (1, 4, 20)),
+        ((4, 5, 5), (30, 6, 1), (50, 7, 1)),     # padded rows
+        ((0, 5, 5), (25, 5, 1), (25, 5, 1)),     # empty rect
+    ]
+    for extent, xs, ys in cases:
+        print(f"case xpay_nd {suf} {extent} {xs} {ys}", flush=True)
+        size = lambda st: 1 + sum((e - 1) * s for e, s in zip(extent, st)) if all(extent) else 1
+        x = rng.standard_normal(size(xs)).astype(npdt)
+        y = rng.standard_normal(size(ys)).astype(npdt)
+        want = y.copy()
+        oracle.xpay_nd(extent, npdt(1.25), x, xs, want, ys)
+        xd, yd = dev(x), dev(y)
+        ext = (ctypes.c_int64 * len(extent))(*extent)
+        xsc = (ctypes.c_int64 * len(extent))(*xs)
+        ysc = (ctypes.c_int64 * len(extent))(*ys)
+        _lib.call(f"lsk_xpay_nd_{suf}", len(extent), ext, 1.25, P(xd), xsc, P(yd), ysc, stream())
+        assert np.array_equal(bits(yd.cpu().numpy()), bits(want))
+
+
+def test_shim_memory_and_streams():
+    """lsk_malloc / lsk_free / streams / copies, with no torch memory involved."""
+    lib = _lib.lib()
+    n = ctypes.c_int(0)
+    _lib.check(lib.lsk_device_count(ctypes.byref(n)))
+    assert n.value >= 1
+    s = ctypes.c_void_p()
+    _lib.check(lib.lsk_stream_create(ctypes.byref(s)))
+    ptr = ctypes.c_void_p()
+    host = np.arange(1000, dtype=np.float64)
+    _lib.check(lib.lsk_malloc(ctypes.byref(ptr), host.nbytes))
+    assert ptr.value and ptr.value % 256 == 0
+    _lib.check(lib.lsk_memcpy_h2d(ptr, host.ctypes.data, host.nbytes, s))
+    _lib.check(lib.lsk_scal_f64(1000, 2.0, ptr, s))
+    back = np.zeros_like(host)
+    _lib.check(lib.lsk_memcpy_d2h(back.ctypes.data, ptr, host.nbytes, s))
+    _lib.check(lib.lsk_stream_check(s))
+    assert np.array_equal(back, host * 2)
+    res = np.zeros(1)
+    _lib.check(lib.lsk_dot_host_f64(1000, ptr, ptr, res.ctypes.data, s))
+    assert res[0] == float(np.dot(host * 2, host * 2))
+    _lib.check(lib.lsk_free(ptr))
+    _lib.check(lib.lsk_stream_destroy(s))
+
+
+def test_rccl_layer_single_rank():
+    """The RCCL entry points with a one-rank communicator (all a 1-GPU box can run)."""
+    lib = _lib.lib()
+    uid = ctypes.create_string_buffer(_lib.UNIQUE_ID_BYTES)
+    _lib.check(lib.lsk_comm_unique_id(uid))
+    comm = ctypes.c_void_p()
+    _lib.check(lib.lsk_comm_init_rank(ctypes.byref(comm), 1, 0, uid))
+    r, w = ctypes.c_int(-1), ctypes.c_int(-1)
+    _lib.check(lib.lsk_comm_rank(comm, ctypes.byref(r), ctypes.byref(w)))
+    assert (r.value, w.value) == (0, 1)
+    buf = dev(np.array([1.5, 2.5]))
+    _lib.check(lib.lsk_allreduce_sum_f64(comm, P(buf), 2, stream()))
+    out = torch.zeros(2, dtype=torch.float64, device="cuda")
+    _lib.check(lib.lsk_allgather_f64(comm, P(buf), P(out), 2, stream()))
+    _lib.check(lib.lsk_halo_exchange_f64(comm, 0, None, None, None, 0, None, None, None, stream()))
+    torch.cuda.synchronize()
+    assert buf.tolist() == [1.5, 2.5] and out.tolist() == [1.5, 2.5]
+    bad_peer = (ctypes.c_int * 1)(0)
+    ptrs = (ctypes.c_void_p * 1)(buf.data_ptr())
+    cnt = (ctypes.c_int64 * 1)(1)
+    assert lib.lsk_halo_exchange_f64(comm, 1, bad_peer, ptrs, cnt, 0, None, None, None, stream()) == -2
+    _lib.check(lib.lsk_comm_destroy(comm))

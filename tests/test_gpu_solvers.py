@@ -1,0 +1,155 @@
+"""End-to-end GPU tests: the reference's test programs (Test01, Test02, Test05, Test06) and the
+BiCGStab / GMRES sequences run through the host mirror on the HIP backend and compared with the
+reference's goldens and the CPU oracle (fp64 residual histories within 1e-10 relative, the bar
+the north star states); plus size-independent properties of the SpMV at the headline size."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from oracle import solvers as S
+
+import host_cases as hc
+
+from legionsolvers_amd import (BiCGStabSolver, CGSolver, GMRESSolver, IndexPartition, IndexSpace,
+                               PartitionedVector, Scalar, SquarePlanner)
+from legionsolvers_amd import stencil_generator as sg
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("kind", ["coo", "csr"])
+@pytest.mark.parametrize("pieces", [1, 4])
+def test_cg_reference_golden(gpu_ctx, kind, pieces, goldens, krylov_golden):
+    """Test05COOSolveCG / Test06CSRSolveCG: N = 100, 10 CG steps, compared as the reference's
+    driver does (sorted printed values, test_all.py:130-133) and, in order, with the outputs of
+    the reference's scripts/krylov.py."""
+    print(f"case cg golden {kind} pieces={pieces}", flush=True)
+    prob = goldens["cg_problem"]
+    ip = IndexPartition.equal(IndexSpace(0, prob["n"] - 1), pieces)
+    make = sg.csr_negative_laplacian_1d if kind == "csr" else sg.coo_negative_laplacian_1d
+    matrix = make(gpu_ctx, prob["n"], ip)
+    rhs = PartitionedVector(gpu_ctx, "rhs", ip)
+    rhs.constant_fill(1.0)
+    sol = PartitionedVector(gpu_ctx, "sol", ip)
+    sol.zero_fill()
+    planner = SquarePlanner(gpu_ctx)
+    planner.add_sol_vector(sol)
+    planner.add_rhs_vector(rhs)
+    planner.add_row_partitioned_matrix(matrix, 0, 0)
+    solver = CGSolver(planner)
+    for _ in range(prob["iterations"]):
+        solver.step()
+    hist = [s.get_value() for s in solver.residual_norm_squared]
+    golden = krylov_golden["cases"][0]
+    np.testing.assert_allclose(hist, golden["residual_norm_squared"], rtol=1e-10)
+    assert sorted(f"{v:g}" for v in hist) == sorted(goldens["expected_cg_output_sorted_set"])
+    np.testing.assert_allclose(sol.to_host().numpy(), golden["x_final"], rtol=1e-10)
+
+
+def test_vector_and_scalar_programs(gpu_ctx, goldens):
+    """Test02VectorOperations (u.u prints 0, fp32/fp64 x 1/2/3-D, 10 colours, some of them
+    empty) and Test01ScalarOperations ((2+10)/(2+2)-2 == 1)."""
+    for dtype in (torch.float32, torch.float64):
+        for space in (IndexSpace(0, 99), IndexSpace((0, 0), (9, 9)), IndexSpace((0, 0, 0), (3, 4, 4))):
+            print(f"case test02 {dtype} {space}", flush=True)
+            ip = IndexPartition.equal(space, 10)
+            u, v, w = (PartitionedVector(gpu_ctx, n, ip, dtype) for n in "uvw")
+            u.constant_fill(1.5)
+            v.constant_fill(2.7)
+            w.assign(u)
+            w.axpy(1.0, v)
+            v.xpay(-1.0, u)
+            u.axpy(-0.5, v)
+            u.axpy(-0.5, w)
+            assert f"{u.dot(u).get_value():g}" == goldens["test02_stdout"][0]
+        two, ten = Scalar(gpu_ctx, 2.0, dtype), Scalar(gpu_ctx, 10.0, dtype)
+        assert ((two + ten) / (two + two) - two).get_value() == goldens["test01_scalar_chain"]["value"]
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("solver_name", ["cg", "bicgstab", "gmres"])
+@pytest.mark.parametrize("kind", ["csr", "coo"])
+def test_solvers_match_oracle(gpu_ctx, dtype, solver_name, kind):
+    """CG / BiCGStab / GMRES on a 3-D 27-point system with a random right-hand side, 4 pieces,
+    two coupled spaces for CG (the BenchmarkStencil set-up): solution and scalar histories
+    against the oracle's restatement of the reference headers."""
+    print(f"case solver {solver_name} {kind} {np.dtype(dtype).name}", flush=True)
+    rects, row, col, val, n = hc.stencil_problem(4, (8, 9, 10), dtype)
+    rhs = np.random.default_rng(31).standard_normal(n)
+    spaces = 2 if solver_name == "cg" else 1
+    opl = hc.oracle_planner(kind, rects, row, col, val, n, 4, dtype, rhs, spaces)
+    mpl = hc.mirror_planner(gpu_ctx, kind, rects, row, col, val, n, 4, dtype, rhs, spaces)
+    if solver_name == "cg":
+        so, sm, steps = S.CGSolver(opl), CGSolver(mpl), 8
+    elif solver_name == "bicgstab":
+        so, sm, steps = S.BiCGStabSolver(opl), BiCGStabSolver(mpl), 5
+    else:
+        so, sm, steps = S.GMRESSolver(opl, 5), GMRESSolver(mpl, 5), 2
+    for _ in range(steps):
+        so.step()
+        sm.step()
+    rtol = 1e-10 if dtype == np.float64 else 2e-3
+    if solver_name == "cg":
+        np.testing.assert_allclose([s.get_value() for s in sm.residual_norm_squared],
+                                   [float(v) for v in so.residual_norm_squared], rtol=rtol)
+    if solver_name == "bicgstab":
+        np.testing.assert_allclose([s.get_value() for s in sm.rho], [float(v) for v in so.rho], rtol=rtol)
+    want = opl.get_vector(0, spaces - 1).astype(np.float64)
+    got = mpl.get_vector(0, spaces - 1).to_host().numpy().astype(np.float64)
+    scale = np.abs(want).max()
+    assert np.abs(got - want).max() <= rtol * 10 * scale
+
+
+def test_spmv_properties_at_headline_size(gpu_ctx):
+    """BenchmarkStencil's headline matrix (3-D 27-point, 512^3, fp64: 134M rows, 3.6G entries,
+    58 GB of col+val) is far beyond what the CPU oracle can check; these properties are
+    size-independent: interior row sums are 0 (88 - 6*6 - 12*3 - 8*2 = 0), boundary row sums
+    are positive, A is symmetric (x.Ay == y.Ax), A is linear, and the entry count is
+    (3*512-2)^3."""
+    n1 = 512
+    free, _ = torch.cuda.mem_get_info()
+    if free < 80 * (1 << 30):
+        n1 = 256  # smaller cards: same properties on 256^3
+    n = n1 ** 3
+    print(f"case spmv properties {n1}^3", flush=True)
+    dim, offs, cfs = sg.benchmark_stencil(4)
+    ip = IndexPartition.equal(IndexSpace(0, n - 1), 1)
+    A = sg.create_linearized_csr_stencil_matrix(gpu_ctx, (n1, n1, n1), offs, cfs, ip)
+    assert A.nnz == (3 * n1 - 2) ** 3
+    be = gpu_ctx.backend
+    kp = A.create_kernel_partition_from_range_partition(ip)
+    assert kp.intervals == [(0, A.nnz - 1)]
+    gp = A.create_domain_partition_from_kernel_partition(IndexSpace(0, n - 1), kp)
+    assert gp.intervals == [(0, n - 1)]
+
+    def matvec(x):
+        y = PartitionedVector(gpu_ctx, "y", ip)
+        A.matvec(y, x.owned, 0, n - 1, kp, 0)
+        return y
+
+    ones = PartitionedVector(gpu_ctx, "ones", ip)
+    ones.constant_fill(1.0)
+    rowsum = matvec(ones).owned.view(n1, n1, n1)
+    interior = rowsum[1:-1, 1:-1, 1:-1]
+    assert float(interior.abs().max()) <= 1e-14
+    assert float(rowsum[0].min()) > 0.1 and float(rowsum[:, 0].min()) > 0.1 and float(rowsum[:, :, -1].min()) > 0.1
+    del rowsum, interior
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = PartitionedVector(gpu_ctx, "x", ip)
+    y = PartitionedVector(gpu_ctx, "yv", ip)
+    x.owned.copy_(torch.randn(n, generator=g, device="cuda", dtype=torch.float64))
+    y.owned.copy_(torch.randn(n, generator=g, device="cuda", dtype=torch.float64))
+    Ax, Ay = matvec(x), matvec(y)
+    xAy, yAx = x.dot(Ay).get_value(), y.dot(Ax).get_value()
+    norm = (x.dot(x).get_value() * Ay.dot(Ay).get_value()) ** 0.5
+    assert abs(xAy - yAx) <= 1e-12 * norm
+    # linearity: A(2x - 3y) == 2Ax - 3Ay
+    z = PartitionedVector(gpu_ctx, "z", ip)
+    z.assign(x)
+    z.scal(2.0)
+    z.axpy(-3.0, y)
+    Az = matvec(z)
+    Az.axpy(-2.0, Ax)
+    Az.axpy(3.0, Ay)
+    assert Az.dot(Az).get_value() ** 0.5 <= 1e-12 * (4 * Ax.dot(Ax).get_value() + 9 * Ay.dot(Ay).get_value()) ** 0.5

@@ -1,0 +1,250 @@
+"""GPU parity tests of the CSR / COO SpMV kernels and the device-side set-up helpers, called
+through the C ABI and compared with the CPU oracle.
+
+Index work (generators, rect rebasing, image bounds) is bit-exact.  SpMV results are sums
+whose order differs from the CPU's ascending-k loop: tolerance 1e-13 (fp64) / 1e-5 (fp32)
+relative to sum_k |val_k x_col_k| of the row.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from legionsolvers_amd import _lib
+
+pytestmark = pytest.mark.gpu
+
+DT = {"f32": (np.float32, torch.float32, 1e-5), "f64": (np.float64, torch.float64, 1e-13)}
+
+
+def P(t):
+    return ctypes.c_void_p(t.data_ptr() if t is not None else 0)
+
+
+def stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _init(gpu_ctx):
+    return gpu_ctx
+
+
+def csr_case(suf, rects, k_base, col, val, x, x_lo, x_hi, beta=0, y0=None, tag=""):
+    """Run lsk_csr_spmv on the given piece and compare with the oracle."""
+    npdt, tdt, tol = DT[suf]
+    rows = rects.shape[0]
+    print(f"case csr_spmv_{suf} {tag} rows={rows} nnz={val.size} k_base={k_base} x=[{x_lo},{x_hi}] beta={beta}",
+          flush=True)
+    y0 = np.zeros(rows, dtype=npdt) if y0 is None else y0.astype(npdt)
+    want = y0.copy()
+    oracle.csr_matvec(rects, k_base, col, val, x, x_lo, x_hi, want, beta=beta)
+    bound = np.zeros(rows, dtype=npdt)
+    oracle.csr_matvec(rects, k_base, col, np.abs(val), np.abs(x), x_lo, x_hi, bound, beta=0)
+    rd, cd, vd, xd, yd = dev(rects), dev(col), dev(val), dev(x), dev(y0)
+    _lib.call(f"lsk_csr_spmv_{suf}", rows, val.size, P(rd), k_base, P(cd), P(vd), P(xd), x_lo, x_hi,
+              P(yd), beta, stream())
+    got = yd.cpu().numpy()
+    err = np.abs(got.astype(np.float64) - want.astype(np.float64))
+    lim = tol * (bound.astype(np.float64) + np.abs(y0) + 1e-300)
+    assert np.all(err <= lim), f"{tag}: max err {err.max()} at row {int(np.argmax(err - lim))}"
+    return got
+
+
+@pytest.mark.parametrize("suf", ["f32", "f64"])
+@pytest.mark.parametrize("flag,extent", [(1, (1000,)), (2, (37, 41)), (3, (9, 11, 13)), (4, (12, 10, 14)),
+                                         (4, (3, 3, 3)), (1, (1,)), (1, (2,))])
+def test_csr_spmv_stencils(suf, flag, extent):
+    npdt = DT[suf][0]
+    offs, cfs = oracle.benchmark_stencil_offsets(flag)
+    rects, _, col, val = oracle.linearized_stencil(extent, offs, cfs, dtype=npdt)
+    n = rects.shape[0]
+    x = np.random.default_rng(21).standard_normal(n).astype(npdt)
+    csr_case(suf, rects, 0, col, val, x, 0, n - 1, tag=f"stencil{flag}{extent}")
+    y0 = np.random.default_rng(22).standard_normal(n).astype(npdt)
+    csr_case(suf, rects, 0, col, val, x, 0, n - 1, beta=1, y0=y0, tag="beta1")
+
+
+@pytest.mark.parametrize("suf", ["f32", "f64"])
+def test_csr_spmv_pieces_and_ghost_windows(suf):
+    """Row-block pieces of a larger matrix: k_base != 0, odd first entry (so the 16-byte
+    loads start off-phase), x handed over as the ghost window only."""
+    npdt = DT[suf][0]
+    offs, cfs = oracle.benchmark_stencil_offsets(4)
+    rects, _, col, val = oracle.linearized_stencil((7, 9, 11), offs, cfs, dtype=npdt)
+    n = rects.shape[0]
+    x = np.random.default_rng(23).standard_normal(n).astype(npdt)
+    for r0, r1 in [(0, 99), (100, 356), (357, 357), (358, n - 1), (5, 5 + 255), (17, 17 + 300)]:
+        piece = np.ascontiguousarray(rects[r0:r1 + 1])
+        k_lo, k_hi = int(piece[0, 0]), int(piece[-1, 1])
+        c, v = np.ascontiguousarray(col[k_lo:k_hi + 1]), np.ascontiguousarray(val[k_lo:k_hi + 1])
+        g_lo, g_hi = int(c.min()), int(c.max())
+        csr_case(suf, piece, k_lo, c, v, np.ascontiguousarray(x[g_lo:g_hi + 1]), g_lo, g_hi,
+                 tag=f"piece[{r0},{r1}]")
+    # a window narrower than the image: out-of-window entries are skipped, not read
+    piece = np.ascontiguousarray(rects[200:400])
+    k_lo, k_hi = int(piece[0, 0]), int(piece[-1, 1])
+    csr_case(suf, piece, k_lo, np.ascontiguousarray(col[k_lo:k_hi + 1]), np.ascontiguousarray(val[k_lo:k_hi + 1]),
+             np.ascontiguousarray(x[250:350]), 250, 349, tag="narrow-window")
+
+
+@pytest.mark.parametrize("suf", ["f32", "f64"])
+def test_csr_spmv_general_rects(suf):
+    """Rects that do not tile the piece front to back (gaps, permuted rows, empty rows, rows
+    longer than the LDS buffer): the per-wave path, same results."""
+    npdt = DT[suf][0]
+    rng = np.random.default_rng(24)
+    # random matrix, variable row lengths incl. empty rows and one very long row
+    lens = rng.integers(0, 40, size=700)
+    lens[5] = 0
+    lens[300] = 20000
+    lens[699] = 0
+    n_cols = 5000
+    starts = np.concatenate([[0], np.cumsum(lens)])
+    nnz = int(starts[-1])
+    col = rng.integers(0, n_cols, size=nnz).astype(np.int64)
+    val = rng.standard_normal(nnz).astype(npdt)
+    x = rng.standard_normal(n_cols).astype(npdt)
+    rects = np.stack([starts[:-1], starts[1:] - 1], axis=1).astype(np.int64)
+    csr_case(suf, rects, 0, col, val, x, 0, n_cols - 1, tag="variable-rows")
+    # permuted rows: each row still owns its own run, but runs are visited out of order
+    perm = rng.permutation(700)
+    csr_case(suf, np.ascontiguousarray(rects[perm]), 0, col, val, x, 0, n_cols - 1, tag="permuted-rows")
+    # gaps: every row ignores its last entry
+    gap = rects.copy()
+    gap[lens > 1, 1] -= 1
+    csr_case(suf, gap, 0, col, val, x, 0, n_cols - 1, tag="gapped-rows")
+    # all rows empty
+    empty = np.stack([np.arange(50), np.arange(50) - 1], axis=1).astype(np.int64)
+    got = csr_case(suf, empty, 0, col[:60], val[:60], x, 0, n_cols - 1, tag="all-empty")
+    assert np.all(got == 0)
+    # dense-ish rows (~512 per row): few rows per workgroup
+    lens = np.full(64, 512)
+    starts = np.concatenate([[0], np.cumsum(lens)])
+    col = rng.integers(0, n_cols, size=int(starts[-1])).astype(np.int64)
+    val = rng.standard_normal(int(starts[-1])).astype(npdt)
+    rects = np.stack([starts[:-1], starts[1:] - 1], axis=1).astype(np.int64)
+    csr_case(suf, rects, 0, col, val, x, 0, n_cols - 1, tag="rows-of-512")
+
+
+@pytest.mark.parametrize("suf", ["f32", "f64"])
+def test_csr_spmv_misaligned_arrays(suf):
+    """col / val handed over at addresses that are not 16-byte aligned."""
+    npdt, tdt, tol = DT[suf]
+    offs, cfs = oracle.benchmark_stencil_offsets(3)
+    rects, _, col, val = oracle.linearized_stencil((6, 7, 8), offs, cfs, dtype=npdt)
+    n = rects.shape[0]
+    x = np.random.default_rng(25).standard_normal(n).astype(npdt)
+    want = np.zeros(n, dtype=npdt)
+    oracle.csr_matvec(rects, 0, col, val, x, 0, n - 1, want)
+    for coff in (0, 1):
+        for voff in range(0, 4 if suf == "f32" else 2):
+            print(f"case csr misaligned {suf} coff={coff} voff={voff}", flush=True)
+            cd = dev(np.concatenate([np.zeros(coff, np.int64), col]))
+            vd = dev(np.concatenate([np.zeros(voff, npdt), val]))
+            xd, rd = dev(x), dev(rects)
+            yd = torch.zeros(n, dtype=tdt, device="cuda")
+            _lib.call(f"lsk_csr_spmv_{suf}", n, val.size, P(rd), 0, P(cd[coff:]), P(vd[voff:]), P(xd),
+                      0, n - 1, P(yd), 0, stream())
+            np.testing.assert_allclose(yd.cpu().numpy(), want, rtol=0, atol=tol * 20)
+
+
+@pytest.mark.parametrize("suf", ["f32", "f64"])
+def test_coo_spmv(suf):
+    npdt, tdt, tol = DT[suf]
+    rng = np.random.default_rng(26)
+    offs, cfs = oracle.benchmark_stencil_offsets(4)
+    _, row, col, val = oracle.linearized_stencil((9, 8, 7), offs, cfs, dtype=npdt, coo=True)
+    n = 9 * 8 * 7
+    x = rng.standard_normal(n).astype(npdt)
+    y0 = rng.standard_normal(n).astype(npdt)
+    cases = {"row-sorted": np.arange(val.size), "shuffled": rng.permutation(val.size)}
+    for name, order in cases.items():
+        r, c, v = row[order].copy(), col[order].copy(), val[order].copy()
+        for (y_lo, y_hi, x_lo, x_hi) in [(0, n - 1, 0, n - 1), (100, 299, 0, n - 1), (0, n - 1, 50, 400), (7, 7, 0, n - 1)]:
+            print(f"case coo_spmv_{suf} {name} y=[{y_lo},{y_hi}] x=[{x_lo},{x_hi}]", flush=True)
+            want = np.ascontiguousarray(y0[y_lo:y_hi + 1]).copy()
+            xs = np.ascontiguousarray(x[x_lo:x_hi + 1])
+            oracle.coo_matvec(r, c, v, xs, x_lo, x_hi, want, y_lo, y_hi)
+            bound = np.zeros(y_hi - y_lo + 1, dtype=npdt)
+            oracle.coo_matvec(r, c, np.abs(v), np.abs(xs), x_lo, x_hi, bound, y_lo, y_hi)
+            yd, rd, cd, vd, xd = dev(y0[y_lo:y_hi + 1]), dev(r), dev(c), dev(v), dev(xs)
+            _lib.call(f"lsk_coo_spmv_{suf}", v.size, P(rd), P(cd), P(vd), P(xd), x_lo, x_hi,
+                      P(yd), y_lo, y_hi, stream())
+            err = np.abs(yd.cpu().numpy().astype(np.float64) - want)
+            assert np.all(err <= tol * (bound + np.abs(want) + 1e-300)), (name, err.max())
+    # one row with many entries (runs longer than the on-chip cut) and duplicates
+    r = np.full(5000, 3, dtype=np.int64)
+    c = rng.integers(0, 10, 5000).astype(np.int64)
+    v = rng.standard_normal(5000).astype(npdt)
+    xs = rng.standard_normal(10).astype(npdt)
+    want = np.zeros(8, dtype=npdt)
+    oracle.coo_matvec(r, c, v, xs, 0, 9, want, 0, 7)
+    yd, rd, cd, vd, xd = torch.zeros(8, dtype=tdt, device="cuda"), dev(r), dev(c), dev(v), dev(xs)
+    _lib.call(f"lsk_coo_spmv_{suf}", 5000, P(rd), P(cd), P(vd), P(xd), 0, 9, P(yd), 0, 7, stream())
+    scale = float(np.abs(v.astype(np.float64) * xs[c]).sum())
+    assert abs(float(yd[3]) - float(want[3])) <= tol * scale * 4
+    assert float(yd.abs().sum() - yd[3].abs()) == 0.0
+
+
+def test_rects_to_indptr_bit_exact():
+    offs, cfs = oracle.benchmark_stencil_offsets(4)
+    rects, _, _, _ = oracle.linearized_stencil((5, 6, 7), offs, cfs)
+    for r0, r1 in [(0, rects.shape[0] - 1), (17, 120), (33, 33)]:
+        piece = np.ascontiguousarray(rects[r0:r1 + 1])
+        out = torch.zeros(piece.shape[0] + 1, dtype=torch.int64, device="cuda")
+        pd = dev(piece)
+        _lib.call("lsk_rects_to_indptr_i64", piece.shape[0], P(pd), P(out), stream())
+        assert np.array_equal(out.cpu().numpy(), oracle.rects_to_indptr(piece))
+
+
+def test_index_bounds():
+    rng = np.random.default_rng(27)
+    for n in (1, 100, 100000, (1 << 21) + 7):
+        idx = rng.integers(-5000, 1 << 40, size=n).astype(np.int64)
+        out = torch.zeros(2, dtype=torch.int64, device="cuda")
+        idx_d = dev(idx)
+        _lib.call("lsk_index_bounds_i64", n, P(idx_d), P(out), stream())
+        assert out.tolist() == [int(idx.min()), int(idx.max())]
+    out = torch.zeros(2, dtype=torch.int64, device="cuda")
+    _lib.call("lsk_index_bounds_i64", 0, None, P(out), stream())
+    assert out.tolist() == [np.iinfo(np.int64).max, np.iinfo(np.int64).min]
+
+
+@pytest.mark.parametrize("suf", ["f32", "f64"])
+@pytest.mark.parametrize("flag,extent", [(1, (50,)), (2, (9, 13)), (3, (5, 6, 7)), (4, (6, 5, 7)), (4, (1, 1, 4))])
+def test_device_stencil_generator_bit_exact(gpu_ctx, suf, flag, extent):
+    """The device generators write exactly what the oracle's restatement of
+    FillLinearizedCSRStencilTask / FillLinearizedCOOStencilTask writes, for 1 and 3 pieces."""
+    from legionsolvers_amd import IndexPartition, IndexSpace
+    from legionsolvers_amd import stencil_generator as sg
+    npdt, tdt, _ = DT[suf]
+    dim, offs, cfs = sg.benchmark_stencil(flag)
+    assert (offs, cfs) == oracle.benchmark_stencil_offsets(flag)
+    rects, row, col, val = oracle.linearized_stencil(extent, offs, cfs, dtype=npdt, coo=True)
+    n = rects.shape[0]
+    for pieces in (1, 3):
+        ip = IndexPartition.equal(IndexSpace(0, n - 1), pieces)
+        m = sg.create_linearized_csr_stencil_matrix(gpu_ctx, extent, offs, cfs, ip, tdt)
+        assert m.k_base == 0 and m.nnz == val.size and m.rows == n
+        assert np.array_equal(m.rects.cpu().numpy(), rects)
+        assert np.array_equal(m.col.cpu().numpy(), col)
+        assert np.array_equal(m.val.cpu().numpy().view(np.uint8), val.view(np.uint8))
+        c = sg.create_linearized_coo_stencil_matrix(gpu_ctx, extent, offs, cfs, ip, tdt)
+        assert np.array_equal(c.row.cpu().numpy(), row) and np.array_equal(c.col.cpu().numpy(), col)
+        assert np.array_equal(c.val.cpu().numpy().view(np.uint8), val.view(np.uint8))
+        kp = m.create_kernel_partition_from_range_partition(ip)
+        gp = m.create_domain_partition_from_kernel_partition(IndexSpace(0, n - 1), kp)
+        from oracle import partition as part
+        for i, piece in enumerate(ip.pieces):
+            want_k = part.image_range(rects, (piece.lo[0], piece.hi[0]))
+            assert kp.intervals[i] == part.bounds(want_k)
+            assert gp.intervals[i] == part.bounds(part.image(col, want_k, (0, n - 1)))
+        kc = c.create_kernel_partition_from_range_partition(ip)
+        assert kc.intervals == kp.intervals  # preimage of rows == image-range of rects here
