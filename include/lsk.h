@@ -52,6 +52,17 @@ const char *lsk_last_error(void);
  * Default 0: print nothing, return the status code. */
 void lsk_set_abort_on_error(int enable);
 
+/* Kernel-selection options, for A/B timing of kernel forms; every setting computes the same
+ * result.  Keys: "csr.variant" (0 workgroup tiles | 1 wave tiles, default 1),
+ * "csr.nontemporal" (0 | 1: stream col/val past the caches, default 0), "xcd_remap" (c > 0:
+ * each XCD takes runs of c consecutive tiles; c < 0: one contiguous eighth of the tiles per
+ * XCD; 0: workgroup id = tile id, the default), "csr.log_rows_per_wave" (-1 = from
+ * the mean row length, else 0..6), "blas1.form" (0 grid-strided | 1 contiguous chunk per
+ * workgroup, default 1).  No counterpart in the reference
+ * (cuSPARSE picks its own algorithm behind CUSPARSE_SPMV_ALG_DEFAULT). */
+int lsk_set_option(const char *key, int value);
+int lsk_get_option(const char *key, int *value);
+
 /* Number of visible HIP devices. */
 int lsk_device_count(int *count);
 

@@ -53,6 +53,8 @@ PROTOTYPES = {
     "lsk_version": (ctypes.c_char_p, []),
     "lsk_last_error": (ctypes.c_char_p, []),
     "lsk_set_abort_on_error": (None, [_i]),
+    "lsk_set_option": (_i, [ctypes.c_char_p, _i]),
+    "lsk_get_option": (_i, [ctypes.c_char_p, ctypes.POINTER(_i)]),
     "lsk_device_count": (_i, [ctypes.POINTER(_i)]),
     "lsk_init": (_i, [_i]),
     "lsk_malloc": (_i, [ctypes.POINTER(_p), _sz]),

@@ -67,34 +67,43 @@ constexpr bool reads_y(int op) { return op == OP_SCAL || op == OP_AXPY || op == 
 // E = element type of one access: the 16-byte vector when every pointer is 16-byte aligned,
 // else the scalar.  x and y are not declared restrict: y == x is a legal call.
 template <typename T, int OP, typename E, int EN>
-__global__ __launch_bounds__(kBlock) void ew_kernel(int64_t n, Alpha<T> a, const T *x, T *y) {
+__global__ __launch_bounds__(kBlock) void ew_kernel(int64_t n, Alpha<T> a, const T *x, T *y, int form) {
     const T alpha = resolve_alpha(a);
     const int64_t ne = n / EN;
     const E *xe = reinterpret_cast<const E *>(x);
     E *ye = reinterpret_cast<E *>(y);
-    const int64_t stride = int64_t(gridDim.x) * kBlock;
-    int64_t i = int64_t(blockIdx.x) * kBlock + threadIdx.x;
-    const bool first = (i == 0);
+    // form 1: a workgroup sweeps contiguous chunks of 4 x 256 accesses (its four accesses per
+    // lane are 4 KiB apart); form 0: every access of the grid is one grid-stride apart.
+    const int64_t gstride = int64_t(gridDim.x) * kBlock;
+    const int64_t inner = form ? kBlock : gstride;
+    const int64_t outer = 4 * gstride;
+    int64_t i = form ? int64_t(blockIdx.x) * (4 * kBlock) + threadIdx.x
+                     : int64_t(blockIdx.x) * kBlock + threadIdx.x;
+    const bool first = (blockIdx.x == 0 && threadIdx.x == 0);
 
-    for (; i + 3 * stride < ne; i += 4 * stride) {
+    for (; i + 3 * inner < ne; i += outer) {
         E xv[4], yv[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            if constexpr (reads_x(OP)) xv[u] = xe[i + u * stride]; else xv[u] = E{};
-            if constexpr (reads_y(OP)) yv[u] = ye[i + u * stride]; else yv[u] = E{};
+            if constexpr (reads_x(OP)) xv[u] = xe[i + u * inner]; else xv[u] = E{};
+            if constexpr (reads_y(OP)) yv[u] = ye[i + u * inner]; else yv[u] = E{};
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            if constexpr (EN == 1) ye[i + u * stride] = apply<T, OP>(alpha, xv[u], yv[u]);
-            else ye[i + u * stride] = apply_v<T, OP>(alpha, xv[u], yv[u]);
+            if constexpr (EN == 1) ye[i + u * inner] = apply<T, OP>(alpha, xv[u], yv[u]);
+            else ye[i + u * inner] = apply_v<T, OP>(alpha, xv[u], yv[u]);
         }
     }
-    for (; i < ne; i += stride) {
-        E xv{}, yv{};
-        if constexpr (reads_x(OP)) xv = xe[i];
-        if constexpr (reads_y(OP)) yv = ye[i];
-        if constexpr (EN == 1) ye[i] = apply<T, OP>(alpha, xv, yv);
-        else ye[i] = apply_v<T, OP>(alpha, xv, yv);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int64_t j = i + u * inner;
+        if (j < ne) {
+            E xv{}, yv{};
+            if constexpr (reads_x(OP)) xv = xe[j];
+            if constexpr (reads_y(OP)) yv = ye[j];
+            if constexpr (EN == 1) ye[j] = apply<T, OP>(alpha, xv, yv);
+            else ye[j] = apply_v<T, OP>(alpha, xv, yv);
+        }
     }
     if (EN > 1 && first) { // the n % EN trailing elements
         for (int64_t j = ne * EN; j < n; ++j) {
@@ -126,10 +135,11 @@ int launch_ew(const char *name, int64_t n, Alpha<T> a, const T *x, T *y, lsk_str
     constexpr int VN = Vec<T>::N;
     const bool vec = lsk::aligned16(y) && (!reads_x(OP) || lsk::aligned16(x));
     hipStream_t s = lsk::as_stream(stream);
+    const int form = lsk::options().blas1_form;
     if (vec) {
-        ew_kernel<T, OP, V, VN><<<stream_grid(n / VN + 1), kBlock, 0, s>>>(n, a, x, y);
+        ew_kernel<T, OP, V, VN><<<stream_grid(n / VN + 1), kBlock, 0, s>>>(n, a, x, y, form);
     } else {
-        ew_kernel<T, OP, T, 1><<<stream_grid(n), kBlock, 0, s>>>(n, a, x, y);
+        ew_kernel<T, OP, T, 1><<<stream_grid(n), kBlock, 0, s>>>(n, a, x, y, form);
     }
     LSK_LAUNCH_CHECK();
     return LSK_OK;
@@ -186,29 +196,36 @@ template <typename T> __device__ __forceinline__ T dot_v(T a, T b, T acc) { retu
 template <typename T, typename E, int EN, bool SAME>
 __global__ __launch_bounds__(kBlock) void dot_kernel(int64_t n, const T *__restrict__ v,
                                                      const T *__restrict__ w,
-                                                     T *__restrict__ out, int fin) {
+                                                     T *__restrict__ out, int fin, int form) {
     const int64_t ne = n / EN;
     const E *ve = reinterpret_cast<const E *>(v);
     const E *we = reinterpret_cast<const E *>(w);
-    const int64_t stride = int64_t(gridDim.x) * kBlock;
-    int64_t i = int64_t(blockIdx.x) * kBlock + threadIdx.x;
-    const bool first = (i == 0);
+    const int64_t gstride = int64_t(gridDim.x) * kBlock;
+    const int64_t inner = form ? kBlock : gstride;
+    const int64_t outer = 4 * gstride;
+    int64_t i = form ? int64_t(blockIdx.x) * (4 * kBlock) + threadIdx.x
+                     : int64_t(blockIdx.x) * kBlock + threadIdx.x;
+    const bool first = (blockIdx.x == 0 && threadIdx.x == 0);
     T acc[4] = {T(0), T(0), T(0), T(0)};
-    for (; i + 3 * stride < ne; i += 4 * stride) {
+    for (; i + 3 * inner < ne; i += outer) {
         E a[4], b[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            a[u] = ve[i + u * stride];
-            if constexpr (!SAME) b[u] = we[i + u * stride];
+            a[u] = ve[i + u * inner];
+            if constexpr (!SAME) b[u] = we[i + u * inner];
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) acc[u] = dot_v<T>(a[u], SAME ? a[u] : b[u], acc[u]);
     }
-    for (; i < ne; i += stride) {
-        E a = ve[i];
-        E b = a;
-        if constexpr (!SAME) b = we[i];
-        acc[0] = dot_v<T>(a, b, acc[0]);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int64_t j = i + u * inner;
+        if (j < ne) {
+            E a = ve[j];
+            E b = a;
+            if constexpr (!SAME) b = we[j];
+            acc[u] = dot_v<T>(a, b, acc[u]);
+        }
     }
     if (EN > 1 && first) {
         for (int64_t j = ne * EN; j < n; ++j) acc[1] = fma_t(v[j], SAME ? v[j] : w[j], acc[1]);
@@ -245,6 +262,7 @@ int launch_dot(const char *name, int64_t n, const T *v, const T *w, T *result, v
     using V = typename Vec<T>::type;
     constexpr int VN = Vec<T>::N;
     const bool same = (v == w);
+    const int form = lsk::options().blas1_form;
     const bool vec = lsk::aligned16(v) && lsk::aligned16(w);
     const int blocks = vec ? stream_grid(n / VN + 1) : stream_grid(n);
     T *partials = result;
@@ -263,11 +281,11 @@ int launch_dot(const char *name, int64_t n, const T *v, const T *w, T *result, v
         }
     }
     if (vec) {
-        if (same) dot_kernel<T, V, VN, true><<<blocks, kBlock, 0, s>>>(n, v, w, partials, fin);
-        else dot_kernel<T, V, VN, false><<<blocks, kBlock, 0, s>>>(n, v, w, partials, fin);
+        if (same) dot_kernel<T, V, VN, true><<<blocks, kBlock, 0, s>>>(n, v, w, partials, fin, form);
+        else dot_kernel<T, V, VN, false><<<blocks, kBlock, 0, s>>>(n, v, w, partials, fin, form);
     } else {
-        if (same) dot_kernel<T, T, 1, true><<<blocks, kBlock, 0, s>>>(n, v, w, partials, fin);
-        else dot_kernel<T, T, 1, false><<<blocks, kBlock, 0, s>>>(n, v, w, partials, fin);
+        if (same) dot_kernel<T, T, 1, true><<<blocks, kBlock, 0, s>>>(n, v, w, partials, fin, form);
+        else dot_kernel<T, T, 1, false><<<blocks, kBlock, 0, s>>>(n, v, w, partials, fin, form);
     }
     LSK_LAUNCH_CHECK();
     if (blocks > 1) {

@@ -16,6 +16,9 @@
 // x_lo..x_hi, as the reference's CPU body does (src/CSRMatrixTasks.cpp:88).
 //
 // HBM bytes per call: nnz*(8 + sizeof(T)) + rows*(16 + sizeof(T)) + the x window.
+#include <algorithm>
+#include <cstdlib>
+
 #include "lsk_common.hpp"
 
 namespace {
@@ -32,6 +35,20 @@ __device__ __forceinline__ double fma_t(double a, double b, double c) { return _
 __device__ __forceinline__ float fma_t(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 
 struct Rect { long long lo, hi; };
+
+// Native 16-byte vectors (the nontemporal builtin does not take HIP's struct vector types).
+typedef double d2_t __attribute__((ext_vector_type(2)));
+typedef float f4_t __attribute__((ext_vector_type(4)));
+typedef long long ll2_t __attribute__((ext_vector_type(2)));
+template <typename T> struct Native;
+template <> struct Native<double> { using V = d2_t; };
+template <> struct Native<float> { using V = f4_t; };
+
+template <bool NT, typename VT>
+__device__ __forceinline__ VT vload(const VT *p) {
+    if constexpr (NT) return __builtin_nontemporal_load(p);
+    else return *p;
+}
 
 template <typename T> __device__ __forceinline__ T vget(const double2 &v, int i) { return i == 0 ? v.x : v.y; }
 template <typename T> __device__ __forceinline__ T vget(const float4 &v, int i) {
@@ -66,7 +83,7 @@ template <typename T, int LOG_R>
 __global__ __launch_bounds__(kBlock) void csr_spmv_kernel(
     int64_t rows, const Rect *__restrict__ rects, int64_t k_base, int64_t nnz,
     const int64_t *__restrict__ col, const T *__restrict__ val, const T *__restrict__ x,
-    int64_t x_lo, int64_t x_hi, T *__restrict__ y, int beta) {
+    int64_t x_lo, int64_t x_hi, T *__restrict__ y, int beta, int remap) {
     constexpr int R = 1 << LOG_R;
     constexpr int G = kBlock / R;
     constexpr int CAP = Cfg<T>::CAP;
@@ -77,7 +94,7 @@ __global__ __launch_bounds__(kBlock) void csr_spmv_kernel(
     __shared__ int s_off[R + 1];
     __shared__ long long s_k0;
 
-    const unsigned tile = lsk::xcd_remap(blockIdx.x, gridDim.x);
+    const unsigned tile = lsk::xcd_remap(blockIdx.x, gridDim.x, remap);
     const int64_t r0 = int64_t(tile) * R;
     const int nr = static_cast<int>(rows - r0 < R ? rows - r0 : R);
     const int tid = threadIdx.x;
@@ -190,6 +207,200 @@ __global__ __launch_bounds__(kBlock) void csr_spmv_kernel(
     }
 }
 
+// One row of the tile per wave, entries straight from HBM (wave-level form of rows_by_wave).
+template <typename T>
+__device__ void wave_rows_direct(int nr, const Rect *__restrict__ rects, int64_t k_base,
+                                 int64_t nnz, const int64_t *__restrict__ col,
+                                 const T *__restrict__ val, const T *__restrict__ x, int64_t x_lo,
+                                 int64_t x_hi, T *__restrict__ y, int beta) {
+    const int lane = threadIdx.x % lsk::kWave;
+    for (int r = 0; r < nr; ++r) {
+        const Rect rc = rects[r];
+        T acc = T(0);
+        const int64_t lo = rc.lo > k_base ? rc.lo : k_base;
+        const int64_t hi = rc.hi < k_base + nnz - 1 ? rc.hi : k_base + nnz - 1;
+        for (int64_t k = lo + lane; k <= hi; k += lsk::kWave) {
+            const int64_t c = col[k - k_base];
+            if (c >= x_lo && c <= x_hi) acc = fma_t(val[k - k_base], x[c - x_lo], acc);
+        }
+        acc = lsk::wave_sum(acc);
+        if (lane == 0) y[r] = beta ? y[r] + acc : acc;
+    }
+}
+
+// Orders this wave's LDS writes before its later LDS reads (other lanes' data) without a
+// workgroup barrier: LDS operations of one wave execute in issue order, so only the
+// compiler must be kept from reordering them.
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// One chunk of the streaming phase: K units per lane (unit u = ubase + k*64 + lane).  All
+// 2K 16-byte loads of val and col are issued before the first use, then all x gathers, then
+// the products go to LDS.  Lanes whose unit lies past the end re-read the last unit (clamped
+// index, same cache line) and drop the result, so the chunk has no branches around loads.
+template <typename T, int K, bool NT>
+__device__ __forceinline__ void stream_chunk(int ubase, int lane, int nfull,
+                                             const T *__restrict__ vbody,
+                                             const int64_t *__restrict__ cbody,
+                                             const T *__restrict__ x, int64_t x_lo, int64_t x_hi,
+                                             T *__restrict__ sp_body) {
+    constexpr int U = Cfg<T>::U;
+    using V = typename Native<T>::V;
+    V vv[K];
+    long long cc[K][U];
+    int uu[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int u = ubase + k * lsk::kWave + lane;
+        uu[k] = u;
+        const int uc = u < nfull ? u : nfull - 1;
+        vv[k] = vload<NT>(reinterpret_cast<const V *>(vbody) + uc);
+#pragma unroll
+        for (int p = 0; p < U; p += 2) {
+            const ll2_t c2 = vload<NT>(reinterpret_cast<const ll2_t *>(cbody + uc * U + p));
+            cc[k][p] = c2.x;
+            cc[k][p + 1] = c2.y;
+        }
+    }
+    T xv[K][U];
+    bool in[K][U];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+#pragma unroll
+        for (int p = 0; p < U; ++p) {
+            const long long c = cc[k][p];
+            in[k][p] = c >= x_lo && c <= x_hi;   // the CPU body's input-domain guard
+            xv[k][p] = x[in[k][p] ? c - x_lo : 0];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        if (uu[k] < nfull) {
+#pragma unroll
+            for (int p = 0; p < U; ++p)
+                sp_body[uu[k] * U + p] = in[k][p] ? vv[k][p] * xv[k][p] : T(0);
+        }
+    }
+}
+
+// Wave-tile CSR SpMV: every wave owns RW = 1 << LOG_RW consecutive rows and never meets
+// the other waves of its workgroup (no s_barrier), so a wave that waits on HBM never holds
+// up three others.  Per tile:
+//   1. lanes < RW load the rects; the tile takes the streaming path when its rows tile one
+//      contiguous, buffer-sized run of entries (wave vote), else rows are walked one by one;
+//   2. the run is read in chunks of up to 4 aligned 16-byte units per lane (stream_chunk); the
+//      last chunk is sized to what is left, so few lanes idle;
+//   3. 64/RW lanes per row add the row's products from LDS; one lane per row stores y.
+template <typename T, int LOG_RW, bool NT>
+__global__ __launch_bounds__(kBlock) void csr_spmv_wave_kernel(
+    int64_t rows, const Rect *__restrict__ rects, int64_t k_base, int64_t nnz,
+    const int64_t *__restrict__ col, const T *__restrict__ val, const T *__restrict__ x,
+    int64_t x_lo, int64_t x_hi, T *__restrict__ y, int beta, int remap) {
+    constexpr int RW = 1 << LOG_RW;
+    constexpr int GW = lsk::kWave / RW;
+    constexpr int WAVES = kBlock / lsk::kWave;
+    constexpr int CAPW = Cfg<T>::CAP / WAVES;
+    constexpr int U = Cfg<T>::U;
+
+    __shared__ T s_prod[WAVES][CAPW];
+
+    const int wave = threadIdx.x / lsk::kWave, lane = threadIdx.x % lsk::kWave;
+    const unsigned tile = lsk::xcd_remap(blockIdx.x, gridDim.x, remap);
+    const int64_t r0 = (int64_t(tile) * WAVES + wave) * RW;
+    if (r0 >= rows) return; // wave-uniform; nothing below synchronises across waves
+    const int nr = static_cast<int>(rows - r0 < RW ? rows - r0 : RW);
+    T *sp = s_prod[wave];
+
+    // ---- 1. rects ------------------------------------------------------------------------
+    Rect rc{0, -1};
+    if (lane < nr) rc = rects[r0 + lane];
+    const long long k0 = __shfl(rc.lo, 0, lsk::kWave);
+    const long long rel_lo = rc.lo - k0, rel_end = rc.hi + 1 - k0;
+    const long long next_lo = __shfl_down(rel_lo, 1, lsk::kWave);
+    bool ok = true;
+    if (lane < nr) {
+        ok = rel_lo >= 0 && rel_end >= rel_lo && rel_end <= CAPW && k0 >= k_base &&
+             rc.hi - k_base < nnz;
+        if (lane < nr - 1) ok = ok && (next_lo == rel_end);
+    }
+    const int nnzw = static_cast<int>(__shfl(rel_end, nr - 1, lsk::kWave));
+    const int64_t *colb = col + (k0 - k_base);
+    const T *valb = val + (k0 - k_base);
+    // Units are U consecutive entries whose val word is 16-byte aligned; `head` entries
+    // precede the first whole unit.  col pairs must be 16-byte aligned at the same entries.
+    const int shift = static_cast<int>((reinterpret_cast<uintptr_t>(valb) / sizeof(T)) % U);
+    const int head0 = (U - shift) % U;
+    const bool col_pairs = ((reinterpret_cast<uintptr_t>(colb) / 8 + head0) % 2) == 0;
+    if (!__all(ok) || !col_pairs) {
+        wave_rows_direct<T>(nr, rects + r0, k_base, nnz, col, val, x, x_lo, x_hi, y + r0, beta);
+        return;
+    }
+
+    // ---- 2. stream --------------------------------------------------------------------------
+    const int head = head0 < nnzw ? head0 : nnzw;
+    const int nfull = (nnzw - head) / U;
+    const int tail0 = head + nfull * U; // first entry after the whole units
+    const T *vbody = valb + head;
+    const int64_t *cbody = colb + head;
+    for (int ubase = 0; ubase < nfull; ubase += lsk::kWave * 4) {
+        const int left = nfull - ubase; // wave-uniform
+        if (left > 3 * lsk::kWave)
+            stream_chunk<T, 4, NT>(ubase, lane, nfull, vbody, cbody, x, x_lo, x_hi, sp + head);
+        else if (left > 2 * lsk::kWave)
+            stream_chunk<T, 3, NT>(ubase, lane, nfull, vbody, cbody, x, x_lo, x_hi, sp + head);
+        else if (left > lsk::kWave)
+            stream_chunk<T, 2, NT>(ubase, lane, nfull, vbody, cbody, x, x_lo, x_hi, sp + head);
+        else
+            stream_chunk<T, 1, NT>(ubase, lane, nfull, vbody, cbody, x, x_lo, x_hi, sp + head);
+    }
+    {   // head and tail entries (those outside the whole units), one per lane
+        const int ntail = nnzw - tail0;
+        const int e = lane < head ? lane : tail0 + (lane - head);
+        if (lane < head + ntail) {
+            const long long c = colb[e];
+            const bool in = c >= x_lo && c <= x_hi;
+            sp[e] = in ? valb[e] * x[c - x_lo] : T(0);
+        }
+    }
+    wave_lds_fence();
+
+    // ---- 3. fold rows ---------------------------------------------------------------------------
+    const int row = lane / GW, g = lane % GW;
+    const int e0 = static_cast<int>(__shfl(rel_lo, row, lsk::kWave));
+    const int e1 = static_cast<int>(__shfl(rel_end, row, lsk::kWave));
+    T acc = T(0);
+    if (row < nr) {
+        // Four LDS reads in flight per step; reads past the row are clamped and dropped.
+        for (int e = e0 + g; e < e1; e += 4 * GW) {
+            T a[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int ek = e + k * GW;
+                a[k] = sp[ek < CAPW ? ek : CAPW - 1];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc += (e + k * GW < e1) ? a[k] : T(0);
+        }
+    }
+    if constexpr (GW > 1) {
+#pragma unroll
+        for (int off = GW / 2; off > 0; off >>= 1) acc += __shfl_xor(acc, off, lsk::kWave);
+    }
+    if (row < nr && g == 0) {
+        T *yp = y + r0 + row;
+        *yp = beta ? *yp + acc : acc;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void zero_kernel(int64_t n, T *__restrict__ y) {
+    const int64_t stride = int64_t(gridDim.x) * kBlock;
+    for (int64_t i = int64_t(blockIdx.x) * kBlock + threadIdx.x; i < n; i += stride) y[i] = T(0);
+}
+
 template <typename T>
 int launch_csr_spmv(const char *name, int64_t rows, int64_t nnz, const int64_t *rects,
                     int64_t k_base, const int64_t *col, const T *val, const T *x, int64_t x_lo,
@@ -207,22 +418,64 @@ int launch_csr_spmv(const char *name, int64_t rows, int64_t nnz, const int64_t *
     if ((reinterpret_cast<uintptr_t>(col) & 7u) || (reinterpret_cast<uintptr_t>(val) & (sizeof(T) - 1)))
         return lsk::fail(LSK_ERR_ALIGN, "%s: col/val must be naturally aligned", name);
 
+    if (x_hi < x_lo) { // an empty input domain admits no entry: y <- beta * y
+        if (beta == 0) {
+            zero_kernel<T><<<static_cast<unsigned>(std::min<int64_t>(lsk::ceil_div(rows, kBlock),
+                                                                  lsk::kMaxGridBlocks)),
+                             kBlock, 0, lsk::as_stream(stream)>>>(rows, y);
+            LSK_LAUNCH_CHECK();
+        }
+        return LSK_OK;
+    }
+    const double mean = rows > 0 ? double(nnz) / double(rows) : 0.0;
+    const Rect *rc = reinterpret_cast<const Rect *>(rects);
+    hipStream_t s = lsk::as_stream(stream);
+    const lsk::Options &tune = lsk::options();
+    if (tune.csr_variant == 1) {
+        // Rows per wave: as many as keep the tile's products inside the wave's quarter of
+        // the LDS buffer at the piece's mean row length, a power of two in 1..64.
+        const double want_w = mean > 0.0 ? 0.9 * (Cfg<T>::CAP / 4) / mean : 64.0;
+        int log_rw = 6;
+        while (log_rw > 0 && double(1 << log_rw) > want_w) --log_rw;
+        if (tune.csr_log_rw >= 0 && tune.csr_log_rw < log_rw) log_rw = tune.csr_log_rw; // only smaller tiles fit
+        const int64_t blocks_w = lsk::ceil_div(rows, int64_t(4) << log_rw);
+        if (blocks_w > 0x7fffffffLL) return lsk::fail(LSK_ERR_UNSUPPORTED, "%s: too many rows", name);
+#define LSK_CSRW_CASE(L)                                                                          \
+    case L:                                                                                       \
+        if (tune.csr_nontemporal)                                                                   \
+            csr_spmv_wave_kernel<T, L, true><<<unsigned(blocks_w), kBlock, 0, s>>>(               \
+                rows, rc, k_base, nnz, col, val, x, x_lo, x_hi, y, beta, tune.xcd_remap);          \
+        else                                                                                      \
+            csr_spmv_wave_kernel<T, L, false><<<unsigned(blocks_w), kBlock, 0, s>>>(              \
+                rows, rc, k_base, nnz, col, val, x, x_lo, x_hi, y, beta, tune.xcd_remap);          \
+        break;
+        switch (log_rw) {
+            LSK_CSRW_CASE(0)
+            LSK_CSRW_CASE(1)
+            LSK_CSRW_CASE(2)
+            LSK_CSRW_CASE(3)
+            LSK_CSRW_CASE(4)
+            LSK_CSRW_CASE(5)
+            LSK_CSRW_CASE(6)
+        }
+#undef LSK_CSRW_CASE
+        LSK_LAUNCH_CHECK();
+        return LSK_OK;
+    }
+
     // Rows per workgroup: as many as keep the tile's products inside the LDS buffer at the
     // piece's mean row length, a power of two in 4..256.
-    const double mean = rows > 0 ? double(nnz) / double(rows) : 0.0;
     const double want = mean > 0.0 ? 0.9 * Cfg<T>::CAP / mean : 256.0;
     int log_r = 8;
     while (log_r > 2 && double(1 << log_r) > want) --log_r;
 
-    const Rect *rc = reinterpret_cast<const Rect *>(rects);
-    hipStream_t s = lsk::as_stream(stream);
     const int64_t blocks64 = lsk::ceil_div(rows, int64_t(1) << log_r);
     if (blocks64 > 0x7fffffffLL) return lsk::fail(LSK_ERR_UNSUPPORTED, "%s: too many rows", name);
     const unsigned blocks = static_cast<unsigned>(blocks64);
 #define LSK_CSR_CASE(L)                                                                       \
     case L:                                                                                   \
         csr_spmv_kernel<T, L><<<blocks, kBlock, 0, s>>>(rows, rc, k_base, nnz, col, val, x,   \
-                                                        x_lo, x_hi, y, beta);                 \
+                                                        x_lo, x_hi, y, beta, tune.xcd_remap); \
         break;
     switch (log_r) {
         LSK_CSR_CASE(2)

@@ -48,16 +48,37 @@ constexpr size_t kScratchBytes = size_t(kMaxGridBlocks) * 16; // one 16-byte slo
 // State of the current device, created on first use (lsk_init does it eagerly).
 int device_state(DeviceState **out);
 
-// Workgroup -> logical tile remap that keeps tiles with neighbouring ids on one XCD: blocks
-// are dealt round-robin over the 8 XCDs, so block b lands with blocks b+8, b+16, ...;
-// giving that set a contiguous range of tiles lets the XCD's private L2 serve the input
-// vector window those tiles share.  Bijective for any grid size.
-__device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblocks) {
-    const unsigned xcd = bid % kNumXcd;
-    const unsigned q = nblocks / kNumXcd;
-    const unsigned r = nblocks % kNumXcd;
-    const unsigned first = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-    return first + bid / kNumXcd;
+// Library options (lsk_set_option); initial values may come from the environment variables
+// LSK_CSR_VARIANT / LSK_CSR_NT / LSK_XCD_REMAP.
+struct Options {
+    int csr_variant = 1;     // 0: workgroup tiles, 1: wave tiles
+    int csr_nontemporal = 0; // stream col/val with nontemporal loads
+    int xcd_remap = 0;       // tiles per XCD chunk (0 off, < 0 one contiguous eighth per XCD)
+    int csr_log_rw = -1;     // log2 rows per wave for the wave-tile form; -1 = from the mean row length
+    int blas1_form = 1;      // 0: grid-strided accesses, 1: contiguous chunk per workgroup
+};
+Options &options();
+
+// Workgroup -> logical tile remap for XCD-local reuse of the input-vector window.  Workgroups
+// are dealt round-robin over the 8 XCDs (block b shares an XCD with b+8, b+16, ...).  With
+// chunk c > 0, every group of 8*c consecutive block ids is re-dealt so that each XCD's c blocks
+// of the group take c CONSECUTIVE tiles; c < 0 gives each XCD one contiguous eighth of the
+// grid; c == 0 is the identity.  Bijective for any grid size (a trailing partial group keeps
+// the identity).  Placement is a speed hint only: results never depend on it.
+__device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblocks, int chunk) {
+    if (chunk == 0) return bid;
+    if (chunk < 0) {
+        const unsigned xcd = bid % kNumXcd;
+        const unsigned q = nblocks / kNumXcd;
+        const unsigned r = nblocks % kNumXcd;
+        const unsigned first = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+        return first + bid / kNumXcd;
+    }
+    const unsigned group = kNumXcd * unsigned(chunk);
+    const unsigned g = bid / group;
+    if ((g + 1) * group > nblocks) return bid; // trailing partial group
+    const unsigned in = bid % group;
+    return g * group + (in % kNumXcd) * unsigned(chunk) + in / kNumXcd;
 }
 
 // Sum over the 64 lanes of a wave; every lane returns the total.

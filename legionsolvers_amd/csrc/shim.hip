@@ -39,6 +39,17 @@ int hip_fail(hipError_t status, const char *expr, const char *file, int line) {
                 expr, file, line);
 }
 
+Options &options() {
+    static Options opts = [] {
+        Options o;
+        if (const char *e = std::getenv("LSK_CSR_VARIANT")) o.csr_variant = std::atoi(e);
+        if (const char *e = std::getenv("LSK_CSR_NT")) o.csr_nontemporal = std::atoi(e);
+        if (const char *e = std::getenv("LSK_XCD_REMAP")) o.xcd_remap = std::atoi(e);
+        return o;
+    }();
+    return opts;
+}
+
 int device_state(DeviceState **out) {
     int dev = -1;
     LSK_HIP(hipGetDevice(&dev));
@@ -63,6 +74,39 @@ const char *lsk_version(void) { return "lsk 0.1 gfx950"; }
 const char *lsk_last_error(void) { return g_error; }
 
 void lsk_set_abort_on_error(int enable) { g_abort_on_error = enable; }
+
+int lsk_set_option(const char *key, int value) {
+    if (!key) return lsk::fail(LSK_ERR_ARG, "lsk_set_option: null key");
+    lsk::Options &o = lsk::options();
+    if (!std::strcmp(key, "csr.variant")) {
+        if (value != 0 && value != 1) return lsk::fail(LSK_ERR_ARG, "csr.variant must be 0 or 1");
+        o.csr_variant = value;
+    } else if (!std::strcmp(key, "csr.nontemporal")) {
+        o.csr_nontemporal = value != 0;
+    } else if (!std::strcmp(key, "xcd_remap")) {
+        o.xcd_remap = value;
+    } else if (!std::strcmp(key, "csr.log_rows_per_wave")) {
+        if (value < -1 || value > 6) return lsk::fail(LSK_ERR_ARG, "csr.log_rows_per_wave must be -1..6");
+        o.csr_log_rw = value;
+    } else if (!std::strcmp(key, "blas1.form")) {
+        o.blas1_form = value != 0;
+    } else {
+        return lsk::fail(LSK_ERR_ARG, "lsk_set_option: unknown key '%s'", key);
+    }
+    return LSK_OK;
+}
+
+int lsk_get_option(const char *key, int *value) {
+    if (!key || !value) return lsk::fail(LSK_ERR_ARG, "lsk_get_option: null argument");
+    const lsk::Options &o = lsk::options();
+    if (!std::strcmp(key, "csr.variant")) *value = o.csr_variant;
+    else if (!std::strcmp(key, "csr.nontemporal")) *value = o.csr_nontemporal;
+    else if (!std::strcmp(key, "xcd_remap")) *value = o.xcd_remap;
+    else if (!std::strcmp(key, "csr.log_rows_per_wave")) *value = o.csr_log_rw;
+    else if (!std::strcmp(key, "blas1.form")) *value = o.blas1_form;
+    else return lsk::fail(LSK_ERR_ARG, "lsk_get_option: unknown key '%s'", key);
+    return LSK_OK;
+}
 
 int lsk_device_count(int *count) {
     if (!count) return lsk::fail(LSK_ERR_ARG, "lsk_device_count: null output");
