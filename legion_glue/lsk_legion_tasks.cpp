@@ -1,0 +1,185 @@
+// Legion-side binding of the lsk C ABI: the GPU (TOC_PROC) bodies of LegionSolvers' six leaf
+// tasks, for a Legion built with HIP (Legion_USE_HIP).  It replaces src/LinearAlgebraTasks.cu,
+// src/CSRMatrixTasks.cu, src/COOMatrixTasks.cu, src/CUDAUtilities.{hpp,cpp}, src/CudaLibs.{hpp,cu}
+// and src/CuSPARSEHelpers.hpp of the reference; nothing above the task bodies changes.
+//
+// NOT COMPILED IN THIS REPOSITORY: it needs <legion.h> and the reference's own headers
+// (TaskBaseClasses.hpp, LegionUtilities.hpp, ...), neither of which is available where liblsk.so
+// is built.  It is the stub a LegionSolvers maintainer adds, together with three widened
+// preprocessor guards (src/TaskBaseClasses.hpp:211,304, src/LegionUtilities.hpp:68,
+// src/Initialize.cpp:14,484: `LEGION_USE_CUDA` -> `LEGION_USE_CUDA || LEGION_USE_HIP`) and a
+// `Legion_USE_HIP` branch in CMakeLists.txt that adds this file and links liblsk.so in place of
+// cudart/cublas/cusparse (CMakeLists.txt:35-60).  The member names keep the
+// reference's `cuda_task_body`, because that is the name TaskTDI::preregister and
+// HasCUDAVariantMixin look for (src/TaskBaseClasses.hpp:211-223, src/MetaprogrammingUtilities.hpp:
+// 123-145).
+#include <legion.h>
+#include <realm/hip/hip_module.h>
+
+#include "COOMatrixTasks.hpp"
+#include "CSRMatrixTasks.hpp"
+#include "LegionUtilities.hpp"
+#include "LinearAlgebraTasks.hpp"
+
+#include "lsk.h"
+
+namespace LegionSolvers {
+
+namespace {
+
+// The task's stream: Realm's per-task HIP stream, with the context synchroniser switched off
+// because every kernel goes onto that one stream (what CUDALibraryContext::get_cuda_stream
+// does with the CUDA module, src/CUDAUtilities.cpp:66-75).
+lsk_stream_t task_stream() {
+    Realm::Hip::HipModule *module =
+        Realm::Runtime::get_runtime().get_module<Realm::Hip::HipModule>("hip");
+    assert(module);
+    module->set_task_ctxsync_required(false);
+    return reinterpret_cast<lsk_stream_t>(module->get_task_hip_stream());
+}
+
+// The reference prints and asserts on any library failure (src/CUDAUtilities.cpp:13-63).
+void check(int status) {
+    if (status != LSK_OK) {
+        std::fprintf(stderr, "[LegionSolvers] %s\n", lsk_last_error());
+        assert(false);
+    }
+}
+
+template <typename T> struct Abi;
+template <> struct Abi<float> {
+    static constexpr auto scal = lsk_scal_f32;
+    static constexpr auto axpy = lsk_axpy_f32;
+    static constexpr auto xpay = lsk_xpay_f32;
+    static constexpr auto xpay_nd = lsk_xpay_nd_f32;
+    static constexpr auto dot_host = lsk_dot_host_f32;
+    static constexpr auto csr_spmv = lsk_csr_spmv_f32;
+    static constexpr auto coo_spmv = lsk_coo_spmv_f32;
+};
+template <> struct Abi<double> {
+    static constexpr auto scal = lsk_scal_f64;
+    static constexpr auto axpy = lsk_axpy_f64;
+    static constexpr auto xpay = lsk_xpay_f64;
+    static constexpr auto xpay_nd = lsk_xpay_nd_f64;
+    static constexpr auto dot_host = lsk_dot_host_f64;
+    static constexpr auto csr_spmv = lsk_csr_spmv_f64;
+    static constexpr auto coo_spmv = lsk_coo_spmv_f64;
+};
+
+// One vector argument of a BLAS-1 task: base pointer of the dense piece and its volume.
+template <typename T, int DIM, typename COORD_T, typename ACC>
+struct Piece {
+    Legion::Domain domain;
+    T *ptr = nullptr;
+    int64_t volume = 0;
+    Piece(Legion::Context ctx, Legion::Runtime *rt, const Legion::Task *task,
+          const std::vector<Legion::PhysicalRegion> &regions, unsigned index) {
+        const auto &req = task->regions[index];
+        assert(req.privilege_fields.size() == 1);
+        ACC acc(regions[index], *req.privilege_fields.begin());
+        domain = rt->get_index_space_domain(ctx, req.region.get_index_space());
+        assert(domain.dense());
+        volume = static_cast<int64_t>(domain.get_volume());
+        if (volume > 0) ptr = const_cast<T *>(acc.ptr(domain.lo()));
+    }
+};
+
+} // namespace
+
+template <typename T, int DIM, typename COORD_T>
+void ScalTask<T, DIM, COORD_T>::cuda_task_body(LEGION_SOLVERS_TASK_ARGS) {
+    Piece<T, DIM, COORD_T, AffineReaderWriter<T, DIM, COORD_T>> x(ctx, rt, task, regions, 0);
+    const T alpha = get_alpha<T>(task->futures);
+    check(Abi<T>::scal(x.volume, alpha, x.ptr, task_stream()));
+}
+
+template <typename T, int DIM, typename COORD_T>
+void AxpyTask<T, DIM, COORD_T>::cuda_task_body(LEGION_SOLVERS_TASK_ARGS) {
+    Piece<T, DIM, COORD_T, AffineReaderWriter<T, DIM, COORD_T>> y(ctx, rt, task, regions, 0);
+    Piece<T, DIM, COORD_T, AffineReader<T, DIM, COORD_T>> x(ctx, rt, task, regions, 1);
+    assert(y.domain == x.domain);
+    const T alpha = get_alpha<T>(task->futures);
+    check(Abi<T>::axpy(y.volume, alpha, x.ptr, y.ptr, task_stream()));
+}
+
+template <typename T, int DIM, typename COORD_T>
+void XpayTask<T, DIM, COORD_T>::cuda_task_body(LEGION_SOLVERS_TASK_ARGS) {
+    Piece<T, DIM, COORD_T, AffineReaderWriter<T, DIM, COORD_T>> y(ctx, rt, task, regions, 0);
+    Piece<T, DIM, COORD_T, AffineReader<T, DIM, COORD_T>> x(ctx, rt, task, regions, 1);
+    assert(y.domain == x.domain);
+    const T alpha = get_alpha<T>(task->futures);
+    // Exact (compact) instances are contiguous; a caller that maps padded N-D instances
+    // passes extents and accessor strides to lsk_xpay_nd_* instead.
+    check(Abi<T>::xpay(y.volume, alpha, x.ptr, y.ptr, task_stream()));
+}
+
+template <typename T, int DIM, typename COORD_T>
+T DotTask<T, DIM, COORD_T>::cuda_task_body(LEGION_SOLVERS_TASK_ARGS) {
+    Piece<T, DIM, COORD_T, AffineReader<T, DIM, COORD_T>> v(ctx, rt, task, regions, 0);
+    Piece<T, DIM, COORD_T, AffineReader<T, DIM, COORD_T>> w(ctx, rt, task, regions, 1);
+    assert(v.domain == w.domain);
+    T result = static_cast<T>(0);
+    check(Abi<T>::dot_host(v.volume, v.ptr, w.ptr, &result, task_stream())); // syncs the stream
+    return result;
+}
+
+LEGION_SOLVERS_KDR_TEMPLATE
+void CSRMatvecTask<LEGION_SOLVERS_KDR_TEMPLATE_ARGS>::cuda_task_body(LEGION_SOLVERS_TASK_ARGS) {
+    static_assert(KERNEL_DIM == 1 && DOMAIN_DIM == 1 && RANGE_DIM == 1);
+    static_assert(sizeof(Legion::Rect<1, KERNEL_COORD_T>) == 16 && sizeof(DOMAIN_COORD_T) == 8);
+    assert(regions.size() == 4 && task->arglen == sizeof(Args));
+    const Args args = *reinterpret_cast<const Args *>(task->args);
+    const auto out_bounds = regions[0].template get_bounds<1, RANGE_COORD_T>().bounds;
+    const auto ker_bounds = regions[1].template get_bounds<1, KERNEL_COORD_T>().bounds;
+    const auto in_bounds = regions[3].template get_bounds<1, DOMAIN_COORD_T>().bounds;
+    if (out_bounds.empty()) return;
+    const AffineReaderWriter<ENTRY_T, 1, RANGE_COORD_T> y(regions[0], *task->regions[0].privilege_fields.begin());
+    const AffineReader<ENTRY_T, 1, KERNEL_COORD_T> val(regions[1], args.fid_entry);
+    const AffineReader<Legion::Point<1, DOMAIN_COORD_T>, 1, KERNEL_COORD_T> col(regions[1], args.fid_col);
+    const AffineReader<Legion::Rect<1, KERNEL_COORD_T>, 1, RANGE_COORD_T> rowptr(
+        regions[2], *task->regions[2].privilege_fields.begin());
+    const AffineReader<ENTRY_T, 1, DOMAIN_COORD_T> x(regions[3], *task->regions[3].privilege_fields.begin());
+    const bool no_x = in_bounds.empty(), no_k = ker_bounds.empty();
+    // beta = 0: what the reference's cuSPARSE call does (src/CSRMatrixTasks.cu:117-118).
+    check(Abi<ENTRY_T>::csr_spmv(
+        static_cast<int64_t>(out_bounds.volume()), no_k ? 0 : static_cast<int64_t>(ker_bounds.volume()),
+        reinterpret_cast<const int64_t *>(rowptr.ptr(out_bounds.lo)), no_k ? 0 : ker_bounds.lo[0],
+        no_k ? nullptr : reinterpret_cast<const int64_t *>(col.ptr(ker_bounds.lo)),
+        no_k ? nullptr : val.ptr(ker_bounds.lo), no_x ? nullptr : x.ptr(in_bounds.lo),
+        no_x ? 0 : in_bounds.lo[0], no_x ? -1 : in_bounds.hi[0],
+        const_cast<ENTRY_T *>(y.ptr(out_bounds.lo)), /*beta=*/0, task_stream()));
+}
+
+LEGION_SOLVERS_KDR_TEMPLATE
+void COOMatvecTask<LEGION_SOLVERS_KDR_TEMPLATE_ARGS>::cuda_task_body(LEGION_SOLVERS_TASK_ARGS) {
+    static_assert(KERNEL_DIM == 1 && DOMAIN_DIM == 1 && RANGE_DIM == 1);
+    assert(regions.size() == 3 && task->arglen == sizeof(Args));
+    const Args args = *reinterpret_cast<const Args *>(task->args);
+    const auto out_bounds = regions[0].template get_bounds<1, RANGE_COORD_T>().bounds;
+    const auto ker_bounds = regions[1].template get_bounds<1, KERNEL_COORD_T>().bounds;
+    const auto in_bounds = regions[2].template get_bounds<1, DOMAIN_COORD_T>().bounds;
+    if (ker_bounds.empty() || out_bounds.empty() || in_bounds.empty()) return;
+    // Reduction-privileged output, accumulated into (src/COOMatrixTasks.cu:101-108).
+    const AffineSumAccessor<ENTRY_T, 1, RANGE_COORD_T> y(regions[0], *task->regions[0].privilege_fields.begin(),
+                                                         LEGION_REDOP_SUM<ENTRY_T>);
+    const AffineReader<ENTRY_T, 1, KERNEL_COORD_T> val(regions[1], args.fid_entry);
+    const AffineReader<Legion::Point<1, RANGE_COORD_T>, 1, KERNEL_COORD_T> row(regions[1], args.fid_row);
+    const AffineReader<Legion::Point<1, DOMAIN_COORD_T>, 1, KERNEL_COORD_T> col(regions[1], args.fid_col);
+    const AffineReader<ENTRY_T, 1, DOMAIN_COORD_T> x(regions[2], *task->regions[2].privilege_fields.begin());
+    check(Abi<ENTRY_T>::coo_spmv(
+        static_cast<int64_t>(ker_bounds.volume()), reinterpret_cast<const int64_t *>(row.ptr(ker_bounds.lo)),
+        reinterpret_cast<const int64_t *>(col.ptr(ker_bounds.lo)), val.ptr(ker_bounds.lo),
+        x.ptr(in_bounds.lo), in_bounds.lo[0], in_bounds.hi[0],
+        reinterpret_cast<ENTRY_T *>(y.ptr(out_bounds.lo)), out_bounds.lo[0], out_bounds.hi[0], task_stream()));
+}
+
+// CSRRmatvecTask / COORmatvecTask stay assert(false), as in the reference
+// (src/CSRMatrixTasks.cu:159-164, src/COOMatrixTasks.cu:149-154).
+
+// The explicit instantiations are the reference's own lists (src/LinearAlgebraTasks.cu:241-366,
+// src/CSRMatrixTasks.cu:167-172, src/COOMatrixTasks.cu:157-162), unchanged.
+
+// LoadCUDALibsTask::task_body (src/CudaLibs.cu:11-20) becomes: lsk_init(device ordinal of the
+// executing processor) -- there are no library handles left to warm.
+
+} // namespace LegionSolvers
