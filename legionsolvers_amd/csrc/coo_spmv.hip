@@ -3,12 +3,20 @@
 // src/COOMatrixTasks.cu:12-146), with the CPU body's domain guards
 // (src/COOMatrixTasks.cpp:67-74).
 //
-// A workgroup takes a chunk of 2048 consecutive entries: lanes load row/col/val coalesced,
-// gather x through L2 and park (row, product) in LDS.  Runs of equal rows inside the chunk,
-// cut every 32 entries so that no lane walks a long run, are summed on chip by the lane that
-// sees the run's head, which then issues ONE floating-point atomic add to y.  Row-sorted
-// input therefore costs one atomic per (row, chunk) pair; unsorted input degrades to one
-// atomic per entry and stays correct.  y accumulates (beta = 1).
+// Two forms, both accumulating into y (beta = 1) and both correct for any entry order:
+//
+// Wave scan (default).  A wave takes 64*K consecutive entries, K steps of one entry per lane.
+// All row/col/val loads of the K steps are issued first, then the K gathers of x.  Per step
+// the products are summed per run of equal rows by a wave-wide segmented inclusive scan in
+// registers (DPP row shifts and row broadcasts, no LDS, no barrier): the run boundaries are one
+// ballot, and a lane adds its neighbour's partial only if that neighbour lies at or after the
+// start of its own run.  The last lane of every run issues ONE floating-point atomic add; the
+// run that is still open at lane 63 is carried into lane 0 of the next step, so row-sorted
+// input costs one atomic per row plus one per wave boundary.
+//
+// Workgroup chunks (option coo.variant = 0).  A workgroup takes 2048 consecutive entries and
+// parks (row, product) in LDS; runs of equal rows, cut every 32 entries, are summed by the
+// lane that sees the run's head.
 //
 // HBM bytes per call: nnz*(16 + sizeof(T)) + the touched x and y windows.
 #include <climits>
@@ -71,6 +79,108 @@ __global__ __launch_bounds__(kBlock) void coo_spmv_kernel(
     }
 }
 
+// ---- wave-scan form ---------------------------------------------------------------------
+
+constexpr int kDppRowShr1 = 0x111, kDppRowShr2 = 0x112, kDppRowShr4 = 0x114, kDppRowShr8 = 0x118;
+constexpr int kDppRowBcast15 = 0x142, kDppRowBcast31 = 0x143;
+
+// Value of `v` in the lane the DPP control selects, 0 where the control selects no lane (past
+// the start of a row of 16 for a shift; rows outside ROW_MASK for a broadcast).
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ float dpp_get(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ double dpp_get(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, static_cast<int>(b), CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, static_cast<int>(b >> 32), CTRL, ROW_MASK, 0xf, false);
+    return __longlong_as_double((static_cast<long long>(hi) << 32) | static_cast<unsigned>(lo));
+}
+
+__device__ __forceinline__ long long wave_read_lane(long long v, int src) {
+    const int lo = __builtin_amdgcn_readlane(static_cast<int>(v), src);
+    const int hi = __builtin_amdgcn_readlane(static_cast<int>(v >> 32), src);
+    return (static_cast<long long>(hi) << 32) | static_cast<unsigned>(lo);
+}
+__device__ __forceinline__ double wave_read_lane(double v, int src) {
+    return __longlong_as_double(wave_read_lane(__double_as_longlong(v), src));
+}
+__device__ __forceinline__ float wave_read_lane(float v, int src) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
+}
+
+// Inclusive sum of s over the lanes start..lane of this wave, where `start` is the first lane
+// of the run the lane belongs to.  Six rounds; a round adds the partial of a lower lane only
+// if that lane is inside the run, in which case the partial it holds covers exactly the part
+// of the run that is still missing.
+template <typename T> __device__ __forceinline__ T run_scan(T s, int lane, int start) {
+    T t;
+    t = dpp_get<kDppRowShr1, 0xf>(s); s += (lane - 1 >= start) ? t : T(0);
+    t = dpp_get<kDppRowShr2, 0xf>(s); s += (lane - 2 >= start) ? t : T(0);
+    t = dpp_get<kDppRowShr4, 0xf>(s); s += (lane - 4 >= start) ? t : T(0);
+    t = dpp_get<kDppRowShr8, 0xf>(s); s += (lane - 8 >= start) ? t : T(0);
+    t = dpp_get<kDppRowBcast15, 0xa>(s); s += ((lane & ~15) - 1 >= start) ? t : T(0); // lanes 16-31, 48-63
+    t = dpp_get<kDppRowBcast31, 0xc>(s); s += (31 >= start) ? t : T(0);               // lanes 32-63
+    return s;
+}
+
+template <typename T, int K>
+__global__ __launch_bounds__(kBlock) void coo_spmv_scan_kernel(
+    int64_t nnz, const int64_t *__restrict__ row, const int64_t *__restrict__ col,
+    const T *__restrict__ val, const T *__restrict__ x, int64_t x_lo, int64_t x_hi,
+    T *__restrict__ y, int64_t y_lo, int64_t y_hi) {
+    const int lane = threadIdx.x & (lsk::kWave - 1);
+    const int64_t wave = int64_t(blockIdx.x) * (kBlock / lsk::kWave) + (threadIdx.x / lsk::kWave);
+    const int64_t base = wave * (lsk::kWave * K);
+    if (base >= nnz) return; // the whole wave leaves together
+    const int64_t last = nnz - 1;
+
+    long long rr[K], cc[K];
+    T vv[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) { // entries past the end re-read the last one and are dropped below
+        const int64_t e = base + j * lsk::kWave + lane;
+        const int64_t ec = e < last ? e : last;
+        rr[j] = row[ec];
+        cc[j] = col[ec];
+        vv[j] = val[ec];
+    }
+    T pp[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        const int64_t e = base + j * lsk::kWave + lane;
+        const bool live = e <= last && cc[j] >= x_lo && cc[j] <= x_hi && rr[j] >= y_lo && rr[j] <= y_hi;
+        const T xv = x[live ? cc[j] - x_lo : 0];
+        pp[j] = live ? vv[j] * xv : T(0);
+        // Dropped entries get a row id no live entry has: they form runs of their own, whose
+        // sums are never written.
+        rr[j] = live ? rr[j] : LLONG_MIN;
+    }
+
+    long long carry_row = LLONG_MIN; // run still open at the end of the previous step
+    T carry = T(0);
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        if (base + j * lsk::kWave > last) break; // wave-uniform: nothing but dropped entries left
+        const long long r = rr[j];
+        T s = pp[j];
+        const long long r0 = wave_read_lane(r, 0);
+        if (lane == 0) {
+            if (r0 == carry_row) s += carry;
+            else if (carry_row != LLONG_MIN) unsafeAtomicAdd(&y[carry_row - y_lo], carry);
+        }
+        const long long rp = __shfl_up(r, 1);
+        const bool head = lane == 0 || rp != r;
+        const unsigned long long heads = __ballot(head);
+        const int start = 63 - __clzll(heads & (~0ull >> (63 - lane))); // bit 0 is always set
+        s = run_scan(s, lane, start);
+        const bool tail = lane < 63 && ((heads >> (lane + 1)) & 1ull);
+        if (tail && r != LLONG_MIN) unsafeAtomicAdd(&y[r - y_lo], s);
+        carry_row = wave_read_lane(r, 63);
+        carry = wave_read_lane(s, 63);
+    }
+    if (lane == 0 && carry_row != LLONG_MIN) unsafeAtomicAdd(&y[carry_row - y_lo], carry);
+}
+
 template <typename T>
 int launch_coo_spmv(const char *name, int64_t nnz, const int64_t *row, const int64_t *col,
                     const T *val, const T *x, int64_t x_lo, int64_t x_hi, T *y, int64_t y_lo,
@@ -80,10 +190,16 @@ int launch_coo_spmv(const char *name, int64_t nnz, const int64_t *row, const int
     if (!row || !col || !val) return lsk::fail(LSK_ERR_ARG, "%s: null kernel arrays", name);
     if (x_hi < x_lo || y_hi < y_lo) return LSK_OK; // an empty domain admits no entry
     if (!x || !y) return lsk::fail(LSK_ERR_ARG, "%s: null vector", name);
-    const int64_t blocks = lsk::ceil_div(nnz, kChunk);
+    const int64_t blocks = lsk::ceil_div(nnz, kChunk); // both forms: 2048 entries per workgroup
     if (blocks > 0x7fffffffLL) return lsk::fail(LSK_ERR_UNSUPPORTED, "%s: too many entries", name);
-    coo_spmv_kernel<T><<<static_cast<unsigned>(blocks), kBlock, 0, lsk::as_stream(stream)>>>(
-        nnz, row, col, val, x, x_lo, x_hi, y, y_lo, y_hi);
+    if (lsk::options().coo_variant == 1) {
+        constexpr int K = kChunk / kBlock;
+        coo_spmv_scan_kernel<T, K><<<static_cast<unsigned>(blocks), kBlock, 0, lsk::as_stream(stream)>>>(
+            nnz, row, col, val, x, x_lo, x_hi, y, y_lo, y_hi);
+    } else {
+        coo_spmv_kernel<T><<<static_cast<unsigned>(blocks), kBlock, 0, lsk::as_stream(stream)>>>(
+            nnz, row, col, val, x, x_lo, x_hi, y, y_lo, y_hi);
+    }
     LSK_LAUNCH_CHECK();
     return LSK_OK;
 }

@@ -56,6 +56,7 @@ struct Options {
     int xcd_remap = 0;       // tiles per XCD chunk (0 off, < 0 one contiguous eighth per XCD)
     int csr_log_rw = -1;     // log2 rows per wave for the wave-tile form; -1 = from the mean row length
     int blas1_form = 1;      // 0: grid-strided accesses, 1: contiguous chunk per workgroup
+    int coo_variant = 1;     // 0: workgroup chunks through LDS, 1: wave-wide segmented scan
 };
 Options &options();
 

@@ -45,6 +45,7 @@ Options &options() {
         if (const char *e = std::getenv("LSK_CSR_VARIANT")) o.csr_variant = std::atoi(e);
         if (const char *e = std::getenv("LSK_CSR_NT")) o.csr_nontemporal = std::atoi(e);
         if (const char *e = std::getenv("LSK_XCD_REMAP")) o.xcd_remap = std::atoi(e);
+        if (const char *e = std::getenv("LSK_COO_VARIANT")) o.coo_variant = std::atoi(e) != 0;
         return o;
     }();
     return opts;
@@ -90,6 +91,9 @@ int lsk_set_option(const char *key, int value) {
         o.csr_log_rw = value;
     } else if (!std::strcmp(key, "blas1.form")) {
         o.blas1_form = value != 0;
+    } else if (!std::strcmp(key, "coo.variant")) {
+        if (value != 0 && value != 1) return lsk::fail(LSK_ERR_ARG, "coo.variant must be 0 or 1");
+        o.coo_variant = value;
     } else {
         return lsk::fail(LSK_ERR_ARG, "lsk_set_option: unknown key '%s'", key);
     }
@@ -104,6 +108,7 @@ int lsk_get_option(const char *key, int *value) {
     else if (!std::strcmp(key, "xcd_remap")) *value = o.xcd_remap;
     else if (!std::strcmp(key, "csr.log_rows_per_wave")) *value = o.csr_log_rw;
     else if (!std::strcmp(key, "blas1.form")) *value = o.blas1_form;
+    else if (!std::strcmp(key, "coo.variant")) *value = o.coo_variant;
     else return lsk::fail(LSK_ERR_ARG, "lsk_get_option: unknown key '%s'", key);
     return LSK_OK;
 }

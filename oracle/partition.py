@@ -31,8 +31,13 @@ def image_range(rects: np.ndarray, row_piece):
     lo, hi = row_piece
     if hi < lo:
         return np.zeros(0, dtype=np.int64)
-    parts = [np.arange(a, b + 1, dtype=np.int64) for a, b in rects[lo:hi + 1] if b >= a]
-    return np.unique(np.concatenate(parts)) if parts else np.zeros(0, dtype=np.int64)
+    r = rects[lo:hi + 1]
+    r = r[r[:, 1] >= r[:, 0]]
+    if len(r) == 0:
+        return np.zeros(0, dtype=np.int64)
+    if np.all(r[1:, 0] == r[:-1, 1] + 1):  # back-to-back rects cover one interval
+        return np.arange(r[0, 0], r[-1, 1] + 1, dtype=np.int64)
+    return np.unique(np.concatenate([np.arange(a, b + 1, dtype=np.int64) for a, b in r]))
 
 
 def preimage(field: np.ndarray, piece):
@@ -49,6 +54,14 @@ def image(field: np.ndarray, kernel_piece: np.ndarray, space=None):
     if space is not None:
         vals = vals[(vals >= space[0]) & (vals <= space[1])]
     return vals.astype(np.int64)
+
+
+def image_bounds(field: np.ndarray, kernel_piece: np.ndarray, space=None):
+    """bounds(image(field, kernel_piece, space)) without building the set."""
+    vals = field[kernel_piece]
+    if space is not None:
+        vals = vals[(vals >= space[0]) & (vals <= space[1])]
+    return bounds(vals)
 
 
 def bounds(indices: np.ndarray):

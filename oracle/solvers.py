@@ -26,7 +26,7 @@ class Matrix:
             self.kernel_pieces = [part.image_range(rects, p) for p in range_pieces]
         else:
             self.kernel_pieces = [part.preimage(row, p) for p in range_pieces]
-        self.ghost_sets = [part.image(col, k, domain_space) for k in self.kernel_pieces]
+        self.ghost_bounds = [part.image_bounds(col, k, domain_space) for k in self.kernel_pieces]
 
     def matvec(self, y, x):
         """Index launch of CSRMatvecTask / COOMatvecTask, CPU bodies, accumulate."""
@@ -35,7 +35,7 @@ class Matrix:
             if rhi < rlo:
                 continue
             klo, khi = part.bounds(kp)
-            glo, ghi = part.bounds(self.ghost_sets[color])
+            glo, ghi = self.ghost_bounds[color]
             xin = np.ascontiguousarray(x[glo:ghi + 1])
             yp = np.ascontiguousarray(y[rlo:rhi + 1])
             if khi >= klo:

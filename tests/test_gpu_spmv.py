@@ -155,8 +155,50 @@ def test_csr_spmv_misaligned_arrays(suf):
             np.testing.assert_allclose(yd.cpu().numpy(), want, rtol=0, atol=tol * 20)
 
 
+@pytest.fixture(params=[1, 0], ids=["wave-scan", "workgroup-chunks"])
+def coo_variant(request):
+    """Both forms of the COO kernel (option coo.variant); the default is restored afterwards."""
+    _lib.call("lsk_set_option", b"coo.variant", request.param)
+    yield request.param
+    _lib.call("lsk_set_option", b"coo.variant", 1)
+
+
 @pytest.mark.parametrize("suf", ["f32", "f64"])
-def test_coo_spmv(suf):
+def test_coo_spmv_run_shapes(suf, coo_variant):
+    """Entry counts around the wave (64), wave-tile (512) and workgroup (2048) boundaries and
+    runs of equal rows of every length from 1 to several waves, sorted and unsorted."""
+    npdt, tdt, tol = DT[suf]
+    rng = np.random.default_rng(27)
+    n_rows, n_cols = 300, 257
+    x = rng.standard_normal(n_cols).astype(npdt)
+    for nnz in (1, 2, 63, 64, 65, 127, 128, 511, 512, 513, 1000, 2047, 2048, 2049, 4096, 10000):
+        for shape in ("short-runs", "long-runs", "unsorted"):
+            if shape == "short-runs":
+                lens = rng.integers(1, 6, size=nnz)
+            elif shape == "long-runs":
+                lens = rng.integers(40, 700, size=nnz)
+            else:
+                lens = np.ones(nnz, dtype=np.int64)
+            ids = rng.integers(0, n_rows, size=nnz) if shape == "unsorted" else np.sort(rng.integers(0, n_rows, size=nnz))
+            r = np.repeat(ids, lens)[:nnz].astype(np.int64)
+            c = rng.integers(0, n_cols, size=nnz).astype(np.int64)
+            v = rng.standard_normal(nnz).astype(npdt)
+            print(f"case coo_spmv_{suf} variant={coo_variant} nnz={nnz} {shape}", flush=True)
+            y0 = rng.standard_normal(n_rows).astype(npdt)
+            want = y0.copy()
+            oracle.coo_matvec(r, c, v, x, 0, n_cols - 1, want, 0, n_rows - 1)
+            bound = np.zeros(n_rows, dtype=npdt)
+            oracle.coo_matvec(r, c, np.abs(v), np.abs(x), 0, n_cols - 1, bound, 0, n_rows - 1)
+            yd, rd, cd, vd, xd = dev(y0), dev(r), dev(c), dev(v), dev(x)
+            _lib.call(f"lsk_coo_spmv_{suf}", nnz, P(rd), P(cd), P(vd), P(xd), 0, n_cols - 1,
+                      P(yd), 0, n_rows - 1, stream())
+            err = np.abs(yd.cpu().numpy().astype(np.float64) - want)
+            lim = tol * (bound.astype(np.float64) + np.abs(want) + 1e-300)
+            assert np.all(err <= lim), (nnz, shape, float(err.max()), int(np.argmax(err - lim)))
+
+
+@pytest.mark.parametrize("suf", ["f32", "f64"])
+def test_coo_spmv(suf, coo_variant):
     npdt, tdt, tol = DT[suf]
     rng = np.random.default_rng(26)
     offs, cfs = oracle.benchmark_stencil_offsets(4)

@@ -35,6 +35,65 @@ def timed(fn, reps):
     return start.elapsed_time(stop) / reps
 
 
+def coo_bench(args, ctx, lib, dtype, esz):
+    from legionsolvers_amd import COOMatrix
+    _, offs, cfs = sg.benchmark_stencil(args.dim)
+    extent = bs.grid_extent(args.dim, args.n, args.n, args.n)
+    rows = 1
+    for e in extent:
+        rows *= e
+    cases = {}
+    ip = IndexPartition.equal(IndexSpace(0, rows - 1), 1)
+    cases[f"stencil dim-flag {args.dim} n={args.n}"] = (
+        sg.create_linearized_coo_stencil_matrix(ctx, extent, offs, cfs, ip, dtype), rows, ip)
+    if args.coo_random_rows:
+        r = args.coo_random_rows
+        g = torch.Generator(device="cuda").manual_seed(20250310)
+        row = torch.arange(r, device="cuda", dtype=torch.int64).repeat_interleave(32)
+        col = torch.randint(0, r, (r * 32,), generator=g, device="cuda", dtype=torch.int64)
+        val = (torch.rand(r * 32, generator=g, device="cuda", dtype=torch.float64) * 2 - 1).to(dtype)
+        rip = IndexPartition.equal(IndexSpace(0, r - 1), 1)
+        cases[f"random 32/row rows={r}"] = (COOMatrix(ctx, row, col, val, IndexSpace(0, r - 1)), r, rip)
+    for name, (A, n, part) in cases.items():
+        kp = A.create_kernel_partition_from_range_partition(part)
+        x = PartitionedVector(ctx, "x", part, dtype)
+        y = PartitionedVector(ctx, "y", part, dtype)
+        x.owned.copy_(torch.randn(n, device="cuda", dtype=dtype))
+        algo = A.nnz * (16 + esz) + n * 3 * esz
+        print(f"{name}: rows={n} nnz={A.nnz} algorithmic bytes/SpMV={algo}", flush=True)
+
+        def spmv():
+            A.matvec(y, x.owned, 0, n - 1, kp, 1)
+
+        ref = None
+        for v in (0, 1):
+            lib.lsk_set_option(b"coo.variant", v)
+            y.zero_fill()
+            spmv()
+            got = y.owned.clone()
+            if ref is None:
+                ref = got
+            else:
+                err = float((got - ref).abs().max())
+                assert err <= (1e-12 if esz == 8 else 1e-4) * float(ref.abs().max()), err
+        for _ in range(50):
+            spmv()
+        torch.cuda.synchronize()
+        times = {0: [], 1: []}
+        for _ in range(args.rounds):
+            for v in (0, 1):
+                lib.lsk_set_option(b"coo.variant", v)
+                spmv()
+                times[v].append(timed(spmv, args.reps))
+        for v in (0, 1):
+            med = statistics.median(times[v])
+            print(f"  coo.variant={v}: median {med:.3f} ms  min {min(times[v]):.3f} ms  "
+                  f"{algo / med / 1e6:.1f} GB/s  ({algo / med / 1e6 / 8000:.3f} of 8 TB/s)", flush=True)
+        del A, x, y
+        torch.cuda.empty_cache()
+    lib.lsk_set_option(b"coo.variant", 1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--n", type=int, default=512)
@@ -48,11 +107,16 @@ def main():
     ap.add_argument("--logrw", default="-1")
     ap.add_argument("--exp", default="0")
     ap.add_argument("--blas1", action="store_true")
+    ap.add_argument("--coo", action="store_true", help="time the COO kernel forms instead (stencil at --n)")
+    ap.add_argument("--coo-random-rows", type=int, default=0,
+                    help="with --coo: also a random row-sorted matrix, 32 entries per row")
     args = ap.parse_args()
     dtype = torch.float64 if args.dtype == "f64" else torch.float32
     esz = 8 if args.dtype == "f64" else 4
     ctx = Context(torch.device("cuda", 0))
     lib = _lib.lib()
+    if args.coo:
+        return coo_bench(args, ctx, lib, dtype, esz)
     _, offs, cfs = sg.benchmark_stencil(args.dim)
     extent = bs.grid_extent(args.dim, args.n, args.n, args.n)
     rows = 1
