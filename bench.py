@@ -95,7 +95,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--n", type=int, default=512, help="grid points per dimension")
+    ap.add_argument("--n", "--grid", dest="n", type=int, default=512, help="grid points per dimension")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -117,10 +117,7 @@ def main():
     t_spmv = spmv_kernel_time(ctx, matrix, planner, reps=20)
     algo_bytes = matrix.nnz * 16 + matrix.rows * 32
     achieved = algo_bytes / t_spmv / 1e9
-    t_max = torch.tensor([t_spmv], dtype=torch.float64, device=ctx.device)
-    if world > 1:
-        dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
-    spmv_gbps_job = (nnz_total * 16 + rows * 32) / float(t_max.item()) / 1e9
+    spmv_gbps_job = (nnz_total * 16 + rows * 32) / ctx.comm.max_over_ranks(t_spmv, ctx.device) / 1e9
     traffic = None
     traffic_file = os.path.join(REPO, "profiles", "spmv_hbm_traffic.json")
     if world == 1 and n1 == 512 and os.path.exists(traffic_file):

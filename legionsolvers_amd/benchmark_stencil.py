@@ -71,12 +71,20 @@ def build_problem(ctx, dim_flag, nx, ny, nz, num_pieces, solver_flag, dtype=torc
 
 
 def init_distributed():
-    """One process per GPU; rendezvous from the torchrun environment."""
+    """One process per GPU; rendezvous from the torchrun environment.  LSK_DIST_BACKEND=gloo
+    with fewer GPUs than ranks is the rehearsal set-up: ranks share the cards and every
+    transfer is staged through host memory (see comm.Communicator)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    backend = os.environ.get("LSK_DIST_BACKEND", "nccl")
+    if backend == "gloo":
+        local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     if world > 1 and not dist.is_initialized():
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     return world, local_rank
 
 
@@ -93,10 +101,7 @@ def timed_steps(ctx, solver, warmup: int, steps: int) -> float:
         solver.step()
     ctx.synchronize()
     ctx.comm.barrier()
-    elapsed = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=ctx.device)
-    if ctx.world_size > 1:
-        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
-    return float(elapsed.item())
+    return ctx.comm.max_over_ranks(time.perf_counter() - t0, ctx.device)
 
 
 def main(argv=None):

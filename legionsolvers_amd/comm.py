@@ -6,6 +6,12 @@ src/PartitionedVector.cpp:353-357; a READ_ONLY requirement on the ghost partitio
 src/CSRMatrix.cpp:202-211).  Here one process drives one MI355X and `torch.distributed`
 carries them: backend "nccl" is RCCL over xGMI on the GPUs, "gloo" runs the same code on CPU
 tensors for tests.  The plan arithmetic (who sends which interval to whom) is pure host code.
+
+Rehearsal transport: when the group's backend is "gloo" and the tensors live on a GPU (several
+ranks sharing one card on a one-GPU machine), every transfer is staged through host memory with
+synchronous copies, because gloo is only ever handed CPU tensors here.  It exists to run the
+multi-rank path on real kernels where RCCL cannot (RCCL refuses two ranks on one device); it is
+not a data path for production.
 """
 from __future__ import annotations
 
@@ -74,6 +80,10 @@ class Communicator:
             self.world_size = dist.get_world_size(group)
         else:
             self.rank, self.world_size = 0, 1
+        self.backend = dist.get_backend(group) if self.world_size > 1 else None
+
+    def _staged(self, t: torch.Tensor) -> bool:
+        return self.backend == "gloo" and t.is_cuda
 
     # -- set-up time (host values) -----------------------------------------------------
     def all_gather_object(self, obj):
@@ -87,11 +97,26 @@ class Communicator:
         if self.world_size > 1:
             dist.barrier(group=self.group)
 
+    def max_over_ranks(self, value: float, device=None) -> float:
+        """Maximum of a host value over the ranks (timing brackets)."""
+        if self.world_size == 1:
+            return float(value)
+        on = device if (self.backend != "gloo" and device is not None) else "cpu"
+        t = torch.tensor([value], dtype=torch.float64, device=on)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        return float(t.item())
+
     # -- per step, on the tensors' device and stream -------------------------------------
     def all_reduce_sum(self, t: torch.Tensor) -> None:
         """In-place sum over ranks (the dot all-reduce; 1..k scalars)."""
-        if self.world_size > 1:
-            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        if self.world_size == 1:
+            return
+        if self._staged(t):
+            host = t.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+            t.copy_(host)
+            return
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
 
     def exchange(self, sends: Sequence[Tuple[int, torch.Tensor]],
                  recvs: Sequence[Tuple[int, torch.Tensor]]) -> None:
@@ -100,13 +125,23 @@ class Communicator:
         pair agree on the order of the operations between them."""
         if self.world_size == 1 or (not sends and not recvs):
             return
+        recvs = sorted(recvs, key=lambda it: it[0])
+        sends = sorted(sends, key=lambda it: it[0])
+        staged = any(self._staged(t) for _, t in list(recvs) + list(sends))
+        if staged:  # .cpu() synchronises with the stream that produced the data
+            landing = [(peer, t, torch.empty(t.shape, dtype=t.dtype)) for peer, t in recvs]
+            recvs = [(peer, host) for peer, _, host in landing]
+            sends = [(peer, t.cpu()) for peer, t in sends]
         ops = []
-        for peer, t in sorted(recvs, key=lambda it: it[0]):
+        for peer, t in recvs:
             ops.append(dist.P2POp(dist.irecv, t, self._global_rank(peer), group=self.group))
-        for peer, t in sorted(sends, key=lambda it: it[0]):
+        for peer, t in sends:
             ops.append(dist.P2POp(dist.isend, t, self._global_rank(peer), group=self.group))
         for work in dist.batch_isend_irecv(ops):
             work.wait()
+        if staged:
+            for _, t, host in landing:
+                t.copy_(host)
 
     def _global_rank(self, group_rank: int) -> int:
         if self.group is None:

@@ -1,0 +1,65 @@
+"""The multi-rank path on real kernels: two ranks share the one GPU of the test machine and
+exchange halos / dot partials over gloo staged through host memory (RCCL refuses two ranks on
+one device, so the nccl transport itself cannot be exercised on a one-GPU box).  The plan
+arithmetic, halo placement, shard generators and reductions are the ones the 8-GPU job uses."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+
+
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _env(extra):
+    env = dict(os.environ)
+    env.update({"MASTER_ADDR": "127.0.0.1", "LSK_DIST_BACKEND": "gloo", "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    env.update(extra)
+    return env
+
+
+def test_solvers_two_ranks_one_gpu():
+    port = str(_free_port())
+    procs = [subprocess.Popen([sys.executable, "-u", os.path.join(HERE, "two_rank_worker.py")],
+                              env=_env({"MASTER_PORT": port, "WORLD_SIZE": "2", "RANK": str(r), "LOCAL_RANK": str(r)}),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=240)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(out)
+    for r, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, f"rank {r}:\n{out[-3000:]}"
+        assert f"rank {r} OK" in out
+
+
+def test_bench_contract_two_ranks_one_gpu():
+    """bench.py under the driver's launch line for N = 2 (small grid): one JSON line from rank 0
+    with the aggregate metric, strong scaling, no cpu_baseline."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--grid", "48"]
+    res = subprocess.run(cmd, env=_env({}), capture_output=True, text=True, timeout=400, cwd=REPO)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 4 and line["warmup"] == 2
+    assert line["scaling"] == "strong" and line["unit"] == "iters/s" and line["value"] > 0
+    assert line["config"]["pieces"] == 2 and "cpu_baseline" not in line
+    assert set(line["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}

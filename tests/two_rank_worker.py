@@ -1,0 +1,55 @@
+"""Worker of test_gpu_two_ranks.py: one rank of a 2-rank job whose ranks share cuda:0 and talk
+over gloo with host staging.  Runs CG (CSR, two coupled spaces), BiCGStab (COO) and GMRES (CSR)
+on the HIP backend and compares every rank's view with the CPU oracle."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+
+import host_cases as hc  # noqa: E402
+from oracle import solvers as S  # noqa: E402
+
+from legionsolvers_amd import BiCGStabSolver, CGSolver, Context, GMRESSolver  # noqa: E402
+
+
+def main():
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo")
+    ctx = Context(torch.device("cuda", 0))
+    assert ctx.world_size == 2 and ctx.comm.backend == "gloo"
+    for solver_name, kind, pieces in (("cg", "csr", 4), ("bicgstab", "coo", 2), ("gmres", "csr", 6), ("cg", "coo", 2)):
+        print(f"rank {ctx.rank} case {solver_name} {kind} pieces={pieces}", flush=True)
+        rects, row, col, val, n = hc.stencil_problem(4, (12, 10, 14), np.float64)
+        rhs = np.random.default_rng(41).standard_normal(n)
+        spaces = 2 if solver_name == "cg" else 1
+        opl = hc.oracle_planner(kind, rects, row, col, val, n, pieces, np.float64, rhs, spaces)
+        mpl = hc.mirror_planner(ctx, kind, rects, row, col, val, n, pieces, np.float64, rhs, spaces)
+        if solver_name == "cg":
+            so, sm, steps = S.CGSolver(opl), CGSolver(mpl), 8
+        elif solver_name == "bicgstab":
+            so, sm, steps = S.BiCGStabSolver(opl), BiCGStabSolver(mpl), 5
+        else:
+            so, sm, steps = S.GMRESSolver(opl, 5), GMRESSolver(mpl, 5), 2
+        for _ in range(steps):
+            so.step()
+            sm.step()
+        if solver_name == "cg":
+            np.testing.assert_allclose([s.get_value() for s in sm.residual_norm_squared],
+                                       [float(v) for v in so.residual_norm_squared], rtol=1e-10)
+        want = opl.get_vector(0, spaces - 1)
+        got = hc.gather_vector(ctx, mpl.get_vector(0, spaces - 1))
+        assert got.shape == want.shape
+        assert np.abs(got - want).max() <= 1e-9 * np.abs(want).max(), (solver_name, kind)
+    dist.barrier()
+    dist.destroy_process_group()
+    print(f"rank {ctx.rank} OK", flush=True)
+
+
+if __name__ == "__main__":
+    main()
