@@ -213,3 +213,55 @@ def test_two_rank_gloo_matches_oracle(tmp_path, krylov_golden):
     so.step()
     so.step()
     np.testing.assert_allclose(res["gmres_sol"], opl.get_vector(0, 0), rtol=1e-9, atol=1e-12)
+
+
+# ------------------------------------------------------------------ eight gloo ranks -------
+
+def _worker8(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ctx = Context(backend=OracleBackend())
+        results = {}
+        # BenchmarkStencil's layout, one row block per rank.  (16, 8, 8): two grid planes per
+        # rank, halos from the two neighbours; (4, 8, 8): half a plane per rank, so the halo
+        # (up to 73 cells) reaches three ranks away on each side.
+        for extent in ((16, 8, 8), (4, 8, 8)):
+            rects, row, col, val, n = hc.stencil_problem(4, extent)
+            pl = hc.mirror_planner(ctx, "csr", rects, row, col, val, n, world, np.float64)
+            plan = pl.row_partitioned_matrices[0].plan
+            per = n // world
+            mine = col[rects[rank * per, 0]:rects[(rank + 1) * per - 1, 1] + 1]
+            want_peers = [q for q in range(int(mine.min()) // per, int(mine.max()) // per + 1) if q != rank]
+            if extent[0] == 16:
+                assert want_peers == [q for q in (rank - 1, rank + 1) if 0 <= q < world]
+            elif 2 <= rank <= 5:
+                assert max(abs(q - rank) for q in want_peers) >= 2
+            assert sorted(t.peer for t in plan.recvs) == want_peers, (rank, plan.recvs)
+            assert sorted(t.peer for t in plan.sends) == want_peers, (rank, plan.sends)
+            solver = CGSolver(pl)
+            for _ in range(12):
+                solver.step()
+            results[f"cg_{extent[0]}"] = [s.get_value() for s in solver.residual_norm_squared]
+            results[f"sol_{extent[0]}"] = hc.gather_vector(ctx, pl.get_vector(0, 0))
+        if rank == 0:
+            torch.save(results, os.path.join(out_dir, "results8.pt"))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_eight_rank_gloo_matches_oracle(tmp_path):
+    """The 8-rank job's host logic (one row block per rank, halo plan, halo placement, dot
+    all-reduce) on CPU tensors, against the oracle with 8 pieces."""
+    mp.spawn(_worker8, args=(8, _free_port(), str(tmp_path)), nprocs=8, join=True)
+    res = torch.load(os.path.join(tmp_path, "results8.pt"), weights_only=False)
+    for extent in ((16, 8, 8), (4, 8, 8)):
+        rects, row, col, val, n = hc.stencil_problem(4, extent)
+        opl = hc.oracle_planner("csr", rects, row, col, val, n, 8, np.float64)
+        so = S.CGSolver(opl)
+        for _ in range(12):
+            so.step()
+        np.testing.assert_allclose(res[f"cg_{extent[0]}"], [float(v) for v in so.residual_norm_squared], rtol=1e-12)
+        np.testing.assert_allclose(res[f"sol_{extent[0]}"], opl.get_vector(0, 0), rtol=1e-10, atol=1e-13)
