@@ -131,7 +131,7 @@ def main():
     two_system = max(args.steps // 5, 2) / seconds2
 
     line = {
-        "metric": "CG iters/sec (fp64) on 3D 27-pt stencil 512^3, single system",
+        "metric": f"CG iters/sec (fp64) on 3D 27-pt stencil {n1}^3, single system",
         "value": iters_per_s,
         "unit": "iters/s",
         "n_gpus": world,

@@ -36,6 +36,16 @@ def _init(gpu_ctx):
     return gpu_ctx
 
 
+@pytest.fixture(params=[1, 0], ids=["wave-tiles", "workgroup-tiles"])
+def csr_variant(request):
+    """All forms of the CSR kernel (option csr.variant); the default is restored afterwards."""
+    default = ctypes.c_int(0)
+    _lib.call("lsk_get_option", b"csr.variant", ctypes.byref(default))
+    _lib.call("lsk_set_option", b"csr.variant", request.param)
+    yield request.param
+    _lib.call("lsk_set_option", b"csr.variant", default.value)
+
+
 def csr_case(suf, rects, k_base, col, val, x, x_lo, x_hi, beta=0, y0=None, tag=""):
     """Run lsk_csr_spmv on the given piece and compare with the oracle."""
     npdt, tdt, tol = DT[suf]
@@ -60,7 +70,7 @@ def csr_case(suf, rects, k_base, col, val, x, x_lo, x_hi, beta=0, y0=None, tag="
 @pytest.mark.parametrize("suf", ["f32", "f64"])
 @pytest.mark.parametrize("flag,extent", [(1, (1000,)), (2, (37, 41)), (3, (9, 11, 13)), (4, (12, 10, 14)),
                                          (4, (3, 3, 3)), (1, (1,)), (1, (2,))])
-def test_csr_spmv_stencils(suf, flag, extent):
+def test_csr_spmv_stencils(suf, flag, extent, csr_variant):
     npdt = DT[suf][0]
     offs, cfs = oracle.benchmark_stencil_offsets(flag)
     rects, _, col, val = oracle.linearized_stencil(extent, offs, cfs, dtype=npdt)
@@ -72,7 +82,7 @@ def test_csr_spmv_stencils(suf, flag, extent):
 
 
 @pytest.mark.parametrize("suf", ["f32", "f64"])
-def test_csr_spmv_pieces_and_ghost_windows(suf):
+def test_csr_spmv_pieces_and_ghost_windows(suf, csr_variant):
     """Row-block pieces of a larger matrix: k_base != 0, odd first entry (so the 16-byte
     loads start off-phase), x handed over as the ghost window only."""
     npdt = DT[suf][0]
@@ -95,7 +105,7 @@ def test_csr_spmv_pieces_and_ghost_windows(suf):
 
 
 @pytest.mark.parametrize("suf", ["f32", "f64"])
-def test_csr_spmv_general_rects(suf):
+def test_csr_spmv_general_rects(suf, csr_variant):
     """Rects that do not tile the piece front to back (gaps, permuted rows, empty rows, rows
     longer than the LDS buffer): the per-wave path, same results."""
     npdt = DT[suf][0]
@@ -134,7 +144,31 @@ def test_csr_spmv_general_rects(suf):
 
 
 @pytest.mark.parametrize("suf", ["f32", "f64"])
-def test_csr_spmv_misaligned_arrays(suf):
+@pytest.mark.parametrize("flag,extent", [(4, (64, 64, 72)), (3, (100, 100, 101)), (2, (1500, 700))])
+def test_csr_spmv_many_tiles(suf, flag, extent, csr_variant):
+    """Large pieces (tens of thousands of tiles), some tiles irregular in the middle of the sweep
+    (rows with a gap, which take the per-row path), and a piece that starts at an odd entry."""
+    npdt = DT[suf][0]
+    offs, cfs = oracle.benchmark_stencil_offsets(flag)
+    rects, _, col, val = oracle.linearized_stencil(extent, offs, cfs, dtype=npdt)
+    n = rects.shape[0]
+    x = np.random.default_rng(28).standard_normal(n).astype(npdt)
+    csr_case(suf, rects, 0, col, val, x, 0, n - 1, tag=f"many-tiles{flag}{extent}")
+    gap = rects.copy()
+    for r in range(1000, n, 50021):  # every so often a row drops its last entry
+        gap[r, 1] -= 1
+    csr_case(suf, gap, 0, col, val, x, 0, n - 1, tag="many-tiles-gaps")
+    r0 = 12345
+    piece = np.ascontiguousarray(rects[r0:])
+    k_lo = int(piece[0, 0])
+    c, v = np.ascontiguousarray(col[k_lo:]), np.ascontiguousarray(val[k_lo:])
+    g_lo, g_hi = int(c.min()), int(c.max())
+    csr_case(suf, piece, k_lo, c, v, np.ascontiguousarray(x[g_lo:g_hi + 1]), g_lo, g_hi, beta=1,
+             y0=np.random.default_rng(29).standard_normal(n - r0).astype(npdt), tag=f"many-tiles-piece k_lo={k_lo}")
+
+
+@pytest.mark.parametrize("suf", ["f32", "f64"])
+def test_csr_spmv_misaligned_arrays(suf, csr_variant):
     """col / val handed over at addresses that are not 16-byte aligned."""
     npdt, tdt, tol = DT[suf]
     offs, cfs = oracle.benchmark_stencil_offsets(3)

@@ -139,7 +139,7 @@ def main():
                                      [int(v) for v in args.remap.split(",")],
                                      [int(v) for v in args.logrw.split(",")],
                                      [int(v) for v in args.exp.split(",")]))
-    configs = [c for c in configs if not (c[0] == 0 and (c[1] == 1 or c[3] != -1 or c[4] != 0))]  # variant 0: no NT / RW forms
+    configs = [c for c in configs if not (c[0] != 1 and (c[1] == 1 or c[2] != 0 or c[3] != -1 or c[4] != 0))]  # NT / remap / RW forms: variant 1 only
     times = {c: [] for c in configs}
     ref = None
     for c in configs:  # results agree across forms
