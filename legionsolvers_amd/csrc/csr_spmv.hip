@@ -26,7 +26,7 @@ namespace {
 using lsk::kBlock;
 
 template <typename T> struct Cfg;
-// Products kept per workgroup: 30 KiB of LDS (+1 KiB of row offsets), so five workgroups
+// Products kept per workgroup: 30 KiB of LDS (+1 KiB of row offsets), so up to five workgroups
 // (20 waves) fit the 160 KiB of a CU.
 template <> struct Cfg<double> { static constexpr int CAP = 3840; static constexpr int U = 2; using V = double2; };
 template <> struct Cfg<float> { static constexpr int CAP = 7680; static constexpr int U = 4; using V = float4; };
@@ -291,10 +291,11 @@ __device__ __forceinline__ void stream_chunk(int ubase, int lane, int nfull,
 // up three others.  Per tile:
 //   1. lanes < RW load the rects; the tile takes the streaming path when its rows tile one
 //      contiguous, buffer-sized run of entries (wave vote), else rows are walked one by one;
-//   2. the run is read in chunks of up to 4 aligned 16-byte units per lane (stream_chunk); the
-//      last chunk is sized to what is left, so few lanes idle;
+//   2. the run is read in chunks of up to KMAX aligned 16-byte units per lane (stream_chunk),
+//      sized to what is left, so few lanes idle; a tile that fits one chunk has all its loads in
+//      flight at once;
 //   3. 64/RW lanes per row add the row's products from LDS; one lane per row stores y.
-template <typename T, int LOG_RW, bool NT>
+template <typename T, int LOG_RW, bool NT, int KMAX>
 __global__ __launch_bounds__(kBlock) void csr_spmv_wave_kernel(
     int64_t rows, const Rect *__restrict__ rects, int64_t k_base, int64_t nnz,
     const int64_t *__restrict__ col, const T *__restrict__ val, const T *__restrict__ x,
@@ -345,16 +346,26 @@ __global__ __launch_bounds__(kBlock) void csr_spmv_wave_kernel(
     const int tail0 = head + nfull * U; // first entry after the whole units
     const T *vbody = valb + head;
     const int64_t *cbody = colb + head;
-    for (int ubase = 0; ubase < nfull; ubase += lsk::kWave * 4) {
+    // Up to KMAX units per lane in one go.  KMAX = 8 holds a whole tile of 32 rows x 27 entries
+    // (7 units): all its col/val loads are in flight together, then all its gathers; two rounds
+    // of 4 units cost 13 % at the headline size.  The instance with KMAX = 4 needs 68 instead
+    // of 103 vector registers (5 instead of 4 waves per SIMD), which is worth 2-7 % on pieces
+    // whose tiles fit 4 units anyway; the launcher picks by mean tile size.
+    for (int ubase = 0; ubase < nfull; ubase += lsk::kWave * KMAX) {
         const int left = nfull - ubase; // wave-uniform
-        if (left > 3 * lsk::kWave)
-            stream_chunk<T, 4, NT>(ubase, lane, nfull, vbody, cbody, x, x_lo, x_hi, sp + head);
-        else if (left > 2 * lsk::kWave)
-            stream_chunk<T, 3, NT>(ubase, lane, nfull, vbody, cbody, x, x_lo, x_hi, sp + head);
-        else if (left > lsk::kWave)
-            stream_chunk<T, 2, NT>(ubase, lane, nfull, vbody, cbody, x, x_lo, x_hi, sp + head);
-        else
-            stream_chunk<T, 1, NT>(ubase, lane, nfull, vbody, cbody, x, x_lo, x_hi, sp + head);
+#define LSK_CHUNK(K)                                                                              \
+    stream_chunk<T, K, NT>(ubase, lane, nfull, vbody, cbody, x, x_lo, x_hi, sp + head)
+        if constexpr (KMAX == 8) {
+            if (left > 7 * lsk::kWave) { LSK_CHUNK(8); continue; }
+            if (left > 6 * lsk::kWave) { LSK_CHUNK(7); continue; }
+            if (left > 5 * lsk::kWave) { LSK_CHUNK(6); continue; }
+            if (left > 4 * lsk::kWave) { LSK_CHUNK(5); continue; }
+        }
+        if (left > 3 * lsk::kWave) LSK_CHUNK(4);
+        else if (left > 2 * lsk::kWave) LSK_CHUNK(3);
+        else if (left > lsk::kWave) LSK_CHUNK(2);
+        else LSK_CHUNK(1);
+#undef LSK_CHUNK
     }
     {   // head and tail entries (those outside the whole units), one per lane
         const int ntail = nnzw - tail0;
@@ -440,14 +451,21 @@ int launch_csr_spmv(const char *name, int64_t rows, int64_t nnz, const int64_t *
         if (tune.csr_log_rw >= 0 && tune.csr_log_rw < log_rw) log_rw = tune.csr_log_rw; // only smaller tiles fit
         const int64_t blocks_w = lsk::ceil_div(rows, int64_t(4) << log_rw);
         if (blocks_w > 0x7fffffffLL) return lsk::fail(LSK_ERR_UNSUPPORTED, "%s: too many rows", name);
+        // Units per lane a mean tile needs: more than 4 -> the 8-unit instance.
+        const double units = 1.05 * mean * double(1 << log_rw) / double(lsk::kWave * Cfg<T>::U);
+        const bool wide = tune.csr_max_units == 0 ? units > 4.0 : tune.csr_max_units == 8;
+#define LSK_CSRW_LAUNCH(L, NT, KMAX)                                                              \
+    csr_spmv_wave_kernel<T, L, NT, KMAX><<<unsigned(blocks_w), kBlock, 0, s>>>(                   \
+        rows, rc, k_base, nnz, col, val, x, x_lo, x_hi, y, beta, tune.xcd_remap)
 #define LSK_CSRW_CASE(L)                                                                          \
     case L:                                                                                       \
-        if (tune.csr_nontemporal)                                                                   \
-            csr_spmv_wave_kernel<T, L, true><<<unsigned(blocks_w), kBlock, 0, s>>>(               \
-                rows, rc, k_base, nnz, col, val, x, x_lo, x_hi, y, beta, tune.xcd_remap);          \
-        else                                                                                      \
-            csr_spmv_wave_kernel<T, L, false><<<unsigned(blocks_w), kBlock, 0, s>>>(              \
-                rows, rc, k_base, nnz, col, val, x, x_lo, x_hi, y, beta, tune.xcd_remap);          \
+        if (tune.csr_nontemporal) {                                                               \
+            if (wide) LSK_CSRW_LAUNCH(L, true, 8);                                                \
+            else LSK_CSRW_LAUNCH(L, true, 4);                                                     \
+        } else {                                                                                  \
+            if (wide) LSK_CSRW_LAUNCH(L, false, 8);                                               \
+            else LSK_CSRW_LAUNCH(L, false, 4);                                                    \
+        }                                                                                         \
         break;
         switch (log_rw) {
             LSK_CSRW_CASE(0)
@@ -458,6 +476,7 @@ int launch_csr_spmv(const char *name, int64_t rows, int64_t nnz, const int64_t *
             LSK_CSRW_CASE(5)
             LSK_CSRW_CASE(6)
         }
+#undef LSK_CSRW_LAUNCH
 #undef LSK_CSRW_CASE
         LSK_LAUNCH_CHECK();
         return LSK_OK;

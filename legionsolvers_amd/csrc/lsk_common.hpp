@@ -55,6 +55,7 @@ struct Options {
     int csr_nontemporal = 0; // stream col/val with nontemporal loads
     int xcd_remap = 0;       // tiles per XCD chunk (0 off, < 0 one contiguous eighth per XCD)
     int csr_log_rw = -1;     // log2 rows per wave for the wave-tile form; -1 = from the mean row length
+    int csr_max_units = 0;   // 16-byte units per lane in flight in the wave-tile form: 0 = by tile size, 4 or 8
     int blas1_form = 1;      // 0: grid-strided accesses, 1: contiguous chunk per workgroup
     int coo_variant = 1;     // 0: workgroup chunks through LDS, 1: wave-wide segmented scan
 };

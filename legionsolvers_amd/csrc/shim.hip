@@ -45,6 +45,10 @@ Options &options() {
         if (const char *e = std::getenv("LSK_CSR_VARIANT")) o.csr_variant = std::atoi(e);
         if (const char *e = std::getenv("LSK_CSR_NT")) o.csr_nontemporal = std::atoi(e);
         if (const char *e = std::getenv("LSK_XCD_REMAP")) o.xcd_remap = std::atoi(e);
+        if (const char *e = std::getenv("LSK_CSR_MAX_UNITS")) {
+            const int v = std::atoi(e);
+            if (v == 0 || v == 4 || v == 8) o.csr_max_units = v;
+        }
         if (const char *e = std::getenv("LSK_COO_VARIANT")) o.coo_variant = std::atoi(e) != 0;
         return o;
     }();
@@ -89,6 +93,9 @@ int lsk_set_option(const char *key, int value) {
     } else if (!std::strcmp(key, "csr.log_rows_per_wave")) {
         if (value < -1 || value > 6) return lsk::fail(LSK_ERR_ARG, "csr.log_rows_per_wave must be -1..6");
         o.csr_log_rw = value;
+    } else if (!std::strcmp(key, "csr.max_units")) {
+        if (value != 0 && value != 4 && value != 8) return lsk::fail(LSK_ERR_ARG, "csr.max_units must be 0, 4 or 8");
+        o.csr_max_units = value;
     } else if (!std::strcmp(key, "blas1.form")) {
         o.blas1_form = value != 0;
     } else if (!std::strcmp(key, "coo.variant")) {
@@ -107,6 +114,7 @@ int lsk_get_option(const char *key, int *value) {
     else if (!std::strcmp(key, "csr.nontemporal")) *value = o.csr_nontemporal;
     else if (!std::strcmp(key, "xcd_remap")) *value = o.xcd_remap;
     else if (!std::strcmp(key, "csr.log_rows_per_wave")) *value = o.csr_log_rw;
+    else if (!std::strcmp(key, "csr.max_units")) *value = o.csr_max_units;
     else if (!std::strcmp(key, "blas1.form")) *value = o.blas1_form;
     else if (!std::strcmp(key, "coo.variant")) *value = o.coo_variant;
     else return lsk::fail(LSK_ERR_ARG, "lsk_get_option: unknown key '%s'", key);

@@ -105,7 +105,7 @@ def main():
     ap.add_argument("--nt", default="0,1")
     ap.add_argument("--remap", default="0,1")
     ap.add_argument("--logrw", default="-1")
-    ap.add_argument("--exp", default="0")
+    ap.add_argument("--kmax", default="0", help="csr.max_units values (0 = automatic, 4, 8)")
     ap.add_argument("--blas1", action="store_true")
     ap.add_argument("--coo", action="store_true", help="time the COO kernel forms instead (stencil at --n)")
     ap.add_argument("--coo-random-rows", type=int, default=0,
@@ -138,8 +138,8 @@ def main():
                                      [int(v) for v in args.nt.split(",")],
                                      [int(v) for v in args.remap.split(",")],
                                      [int(v) for v in args.logrw.split(",")],
-                                     [int(v) for v in args.exp.split(",")]))
-    configs = [c for c in configs if not (c[0] != 1 and (c[1] == 1 or c[2] != 0 or c[3] != -1 or c[4] != 0))]  # NT / remap / RW forms: variant 1 only
+                                     [int(v) for v in args.kmax.split(",")]))
+    configs = [c for c in configs if not (c[0] != 1 and (c[1] == 1 or c[3] != -1 or c[4] != 0))]  # NT / RW / units forms: variant 1 only
     times = {c: [] for c in configs}
     ref = None
     for c in configs:  # results agree across forms
@@ -147,6 +147,7 @@ def main():
         lib.lsk_set_option(b"csr.nontemporal", c[1])
         lib.lsk_set_option(b"xcd_remap", c[2])
         lib.lsk_set_option(b"csr.log_rows_per_wave", c[3])
+        lib.lsk_set_option(b"csr.max_units", c[4])
         spmv()
         got = y.owned.clone()
         if ref is None:
@@ -164,9 +165,10 @@ def main():
             lib.lsk_set_option(b"csr.nontemporal", c[1])
             lib.lsk_set_option(b"xcd_remap", c[2])
             lib.lsk_set_option(b"csr.log_rows_per_wave", c[3])
+            lib.lsk_set_option(b"csr.max_units", c[4])
             spmv()
             times[c].append(timed(spmv, args.reps))
-    print(f"{'variant':>8} {'nt':>3} {'remap':>5} {'logrw':>5} {'exp':>3} {'median ms':>10} {'min ms':>8} {'GB/s(med)':>10} {'frac 8TB/s':>10}")
+    print(f"{'variant':>8} {'nt':>3} {'remap':>5} {'logrw':>5} {'kmx':>3} {'median ms':>10} {'min ms':>8} {'GB/s(med)':>10} {'frac 8TB/s':>10}")
     for c in configs:
         med, mn = statistics.median(times[c]), min(times[c])
         print("   rounds:", " ".join(f"{t:.2f}" for t in times[c]))

@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""HBM-side traffic of one CSR SpMV launch from the two rocprofv3 --pmc passes over
+tools/pmc_spmv.py (FETCH_SIZE and WRITE_SIZE, each its own run):
+
+    python tools/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json>
+
+FETCH_SIZE is reported in KiB and tallies a 128-byte read request as 64 bytes on gfx950; the dot
+product in the same run (2 * rows * 8 bytes read, nothing else) calibrates that factor."""
+import csv
+import json
+import sys
+
+
+def means(path, counter):
+    acc = {}
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] != counter:
+            continue
+        name = r["Kernel_Name"]
+        key = "spmv" if "csr_spmv" in name else "dot" if "dot_kernel" in name else None
+        if key:
+            acc.setdefault(key, []).append(float(r["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in acc.items()}
+
+
+def main():
+    fetch, write, out = sys.argv[1:4]
+    rows, nnz = 512 ** 3, (3 * 512 - 2) ** 3
+    f, w = means(fetch, "FETCH_SIZE"), means(write, "WRITE_SIZE")
+    dot_true = 2 * rows * 8
+    ratio = dot_true / (f["dot"] * 1024)
+    factor = 2 if 1.9 < ratio < 2.1 else 1
+    traffic = factor * f["spmv"] * 1024 + w["spmv"] * 1024
+    algo = nnz * 16 + rows * 32
+    json.dump({
+        "workload": "csr_spmv f64, 27-pt 512^3, 1 GPU",
+        "FETCH_SIZE_KB_mean": f["spmv"], "WRITE_SIZE_KB_mean": w["spmv"],
+        "calibration": {"kernel": f"dot_kernel f64 (reads 2*rows*8 = {dot_true} B)",
+                        "FETCH_SIZE_KB_mean": f["dot"], "ratio_true_over_reported": ratio},
+        "correction": f"bytes = {factor}*FETCH_SIZE*1024 + WRITE_SIZE*1024 (factor from the calibration)",
+        "bytes_per_launch": int(round(traffic)), "algorithmic_bytes_per_launch": algo,
+        "ratio_traffic_over_algorithmic": traffic / algo,
+    }, open(out, "w"), indent=1)
+    print(open(out).read())
+
+
+if __name__ == "__main__":
+    main()
