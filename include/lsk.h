@@ -57,7 +57,7 @@ void lsk_set_abort_on_error(int enable);
  * "csr.nontemporal" (0 | 1: stream col/val past the caches, default 0), "xcd_remap" (c > 0:
  * each XCD takes runs of c consecutive tiles; c < 0: one contiguous eighth of the tiles per
  * XCD; 0: workgroup id = tile id, the default), "csr.log_rows_per_wave" (-1 = from
- * the mean row length, else 0..6), "csr.max_units" (16-byte units per lane the wave-tile form
+ * the mean row length, else 0..8), "csr.max_units" (16-byte units per lane the wave-tile form
  * keeps in flight: 0 = chosen from the mean tile size, 4 or 8), "blas1.form" (0 grid-strided | 1 contiguous chunk per
  * workgroup, default 1), "coo.variant" (0 workgroup chunks through LDS | 1 wave-wide segmented
  * scan, default 1).  No counterpart in the reference

@@ -40,6 +40,9 @@ struct Rect { long long lo, hi; };
 typedef double d2_t __attribute__((ext_vector_type(2)));
 typedef float f4_t __attribute__((ext_vector_type(4)));
 typedef long long ll2_t __attribute__((ext_vector_type(2)));
+// The same, promised only 8-byte alignment: col pairs sit at the val units' entries, whose
+// 16-byte phase may differ from the col array's.
+typedef ll2_t ll2_a8_t __attribute__((aligned(8)));
 template <typename T> struct Native;
 template <> struct Native<double> { using V = d2_t; };
 template <> struct Native<float> { using V = f4_t; };
@@ -48,6 +51,12 @@ template <bool NT, typename VT>
 __device__ __forceinline__ VT vload(const VT *p) {
     if constexpr (NT) return __builtin_nontemporal_load(p);
     else return *p;
+}
+
+template <bool NT> __device__ __forceinline__ ll2_t load_col_pair(const int64_t *p) {
+    const ll2_a8_t *q = reinterpret_cast<const ll2_a8_t *>(p);
+    if constexpr (NT) return __builtin_nontemporal_load(q);
+    else return *q;
 }
 
 template <typename T> __device__ __forceinline__ T vget(const double2 &v, int i) { return i == 0 ? v.x : v.y; }
@@ -260,7 +269,7 @@ __device__ __forceinline__ void stream_chunk(int ubase, int lane, int nfull,
         vv[k] = vload<NT>(reinterpret_cast<const V *>(vbody) + uc);
 #pragma unroll
         for (int p = 0; p < U; p += 2) {
-            const ll2_t c2 = vload<NT>(reinterpret_cast<const ll2_t *>(cbody + uc * U + p));
+            const ll2_t c2 = load_col_pair<NT>(cbody + uc * U + p);
             cc[k][p] = c2.x;
             cc[k][p + 1] = c2.y;
         }
@@ -286,71 +295,26 @@ __device__ __forceinline__ void stream_chunk(int ubase, int lane, int nfull,
     }
 }
 
-// Wave-tile CSR SpMV: every wave owns RW = 1 << LOG_RW consecutive rows and never meets
-// the other waves of its workgroup (no s_barrier), so a wave that waits on HBM never holds
-// up three others.  Per tile:
-//   1. lanes < RW load the rects; the tile takes the streaming path when its rows tile one
-//      contiguous, buffer-sized run of entries (wave vote), else rows are walked one by one;
-//   2. the run is read in chunks of up to KMAX aligned 16-byte units per lane (stream_chunk),
-//      sized to what is left, so few lanes idle; a tile that fits one chunk has all its loads in
-//      flight at once;
-//   3. 64/RW lanes per row add the row's products from LDS; one lane per row stores y.
-template <typename T, int LOG_RW, bool NT, int KMAX>
-__global__ __launch_bounds__(kBlock) void csr_spmv_wave_kernel(
-    int64_t rows, const Rect *__restrict__ rects, int64_t k_base, int64_t nnz,
-    const int64_t *__restrict__ col, const T *__restrict__ val, const T *__restrict__ x,
-    int64_t x_lo, int64_t x_hi, T *__restrict__ y, int beta, int remap) {
-    constexpr int RW = 1 << LOG_RW;
-    constexpr int GW = lsk::kWave / RW;
-    constexpr int WAVES = kBlock / lsk::kWave;
-    constexpr int CAPW = Cfg<T>::CAP / WAVES;
+// The streaming phase of one batch of consecutive rows: n entries starting at valb / colb go as
+// products into sp[0, n).  Units are U consecutive entries whose val word is 16-byte aligned;
+// the entries before the first and after the last whole unit are handled one per lane.
+template <typename T, bool NT, int KMAX>
+__device__ __forceinline__ void stream_batch(int lane, int n, const T *__restrict__ valb,
+                                             const int64_t *__restrict__ colb,
+                                             const T *__restrict__ x, int64_t x_lo, int64_t x_hi,
+                                             T *__restrict__ sp) {
     constexpr int U = Cfg<T>::U;
-
-    __shared__ T s_prod[WAVES][CAPW];
-
-    const int wave = threadIdx.x / lsk::kWave, lane = threadIdx.x % lsk::kWave;
-    const unsigned tile = lsk::xcd_remap(blockIdx.x, gridDim.x, remap);
-    const int64_t r0 = (int64_t(tile) * WAVES + wave) * RW;
-    if (r0 >= rows) return; // wave-uniform; nothing below synchronises across waves
-    const int nr = static_cast<int>(rows - r0 < RW ? rows - r0 : RW);
-    T *sp = s_prod[wave];
-
-    // ---- 1. rects ------------------------------------------------------------------------
-    Rect rc{0, -1};
-    if (lane < nr) rc = rects[r0 + lane];
-    const long long k0 = __shfl(rc.lo, 0, lsk::kWave);
-    const long long rel_lo = rc.lo - k0, rel_end = rc.hi + 1 - k0;
-    const long long next_lo = __shfl_down(rel_lo, 1, lsk::kWave);
-    bool ok = true;
-    if (lane < nr) {
-        ok = rel_lo >= 0 && rel_end >= rel_lo && rel_end <= CAPW && k0 >= k_base &&
-             rc.hi - k_base < nnz;
-        if (lane < nr - 1) ok = ok && (next_lo == rel_end);
-    }
-    const int nnzw = static_cast<int>(__shfl(rel_end, nr - 1, lsk::kWave));
-    const int64_t *colb = col + (k0 - k_base);
-    const T *valb = val + (k0 - k_base);
-    // Units are U consecutive entries whose val word is 16-byte aligned; `head` entries
-    // precede the first whole unit.  col pairs must be 16-byte aligned at the same entries.
     const int shift = static_cast<int>((reinterpret_cast<uintptr_t>(valb) / sizeof(T)) % U);
     const int head0 = (U - shift) % U;
-    const bool col_pairs = ((reinterpret_cast<uintptr_t>(colb) / 8 + head0) % 2) == 0;
-    if (!__all(ok) || !col_pairs) {
-        wave_rows_direct<T>(nr, rects + r0, k_base, nnz, col, val, x, x_lo, x_hi, y + r0, beta);
-        return;
-    }
-
-    // ---- 2. stream --------------------------------------------------------------------------
-    const int head = head0 < nnzw ? head0 : nnzw;
-    const int nfull = (nnzw - head) / U;
+    const int head = head0 < n ? head0 : n;
+    const int nfull = (n - head) / U;
     const int tail0 = head + nfull * U; // first entry after the whole units
     const T *vbody = valb + head;
     const int64_t *cbody = colb + head;
     // Up to KMAX units per lane in one go.  KMAX = 8 holds a whole tile of 32 rows x 27 entries
     // (7 units): all its col/val loads are in flight together, then all its gathers; two rounds
-    // of 4 units cost 13 % at the headline size.  The instance with KMAX = 4 needs 68 instead
-    // of 103 vector registers (5 instead of 4 waves per SIMD), which is worth 2-7 % on pieces
-    // whose tiles fit 4 units anyway; the launcher picks by mean tile size.
+    // of 4 units cost 13 % at that size.  The instance with KMAX = 4 needs 68 instead of 103
+    // vector registers (5 instead of 4 waves per SIMD); the launcher picks by mean tile size.
     for (int ubase = 0; ubase < nfull; ubase += lsk::kWave * KMAX) {
         const int left = nfull - ubase; // wave-uniform
 #define LSK_CHUNK(K)                                                                              \
@@ -367,42 +331,159 @@ __global__ __launch_bounds__(kBlock) void csr_spmv_wave_kernel(
         else LSK_CHUNK(1);
 #undef LSK_CHUNK
     }
-    {   // head and tail entries (those outside the whole units), one per lane
-        const int ntail = nnzw - tail0;
+    const int n_edge = head + (n - tail0);
+    if (lane < n_edge) {
         const int e = lane < head ? lane : tail0 + (lane - head);
-        if (lane < head + ntail) {
-            const long long c = colb[e];
-            const bool in = c >= x_lo && c <= x_hi;
-            sp[e] = in ? valb[e] * x[c - x_lo] : T(0);
-        }
+        const long long c = colb[e];
+        const bool in = c >= x_lo && c <= x_hi;
+        sp[e] = in ? valb[e] * x[c - x_lo] : T(0);
     }
-    wave_lds_fence();
+}
 
-    // ---- 3. fold rows ---------------------------------------------------------------------------
-    const int row = lane / GW, g = lane % GW;
-    const int e0 = static_cast<int>(__shfl(rel_lo, row, lsk::kWave));
-    const int e1 = static_cast<int>(__shfl(rel_end, row, lsk::kWave));
+// Sum of sp[e0, e1) taken in steps of `stride` from e0 + g, four LDS reads in flight; reads
+// past the end are clamped to a valid slot and dropped.
+template <typename T, int CAPW>
+__device__ __forceinline__ T fold_range(const T *__restrict__ sp, int e0, int e1, int g, int stride) {
     T acc = T(0);
-    if (row < nr) {
-        // Four LDS reads in flight per step; reads past the row are clamped and dropped.
-        for (int e = e0 + g; e < e1; e += 4 * GW) {
-            T a[4];
+    for (int e = e0 + g; e < e1; e += 4 * stride) {
+        T a[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int ek = e + k * GW;
-                a[k] = sp[ek < CAPW ? ek : CAPW - 1];
-            }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) acc += (e + k * GW < e1) ? a[k] : T(0);
+        for (int k = 0; k < 4; ++k) {
+            const int ek = e + k * stride;
+            a[k] = sp[ek < CAPW ? ek : CAPW - 1];
         }
-    }
-    if constexpr (GW > 1) {
 #pragma unroll
-        for (int off = GW / 2; off > 0; off >>= 1) acc += __shfl_xor(acc, off, lsk::kWave);
+        for (int k = 0; k < 4; ++k) acc += (e + k * stride < e1) ? a[k] : T(0);
     }
-    if (row < nr && g == 0) {
-        T *yp = y + r0 + row;
-        *yp = beta ? *yp + acc : acc;
+    return acc;
+}
+
+// Wave-tile CSR SpMV: every wave owns ROWS = 1 << LOG_ROWS consecutive rows (1..256) and never
+// meets the other waves of its workgroup (no s_barrier), so a wave that waits on HBM never holds
+// up three others.  Per tile:
+//   1. lanes load the rects, ROWS/64 per lane when ROWS > 64 (row j*64 + lane, coalesced).  If the
+//      rows do not tile one contiguous run of entries inside the piece (wave vote), they are
+//      walked one by one straight from HBM;
+//   2. otherwise the rows are taken in batches of as many consecutive rows as fit the wave's
+//      LDS buffer -- the whole tile at once in the normal case; a row that alone exceeds the
+//      buffer is walked straight from HBM.  A batch's run is read in chunks of up to KMAX aligned
+//      16-byte units per lane (stream_batch / stream_chunk);
+//   3. the rows' products are added out of LDS: 64/ROWS lanes per row when ROWS < 64, else every
+//      lane folds its own ROWS/64 rows; y is stored one lane per row.
+template <typename T, int LOG_ROWS, bool NT, int KMAX>
+__global__ __launch_bounds__(kBlock, 4) void csr_spmv_wave_kernel( // at least 4 waves per SIMD: <= 128 VGPRs
+    int64_t rows, const Rect *__restrict__ rects, int64_t k_base, int64_t nnz,
+    const int64_t *__restrict__ col, const T *__restrict__ val, const T *__restrict__ x,
+    int64_t x_lo, int64_t x_hi, T *__restrict__ y, int beta, int remap) {
+    constexpr int ROWS = 1 << LOG_ROWS;
+    constexpr int RPL = ROWS > lsk::kWave ? ROWS / lsk::kWave : 1; // rects per lane
+    constexpr int GW = ROWS < lsk::kWave ? lsk::kWave / ROWS : 1;  // lanes per row in the fold
+    constexpr int WAVES = kBlock / lsk::kWave;
+    constexpr int CAPW = Cfg<T>::CAP / WAVES;
+
+    __shared__ T s_prod[WAVES][CAPW];
+
+    const int wave = threadIdx.x / lsk::kWave, lane = threadIdx.x % lsk::kWave;
+    const unsigned tile = lsk::xcd_remap(blockIdx.x, gridDim.x, remap);
+    const int64_t r0 = (int64_t(tile) * WAVES + wave) * ROWS;
+    if (r0 >= rows) return; // wave-uniform; nothing below synchronises across waves
+    const int nr = static_cast<int>(rows - r0 < ROWS ? rows - r0 : ROWS);
+    T *sp = s_prod[wave];
+
+    // ---- 1. rects ------------------------------------------------------------------------
+    Rect rc[RPL];
+#pragma unroll
+    for (int j = 0; j < RPL; ++j) {
+        const int row = j * lsk::kWave + lane;
+        rc[j] = Rect{0, -1};
+        if (row < nr) rc[j] = rects[r0 + row];
+    }
+    const long long k0 = lsk::wave_first(rc[0].lo);
+    int rel_lo[RPL], rel_end[RPL]; // this lane's rows relative to k0 (32-bit once validated)
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < RPL; ++j) {
+        const long long lo64 = rc[j].lo - k0, end64 = rc[j].hi + 1 - k0;
+        const int row = j * lsk::kWave + lane;
+        if (row < nr)
+            ok = ok && lo64 >= 0 && end64 >= lo64 && end64 <= 0x3fffffff && k0 >= k_base && rc[j].hi - k_base < nnz;
+        rel_lo[j] = static_cast<int>(lo64);
+        rel_end[j] = static_cast<int>(end64);
+    }
+#pragma unroll
+    for (int j = 0; j < RPL; ++j) {
+        const int row = j * lsk::kWave + lane;
+        // the next row's first entry: the neighbouring lane's, or lane 0's next rect
+        int next_lo = __shfl_down(rel_lo[j], 1, lsk::kWave);
+        if constexpr (RPL > 1) {
+            const int wrap = __builtin_amdgcn_readfirstlane(rel_lo[j + 1 < RPL ? j + 1 : j]);
+            if (lane == lsk::kWave - 1) next_lo = wrap;
+        }
+        if (row < nr - 1) ok = ok && (next_lo == rel_end[j]);
+    }
+    if (!__all(ok)) {
+        wave_rows_direct<T>(nr, rects + r0, k_base, nnz, col, val, x, x_lo, x_hi, y + r0, beta);
+        return;
+    }
+    const int64_t *colb = col + (k0 - k_base);
+    const T *valb = val + (k0 - k_base);
+
+    // value of a per-row quantity at tile row q (q wave-uniform), as a wave-uniform value
+    auto at_row = [&](const int (&v)[RPL], int q) {
+        int out = 0;
+#pragma unroll
+        for (int j = 0; j < RPL; ++j) {
+            const int got = __builtin_amdgcn_readlane(v[j], q % lsk::kWave);
+            if (j == q / lsk::kWave) out = got;
+        }
+        return out;
+    };
+
+    // ---- 2./3. batches of consecutive rows that fit the buffer ---------------------------
+    for (int ra = 0; ra < nr;) {
+        const int base = at_row(rel_lo, ra);
+        int m = 0; // rows ra .. ra+m-1 fit (the condition is monotone in the row)
+#pragma unroll
+        for (int j = 0; j < RPL; ++j) {
+            const int row = j * lsk::kWave + lane;
+            const bool fits = row >= ra && row < nr && rel_end[j] - base <= CAPW;
+            m += __popcll(__ballot(fits));
+        }
+        if (m == 0) { // this row alone is longer than the buffer
+            wave_rows_direct<T>(1, rects + r0 + ra, k_base, nnz, col, val, x, x_lo, x_hi, y + r0 + ra, beta);
+            ra += 1;
+            continue;
+        }
+        const int n = at_row(rel_end, ra + m - 1) - base;
+        stream_batch<T, NT, KMAX>(lane, n, valb + base, colb + base, x, x_lo, x_hi, sp);
+        wave_lds_fence();
+        if constexpr (RPL == 1) {
+            const int row = lane / GW, g = lane % GW;
+            const int e0 = __shfl(rel_lo[0], row, lsk::kWave) - base;
+            const int e1 = __shfl(rel_end[0], row, lsk::kWave) - base;
+            const bool mine = row >= ra && row < ra + m;
+            T acc = mine ? fold_range<T, CAPW>(sp, e0, e1, g, GW) : T(0);
+            if constexpr (GW > 1) {
+#pragma unroll
+                for (int off = GW / 2; off > 0; off >>= 1) acc += __shfl_xor(acc, off, lsk::kWave);
+            }
+            if (mine && g == 0) {
+                T *yp = y + r0 + row;
+                *yp = beta ? *yp + acc : acc;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < RPL; ++j) {
+                const int row = j * lsk::kWave + lane;
+                if (row >= ra && row < ra + m) {
+                    const T acc = fold_range<T, CAPW>(sp, rel_lo[j] - base, rel_end[j] - base, 0, 1);
+                    T *yp = y + r0 + row;
+                    *yp = beta ? *yp + acc : acc;
+                }
+            }
+        }
+        ra += m;
+        if (ra < nr) wave_lds_fence(); // the next batch overwrites the buffer
     }
 }
 
@@ -444,9 +525,10 @@ int launch_csr_spmv(const char *name, int64_t rows, int64_t nnz, const int64_t *
     const lsk::Options &tune = lsk::options();
     if (tune.csr_variant == 1) {
         // Rows per wave: as many as keep the tile's products inside the wave's quarter of
-        // the LDS buffer at the piece's mean row length, a power of two in 1..64.
-        const double want_w = mean > 0.0 ? 0.9 * (Cfg<T>::CAP / 4) / mean : 64.0;
-        int log_rw = 6;
+        // the LDS buffer at the piece's mean row length, a power of two in 1..256.  (A tile that
+        // turns out larger is taken in several batches, so the estimate only has to be typical.)
+        const double want_w = mean > 0.0 ? 0.95 * (Cfg<T>::CAP / 4) / mean : 256.0;
+        int log_rw = 8;
         while (log_rw > 0 && double(1 << log_rw) > want_w) --log_rw;
         if (tune.csr_log_rw >= 0 && tune.csr_log_rw < log_rw) log_rw = tune.csr_log_rw; // only smaller tiles fit
         const int64_t blocks_w = lsk::ceil_div(rows, int64_t(4) << log_rw);
@@ -475,6 +557,8 @@ int launch_csr_spmv(const char *name, int64_t rows, int64_t nnz, const int64_t *
             LSK_CSRW_CASE(4)
             LSK_CSRW_CASE(5)
             LSK_CSRW_CASE(6)
+            LSK_CSRW_CASE(7)
+            LSK_CSRW_CASE(8)
         }
 #undef LSK_CSRW_LAUNCH
 #undef LSK_CSRW_CASE

@@ -91,4 +91,11 @@ __device__ __forceinline__ T wave_sum(T v) {
     return v;
 }
 
+// Lane 0's value, as a wave-uniform (scalar-register) value.
+__device__ __forceinline__ long long wave_first(long long v) {
+    const int lo = __builtin_amdgcn_readfirstlane(static_cast<int>(v));
+    const int hi = __builtin_amdgcn_readfirstlane(static_cast<int>(v >> 32));
+    return (static_cast<long long>(hi) << 32) | static_cast<unsigned>(lo);
+}
+
 } // namespace lsk

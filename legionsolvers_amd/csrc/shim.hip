@@ -91,7 +91,7 @@ int lsk_set_option(const char *key, int value) {
     } else if (!std::strcmp(key, "xcd_remap")) {
         o.xcd_remap = value;
     } else if (!std::strcmp(key, "csr.log_rows_per_wave")) {
-        if (value < -1 || value > 6) return lsk::fail(LSK_ERR_ARG, "csr.log_rows_per_wave must be -1..6");
+        if (value < -1 || value > 8) return lsk::fail(LSK_ERR_ARG, "csr.log_rows_per_wave must be -1..8");
         o.csr_log_rw = value;
     } else if (!std::strcmp(key, "csr.max_units")) {
         if (value != 0 && value != 4 && value != 8) return lsk::fail(LSK_ERR_ARG, "csr.max_units must be 0, 4 or 8");
