@@ -134,6 +134,28 @@ def test_csr_spmv_general_rects(suf, csr_variant):
     empty = np.stack([np.arange(50), np.arange(50) - 1], axis=1).astype(np.int64)
     got = csr_case(suf, empty, 0, col[:60], val[:60], x, 0, n_cols - 1, tag="all-empty")
     assert np.all(got == 0)
+    # short rows (several rects per lane) with a few long ones in between: tiles that are taken
+    # in batches, and rows that alone exceed the on-chip buffer
+    for seed, (short_hi, long_len, every) in enumerate([(6, 3000, 97), (3, 700, 41), (8, 1200, 300)]):
+        rng2 = np.random.default_rng(100 + seed)
+        lens2 = rng2.integers(0, short_hi, size=3000)
+        lens2[::every] = long_len
+        starts2 = np.concatenate([[0], np.cumsum(lens2)])
+        col2 = rng2.integers(0, n_cols, size=int(starts2[-1])).astype(np.int64)
+        val2 = rng2.standard_normal(int(starts2[-1])).astype(npdt)
+        rects2 = np.stack([starts2[:-1], starts2[1:] - 1], axis=1).astype(np.int64)
+        csr_case(suf, rects2, 0, col2, val2, x, 0, n_cols - 1, tag=f"short-and-long-rows-{seed}")
+    # clusters of long rows among short ones: the mean picks large tiles, the clusters overflow them
+    lens3 = np.full(4000, 2)
+    for c0 in range(100, 4000, 500):
+        lens3[c0:c0 + 40] = 200
+    starts3 = np.concatenate([[0], np.cumsum(lens3)])
+    col3 = rng.integers(0, n_cols, size=int(starts3[-1])).astype(np.int64)
+    val3 = rng.standard_normal(int(starts3[-1])).astype(npdt)
+    rects3 = np.stack([starts3[:-1], starts3[1:] - 1], axis=1).astype(np.int64)
+    csr_case(suf, rects3, 0, col3, val3, x, 0, n_cols - 1, tag="clustered-long-rows")
+    csr_case(suf, rects3, 0, col3, val3, x, 0, n_cols - 1, beta=1,
+             y0=rng.standard_normal(4000).astype(npdt), tag="clustered-long-rows-beta1")
     # dense-ish rows (~512 per row): few rows per workgroup
     lens = np.full(64, 512)
     starts = np.concatenate([[0], np.cumsum(lens)])
