@@ -229,6 +229,21 @@ int lsk_csr_spmv_f64(int64_t rows, int64_t nnz, const int64_t *rects, int64_t k_
                      const int64_t *col, const double *val, const double *x, int64_t x_lo,
                      int64_t x_hi, double *y, int beta, lsk_stream_t stream);
 
+/* Set-up-time tuning of the tile -> XCD placement for one CSR piece: runs the SpMV above (beta = 0,
+ * y is overwritten with A x) a few times per candidate value of the "xcd_remap" option, timed with
+ * HIP events on `stream`, and returns the fastest candidate in *remap_out and its milliseconds
+ * per launch in *ms_out (either may be null).  The option itself is left as it was: the caller
+ * stores the value with the matrix and sets it before its launches.  Which placement wins depends
+ * on how the piece's columns repeat from row block to row block (for a linearised stencil, on
+ * the plane size), so it is measured, not derived.  Blocks until the measurements are done.
+ * No counterpart in the reference (cuSPARSE's algorithm choice is internal). */
+int lsk_csr_spmv_tune_f32(int64_t rows, int64_t nnz, const int64_t *rects, int64_t k_base,
+                          const int64_t *col, const float *val, const float *x, int64_t x_lo,
+                          int64_t x_hi, float *y, lsk_stream_t stream, int *remap_out, float *ms_out);
+int lsk_csr_spmv_tune_f64(int64_t rows, int64_t nnz, const int64_t *rects, int64_t k_base,
+                          const int64_t *col, const double *val, const double *x, int64_t x_lo,
+                          int64_t x_hi, double *y, lsk_stream_t stream, int *remap_out, float *ms_out);
+
 /* indptr[i] = rects[i].lo - rects[0].lo for i < rows; indptr[rows] = rects[rows-1].hi + 1
  * - rects[0].lo.  Bit-exact restatement of convertGlobalRowptrToLocalIndPtr
  * (src/CuSPARSEHelpers.hpp:9-31) for callers that want a classic CSR offset array; the

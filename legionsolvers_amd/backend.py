@@ -37,6 +37,7 @@ class HipBackend:
         # Partial sums of dot/nrm2: private to this backend so that other users of the
         # library's per-device scratch cannot race with it.
         self._ws_bytes = int(self.lib.lsk_dot_workspace_bytes(0))
+        self._placement = 0  # value of the library's xcd_remap option as last set from here
         self._ws = torch.empty(self._ws_bytes, dtype=torch.uint8, device=self.device)
 
     # -- plumbing ------------------------------------------------------------------------
@@ -91,9 +92,23 @@ class HipBackend:
     # -- SpMV ------------------------------------------------------------------------------
     def csr_spmv(self, rows: int, nnz: int, rects: torch.Tensor, k_base: int, col: torch.Tensor,
                  val: torch.Tensor, x: torch.Tensor, x_lo: int, x_hi: int, y: torch.Tensor,
-                 beta: int) -> None:
+                 beta: int, placement: int = 0) -> None:
+        """`placement`: the piece's tile -> XCD placement found by csr_spmv_tune (a speed hint)."""
+        if placement != self._placement:
+            _lib.call("lsk_set_option", b"xcd_remap", placement)
+            self._placement = placement
         _lib.call(f"lsk_csr_spmv_{_lib.suffix(val.dtype)}", rows, nnz, _ptr(rects), k_base, _ptr(col),
                   _ptr(val), _ptr(x), x_lo, x_hi, _ptr(y), beta, self.stream())
+
+    def csr_spmv_tune(self, rows: int, nnz: int, rects: torch.Tensor, k_base: int, col: torch.Tensor,
+                      val: torch.Tensor, x: torch.Tensor, x_lo: int, x_hi: int,
+                      y: torch.Tensor) -> Tuple[int, float]:
+        """(placement, milliseconds per launch) of the fastest tile -> XCD placement for this
+        piece; y is overwritten.  Synchronises."""
+        remap, ms = ctypes.c_int(0), ctypes.c_float(0.0)
+        _lib.call(f"lsk_csr_spmv_tune_{_lib.suffix(val.dtype)}", rows, nnz, _ptr(rects), k_base, _ptr(col),
+                  _ptr(val), _ptr(x), x_lo, x_hi, _ptr(y), self.stream(), ctypes.byref(remap), ctypes.byref(ms))
+        return remap.value, ms.value
 
     def coo_spmv(self, nnz: int, row: torch.Tensor, col: torch.Tensor, val: torch.Tensor,
                  x: torch.Tensor, x_lo: int, x_hi: int, y: torch.Tensor, y_lo: int, y_hi: int) -> None:

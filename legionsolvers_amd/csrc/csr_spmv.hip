@@ -607,9 +607,69 @@ __global__ __launch_bounds__(kBlock) void rects_to_indptr_kernel(int64_t rows,
     }
 }
 
+// Times the candidates of the tile -> XCD placement on this piece and reports the fastest.
+template <typename T>
+int tune_csr_spmv(const char *name, int64_t rows, int64_t nnz, const int64_t *rects, int64_t k_base,
+                  const int64_t *col, const T *val, const T *x, int64_t x_lo, int64_t x_hi, T *y,
+                  lsk_stream_t stream, int *remap_out, float *ms_out) {
+    static const int candidates[] = {0, 64, 256, 1024};
+    constexpr int kWarm = 2, kTimed = 5;
+    lsk::Options &tune = lsk::options();
+    const int saved = tune.xcd_remap;
+    hipStream_t s = lsk::as_stream(stream);
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    LSK_HIP(hipEventCreate(&t0));
+    LSK_HIP(hipEventCreate(&t1));
+    int best = saved, status = LSK_OK;
+    float best_ms = -1.0f;
+    for (int c : candidates) {
+        tune.xcd_remap = c;
+        for (int i = 0; i < kWarm && status == LSK_OK; ++i)
+            status = launch_csr_spmv<T>(name, rows, nnz, rects, k_base, col, val, x, x_lo, x_hi, y, 0, stream);
+        if (status != LSK_OK) break;
+        if (hipEventRecord(t0, s) != hipSuccess) { status = lsk::fail(LSK_ERR_HIP, "%s: event record", name); break; }
+        for (int i = 0; i < kTimed && status == LSK_OK; ++i)
+            status = launch_csr_spmv<T>(name, rows, nnz, rects, k_base, col, val, x, x_lo, x_hi, y, 0, stream);
+        if (status != LSK_OK) break;
+        float ms = 0.0f;
+        if (hipEventRecord(t1, s) != hipSuccess || hipEventSynchronize(t1) != hipSuccess ||
+            hipEventElapsedTime(&ms, t0, t1) != hipSuccess) {
+            status = lsk::fail(LSK_ERR_HIP, "%s: event timing", name);
+            break;
+        }
+        ms /= kTimed;
+        if (best_ms < 0.0f || ms < best_ms) {
+            best_ms = ms;
+            best = c;
+        }
+    }
+    tune.xcd_remap = saved;
+    (void)hipEventDestroy(t0);
+    (void)hipEventDestroy(t1);
+    if (status != LSK_OK) return status;
+    if (remap_out) *remap_out = best;
+    if (ms_out) *ms_out = best_ms;
+    return LSK_OK;
+}
+
 } // namespace
 
 extern "C" {
+
+int lsk_csr_spmv_tune_f32(int64_t rows, int64_t nnz, const int64_t *rects, int64_t k_base,
+                          const int64_t *col, const float *val, const float *x, int64_t x_lo,
+                          int64_t x_hi, float *y, lsk_stream_t stream, int *remap_out, float *ms_out) {
+    return tune_csr_spmv<float>("lsk_csr_spmv_tune_f32", rows, nnz, rects, k_base, col, val, x, x_lo, x_hi,
+                                y, stream, remap_out, ms_out);
+}
+
+int lsk_csr_spmv_tune_f64(int64_t rows, int64_t nnz, const int64_t *rects, int64_t k_base,
+                          const int64_t *col, const double *val, const double *x, int64_t x_lo,
+                          int64_t x_hi, double *y, lsk_stream_t stream, int *remap_out, float *ms_out) {
+    return tune_csr_spmv<double>("lsk_csr_spmv_tune_f64", rows, nnz, rects, k_base, col, val, x, x_lo, x_hi,
+                                 y, stream, remap_out, ms_out);
+}
+
 
 int lsk_csr_spmv_f32(int64_t rows, int64_t nnz, const int64_t *rects, int64_t k_base,
                      const int64_t *col, const float *val, const float *x, int64_t x_lo,

@@ -12,6 +12,7 @@ on the device.  `matvec` is one leaf launch per local piece.
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 from typing import List, Tuple
 
@@ -70,6 +71,32 @@ class CSRMatrix(AbstractMatrix):
         self.row_lo = int(row_lo)
         self.rows = rects.shape[0]
         self.nnz = col.numel()
+        self.placement = {}  # piece colour -> tile placement found by tune()
+
+    TUNE_MIN_ROWS = 1 << 21  # pieces below this are not worth the ~30 trial launches
+
+    def tune(self, x_lo, x_hi, kernel_partition, range_partition) -> None:
+        """Set-up-time choice of the tile -> XCD placement per piece (the backend times a few
+        candidates on the piece itself).  A speed hint: results do not depend on it.  No
+        counterpart in the reference, where cuSPARSE picks its algorithm internally."""
+        tuner = getattr(self.ctx.backend, "csr_spmv_tune", None)
+        if tuner is None or os.environ.get("LSK_TUNE", "1") == "0" or x_hi < x_lo:
+            return
+        x = y = None
+        for i, c in enumerate(kernel_partition.colors):
+            p = range_partition.pieces[c]
+            k_lo, k_hi = kernel_partition.intervals[i]
+            nnz = max(k_hi - k_lo + 1, 0)
+            if p.volume < self.TUNE_MIN_ROWS or nnz == 0:
+                continue
+            if x is None:
+                x = torch.zeros(x_hi - x_lo + 1, dtype=self.dtype, device=self.val.device)
+            if y is None or y.numel() < p.volume:
+                y = torch.empty(p.volume, dtype=self.dtype, device=self.val.device)
+            r0 = p.lo[0] - self.row_lo
+            off = k_lo - self.k_base
+            self.placement[c], _ = tuner(p.volume, nnz, self.rects[r0:r0 + p.volume], k_lo,
+                                         self.col[off:off + nnz], self.val[off:off + nnz], x, x_lo, x_hi, y)
 
     def create_kernel_partition_from_range_partition(self, range_partition):
         """Image-range of the rowptr rects over each piece's rows (src/CSRMatrix.cpp:89-109)."""
@@ -104,7 +131,7 @@ class CSRMatrix(AbstractMatrix):
             off = (k_lo - self.k_base) if nnz else 0
             self.ctx.backend.csr_spmv(rows, nnz, self.rects[r0:r0 + rows], k_lo if nnz else self.k_base,
                                       self.col[off:off + nnz], self.val[off:off + nnz], x, x_lo, x_hi,
-                                      dst.piece(i), beta)
+                                      dst.piece(i), beta, self.placement.get(c, 0))
 
 
 class COOMatrix(AbstractMatrix):

@@ -102,6 +102,11 @@ class SquarePlanner:
         mine = (domain_partition.rank_interval(rank, world), _hull(ghost_partition.intervals))
         everyone = self.ctx.comm.all_gather_object(mine)
         plan = build_halo_plan(rank, [e[0] for e in everyone], [e[1] for e in everyone])
+        tune = getattr(matrix, "tune", None)
+        if tune is not None and not getattr(matrix, "_tuned", False):
+            window = _hull(ghost_partition.intervals)
+            tune(window[0], window[1], kernel_partition, range_partition)
+            matrix._tuned = True
         self.row_partitioned_matrices.append(
             _MatrixEntry(matrix, domain_index, range_index, kernel_partition, ghost_partition, plan))
 

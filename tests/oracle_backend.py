@@ -70,7 +70,7 @@ class OracleBackend:
         bv = b.item() if b is not None else 0.0
         out[0] = float(oracle.scalar_op(_OPS[op], a.item(), bv, _np(a).dtype))
 
-    def csr_spmv(self, rows, nnz, rects, k_base, col, val, x, x_lo, x_hi, y, beta):
+    def csr_spmv(self, rows, nnz, rects, k_base, col, val, x, x_lo, x_hi, y, beta, placement=0):
         oracle.csr_matvec(_np(rects), k_base, _np(col), _np(val), _np(x), x_lo, x_hi, _np(y), beta=beta)
 
     def coo_spmv(self, nnz, row, col, val, x, x_lo, x_hi, y, y_lo, y_hi):

@@ -153,3 +153,22 @@ def test_spmv_properties_at_headline_size(gpu_ctx):
     Az.axpy(-2.0, Ax)
     Az.axpy(3.0, Ay)
     assert Az.dot(Az).get_value() ** 0.5 <= 1e-12 * (4 * Ax.dot(Ax).get_value() + 9 * Ay.dot(Ay).get_value()) ** 0.5
+
+
+def test_cg_with_tuned_placement(gpu_ctx, monkeypatch):
+    """The planner's set-up-time placement tuning (normally only for pieces of millions of rows)
+    forced on a small problem: same CG history as the oracle, whatever placement it picks."""
+    from legionsolvers_amd import CSRMatrix
+    monkeypatch.setattr(CSRMatrix, "TUNE_MIN_ROWS", 1)
+    rects, row, col, val, n = hc.stencil_problem(4, (16, 16, 16), np.float64)
+    rhs = np.random.default_rng(32).standard_normal(n)
+    opl = hc.oracle_planner("csr", rects, row, col, val, n, 2, np.float64, rhs)
+    mpl = hc.mirror_planner(gpu_ctx, "csr", rects, row, col, val, n, 2, np.float64, rhs)
+    matrix = mpl.row_partitioned_matrices[0].matrix
+    assert sorted(matrix.placement) == [0, 1] and all(v in (0, 64, 256, 1024) for v in matrix.placement.values())
+    so, sm = S.CGSolver(opl), CGSolver(mpl)
+    for _ in range(8):
+        so.step()
+        sm.step()
+    np.testing.assert_allclose([s.get_value() for s in sm.residual_norm_squared],
+                               [float(v) for v in so.residual_norm_squared], rtol=1e-10)

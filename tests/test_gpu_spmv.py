@@ -291,6 +291,42 @@ def test_coo_spmv(suf, coo_variant):
     assert float(yd.abs().sum() - yd[3].abs()) == 0.0
 
 
+@pytest.mark.parametrize("suf", ["f32", "f64"])
+def test_csr_spmv_tune(suf):
+    """The set-up-time placement tuner: returns one of its candidates with a positive time,
+    leaves y = A x behind and the library option as it was."""
+    npdt, tdt, tol = DT[suf]
+    offs, cfs = oracle.benchmark_stencil_offsets(4)
+    rects, _, col, val = oracle.linearized_stencil((40, 40, 40), offs, cfs, dtype=npdt)
+    n = rects.shape[0]
+    x = np.random.default_rng(30).standard_normal(n).astype(npdt)
+    want = np.zeros(n, dtype=npdt)
+    oracle.csr_matvec(rects, 0, col, val, x, 0, n - 1, want)
+    before = ctypes.c_int(-7)
+    _lib.call("lsk_get_option", b"xcd_remap", ctypes.byref(before))
+    rd, cd, vd, xd = dev(rects), dev(col), dev(val), dev(x)
+    yd = torch.full((n,), 9.0, dtype=tdt, device="cuda")
+    remap, ms = ctypes.c_int(-1), ctypes.c_float(-1.0)
+    print(f"case csr_spmv_tune_{suf} rows={n}", flush=True)
+    _lib.call(f"lsk_csr_spmv_tune_{suf}", n, val.size, P(rd), 0, P(cd), P(vd), P(xd), 0, n - 1, P(yd),
+              stream(), ctypes.byref(remap), ctypes.byref(ms))
+    assert remap.value in (0, 64, 256, 1024) and ms.value > 0.0
+    after = ctypes.c_int(-7)
+    _lib.call("lsk_get_option", b"xcd_remap", ctypes.byref(after))
+    assert after.value == before.value
+    np.testing.assert_allclose(yd.cpu().numpy(), want, rtol=0, atol=tol * 40)
+    # every candidate placement gives the same (bit-identical) result
+    results = []
+    for c in (0, 64, 256, 1024, -1):
+        _lib.call("lsk_set_option", b"xcd_remap", c)
+        y2 = torch.zeros(n, dtype=tdt, device="cuda")
+        _lib.call(f"lsk_csr_spmv_{suf}", n, val.size, P(rd), 0, P(cd), P(vd), P(xd), 0, n - 1, P(y2), 0, stream())
+        results.append(y2.cpu().numpy())
+    _lib.call("lsk_set_option", b"xcd_remap", before.value)
+    for r in results[1:]:
+        assert np.array_equal(r, results[0])
+
+
 def test_rects_to_indptr_bit_exact():
     offs, cfs = oracle.benchmark_stencil_offsets(4)
     rects, _, _, _ = oracle.linearized_stencil((5, 6, 7), offs, cfs)
