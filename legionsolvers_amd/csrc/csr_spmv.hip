@@ -17,6 +17,7 @@
 //
 // HBM bytes per call: nnz*(8 + sizeof(T)) + rows*(16 + sizeof(T)) + the x window.
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 
 #include "lsk_common.hpp"
@@ -612,7 +613,7 @@ template <typename T>
 int tune_csr_spmv(const char *name, int64_t rows, int64_t nnz, const int64_t *rects, int64_t k_base,
                   const int64_t *col, const T *val, const T *x, int64_t x_lo, int64_t x_hi, T *y,
                   lsk_stream_t stream, int *remap_out, float *ms_out) {
-    static const int candidates[] = {0, 64, 256, 1024};
+    static const int candidates[] = {0, 16, 64, 256, 1024, 4096};
     constexpr int kWarm = 2, kTimed = 5;
     lsk::Options &tune = lsk::options();
     const int saved = tune.xcd_remap;
@@ -638,6 +639,8 @@ int tune_csr_spmv(const char *name, int64_t rows, int64_t nnz, const int64_t *re
             break;
         }
         ms /= kTimed;
+        if (std::getenv("LSK_TUNE_VERBOSE"))
+            std::fprintf(stderr, "[lsk] %s: xcd_remap %d -> %.3f ms per launch\n", name, c, ms);
         if (best_ms < 0.0f || ms < best_ms) {
             best_ms = ms;
             best = c;

@@ -165,7 +165,7 @@ def test_cg_with_tuned_placement(gpu_ctx, monkeypatch):
     opl = hc.oracle_planner("csr", rects, row, col, val, n, 2, np.float64, rhs)
     mpl = hc.mirror_planner(gpu_ctx, "csr", rects, row, col, val, n, 2, np.float64, rhs)
     matrix = mpl.row_partitioned_matrices[0].matrix
-    assert sorted(matrix.placement) == [0, 1] and all(v in (0, 64, 256, 1024) for v in matrix.placement.values())
+    assert sorted(matrix.placement) == [0, 1] and all(v in (0, 16, 64, 256, 1024, 4096) for v in matrix.placement.values())
     so, sm = S.CGSolver(opl), CGSolver(mpl)
     for _ in range(8):
         so.step()

@@ -310,14 +310,14 @@ def test_csr_spmv_tune(suf):
     print(f"case csr_spmv_tune_{suf} rows={n}", flush=True)
     _lib.call(f"lsk_csr_spmv_tune_{suf}", n, val.size, P(rd), 0, P(cd), P(vd), P(xd), 0, n - 1, P(yd),
               stream(), ctypes.byref(remap), ctypes.byref(ms))
-    assert remap.value in (0, 64, 256, 1024) and ms.value > 0.0
+    assert remap.value in (0, 16, 64, 256, 1024, 4096) and ms.value > 0.0
     after = ctypes.c_int(-7)
     _lib.call("lsk_get_option", b"xcd_remap", ctypes.byref(after))
     assert after.value == before.value
     np.testing.assert_allclose(yd.cpu().numpy(), want, rtol=0, atol=tol * 40)
     # every candidate placement gives the same (bit-identical) result
     results = []
-    for c in (0, 64, 256, 1024, -1):
+    for c in (0, 16, 64, 256, 1024, 4096, -1):
         _lib.call("lsk_set_option", b"xcd_remap", c)
         y2 = torch.zeros(n, dtype=tdt, device="cuda")
         _lib.call(f"lsk_csr_spmv_{suf}", n, val.size, P(rd), 0, P(cd), P(vd), P(xd), 0, n - 1, P(y2), 0, stream())

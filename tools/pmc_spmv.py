@@ -23,6 +23,7 @@ rows = n1 ** 3
 ip = IndexPartition.equal(IndexSpace(0, rows - 1), 1)
 A = sg.create_linearized_csr_stencil_matrix(ctx, (n1, n1, n1), offs, cfs, ip)
 kp = A.create_kernel_partition_from_range_partition(ip)
+A.tune(0, rows - 1, kp, ip)  # the placement the planner would pick at set-up
 x = PartitionedVector(ctx, "x", ip)
 y = PartitionedVector(ctx, "y", ip)
 x.owned.copy_(torch.randn(rows, device="cuda", dtype=torch.float64))
@@ -34,5 +35,6 @@ for _ in range(3):
     x.dot(y)
     y.axpy(a, x)
 ctx.synchronize()
+print(f"tile placement {A.placement}")
 print(f"rows={rows} nnz={A.nnz} spmv_algorithmic_bytes={A.nnz * 16 + rows * 32} "
       f"dot_bytes={rows * 16} axpy_read_bytes={rows * 16} axpy_write_bytes={rows * 8}")

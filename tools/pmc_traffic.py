@@ -20,7 +20,9 @@ def means(path, counter):
         key = "spmv" if "csr_spmv" in name else "dot" if "dot_kernel" in name else None
         if key:
             acc.setdefault(key, []).append(float(r["Counter_Value"]))
-    return {k: sum(v) / len(v) for k, v in acc.items()}
+    # the last three launches of each kind are the measured ones (earlier SpMV launches belong
+    # to the set-up-time placement tuning)
+    return {k: sum(v[-3:]) / len(v[-3:]) for k, v in acc.items()}
 
 
 def main():
