@@ -2,6 +2,7 @@
 declares, and its host-only entry points (get_alpha, task ids, argument validation) behave.
 No compute call is made: there is no GPU here."""
 import ctypes
+import os
 
 import numpy as np
 import pytest
@@ -85,3 +86,18 @@ def test_product_path_refuses_to_run_without_a_gpu():
     from legionsolvers_amd import Context
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         Context()
+
+
+def test_abort_on_error_matches_the_reference_behaviour():
+    """With lsk_set_abort_on_error(1) a failing call prints its message and aborts, as the
+    reference's CHECK_* macros do (src/CUDAUtilities.cpp:13-63).  Run in a child process."""
+    import subprocess
+    import sys
+    code = ("import ctypes, sys; sys.path.insert(0, %r); from legionsolvers_amd import _lib; "
+            "L = _lib.lib(); L.lsk_set_abort_on_error(1); "
+            "L.lsk_scal_f64(-1, 1.0, ctypes.c_void_p(0), ctypes.c_void_p(0)); print('survived')"
+            % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert res.returncode == -6, (res.returncode, res.stderr[-500:])  # SIGABRT
+    assert "[lsk]" in res.stderr and "negative" in res.stderr
+    assert "survived" not in res.stdout
