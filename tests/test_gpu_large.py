@@ -1,0 +1,79 @@
+"""Maximum sizes: element and row counts beyond 2^31, where 32-bit index arithmetic would wrap.
+Checked against torch on the device (whole vectors) and the CPU oracle (slices around the
+boundaries).  Needs ~100 GB of device memory; skipped on smaller cards."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from legionsolvers_amd import _lib
+
+pytestmark = pytest.mark.gpu
+
+
+def P(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _need(gib):
+    free, _ = torch.cuda.mem_get_info()
+    if free < gib * (1 << 30):
+        pytest.skip(f"needs {gib} GiB of free device memory")
+
+
+def test_blas1_beyond_2_31_elements(gpu_ctx):
+    _need(40)
+    n = (1 << 31) + 1027
+    print(f"case blas1 n={n} fp32", flush=True)
+    g = torch.Generator(device="cuda").manual_seed(3)
+    x = torch.randn(n, generator=g, device="cuda", dtype=torch.float32)
+    y = torch.randn(n, generator=g, device="cuda", dtype=torch.float32)
+    windows = [(0, 4096), ((1 << 31) - 2048, (1 << 31) + 1027), (n - 4096, n), ((1 << 30) + 7, (1 << 30) + 4103)]
+    keep = [(x[a:b].cpu().numpy().copy(), y[a:b].cpu().numpy().copy()) for a, b in windows]
+    alpha = np.float32(-0.625)
+    _lib.call("lsk_axpy_f32", n, float(alpha), P(x), P(y), stream())      # y = fma(alpha, x, y)
+    for (a, b), (xs, ys) in zip(windows, keep):
+        want = ys.copy()
+        oracle.axpy(alpha, xs, want)
+        assert np.array_equal(y[a:b].cpu().numpy(), want), (a, b)
+    # dot over the whole range against torch in fp64, block by block
+    out = torch.zeros(1, device="cuda", dtype=torch.float32)
+    ws = torch.empty(_lib.lib().lsk_dot_workspace_bytes(0), dtype=torch.uint8, device="cuda")
+    _lib.call("lsk_dot_f32", n, P(x), P(y), P(out), P(ws), ws.numel(), stream())
+    want, bound = 0.0, 0.0
+    step = 1 << 28
+    for a in range(0, n, step):
+        prod = x[a:a + step].double() * y[a:a + step].double()
+        want += float(prod.sum())
+        bound += float(prod.abs().sum())
+    assert abs(float(out) - want) <= 2e-6 * bound
+    # fill and scal touch every element: the tail would stay untouched if the count wrapped
+    _lib.call("lsk_fill_f32", n, 3.0, P(y), stream())
+    _lib.call("lsk_scal_f32", n, 0.5, P(y), stream())
+    assert float(y[-1]) == 1.5 and float(y[1 << 31]) == 1.5 and float(y[0]) == 1.5
+    assert float(y.min()) == 1.5 and float(y.max()) == 1.5
+
+
+def test_csr_spmv_beyond_2_31_rows(gpu_ctx):
+    """A diagonal matrix with 2^31 + 517 rows (one entry per row, 256 rows per wave)."""
+    _need(110)
+    rows = (1 << 31) + 517
+    print(f"case csr rows={rows} fp32 diagonal", flush=True)
+    idx = torch.arange(rows, device="cuda", dtype=torch.int64)
+    rects = torch.stack([idx, idx], dim=1).contiguous()
+    val = (idx % 7 + 1).to(torch.float32)
+    x = (idx % 5 + 1).to(torch.float32)
+    y = torch.full((rows,), -1.0, device="cuda", dtype=torch.float32)
+    _lib.call("lsk_csr_spmv_f32", rows, rows, P(rects), 0, P(idx), P(val), P(x), 0, rows - 1, P(y), 0, stream())
+    assert bool((y == val * x).all())
+    del rects
+    # the same matrix as COO
+    y.zero_()
+    _lib.call("lsk_coo_spmv_f32", rows, P(idx), P(idx), P(val), P(x), 0, rows - 1, P(y), 0, rows - 1, stream())
+    assert bool((y == val * x).all())
