@@ -201,6 +201,33 @@ int lsk_xpay_dev_f32(int64_t n, int nf, const float *f0, const float *f1, const 
 int lsk_xpay_dev_f64(int64_t n, int nf, const double *f0, const double *f1, const double *f2,
                      const double *f3, const double *x, double *y, lsk_stream_t stream);
 
+/* Fused axpy and squared norm: y <- fma(alpha, x, y) exactly as lsk_axpy_* / lsk_axpy_dev_*, and
+ * partials[0 .. *count) <- per-workgroup shares of sum_i y_new[i]^2 (at most 2048; `capacity` is
+ * the room in `partials`, *count is written on the host).  lsk_sum_partials_* turns them into
+ * the dot product y.y when the caller wants it.  Saves the second pass over y that AxpyTask
+ * followed by DotTask(v, v) makes (src/CGSolver.hpp:49-51: r <- r - alpha q; r.r).  No
+ * counterpart in the reference, whose tasks are launched one by one. */
+int lsk_axpy_sqnorm_f32(int64_t n, float alpha, const float *x, float *y, float *partials,
+                        int64_t capacity, int *count, lsk_stream_t stream);
+int lsk_axpy_sqnorm_f64(int64_t n, double alpha, const double *x, double *y, double *partials,
+                        int64_t capacity, int *count, lsk_stream_t stream);
+int lsk_axpy_sqnorm_dev_f32(int64_t n, int nf, const float *f0, const float *f1, const float *f2,
+                            const float *f3, const float *x, float *y, float *partials,
+                            int64_t capacity, int *count, lsk_stream_t stream);
+int lsk_axpy_sqnorm_dev_f64(int64_t n, int nf, const double *f0, const double *f1, const double *f2,
+                            const double *f3, const double *x, double *y, double *partials,
+                            int64_t capacity, int *count, lsk_stream_t stream);
+
+/* *result_dev <- partials[0] + ... + partials[count-1], in an order fixed by `count` alone (so
+ * bit-reproducible): the second stage of the fused forms (lsk_axpy_sqnorm_*, lsk_csr_spmv_dot_*).
+ * Counts above 8192 take two kernel stages through `workspace` (lsk_dot_workspace_bytes(0)
+ * bytes; NULL = the library's own per-device scratch, then not concurrently with other calls
+ * that use it). */
+int lsk_sum_partials_f32(int64_t count, const float *partials, float *result_dev, void *workspace,
+                         size_t workspace_bytes, lsk_stream_t stream);
+int lsk_sum_partials_f64(int64_t count, const double *partials, double *result_dev, void *workspace,
+                         size_t workspace_bytes, lsk_stream_t stream);
+
 /* ------------------------------------------------------------- CSR SpMV ------------- */
 /* y[r] <- beta*y[r] + sum_{k in rects[r]} val[k] * x[col[k]]   for the shard's rows,
  * beta in {0, 1}.
@@ -228,6 +255,24 @@ int lsk_csr_spmv_f32(int64_t rows, int64_t nnz, const int64_t *rects, int64_t k_
 int lsk_csr_spmv_f64(int64_t rows, int64_t nnz, const int64_t *rects, int64_t k_base,
                      const int64_t *col, const double *val, const double *x, int64_t x_lo,
                      int64_t x_hi, double *y, int beta, lsk_stream_t stream);
+
+/* Fused product and dot: y as lsk_csr_spmv_*, and partials[0 .. *count) <- per-wave shares of
+ * sum_r y_new[r] * w[r], where w[0] pairs with the piece's first row (w = the piece of the
+ * vector the caller will dot y with; for CG, p itself: p.Ap, src/CGSolver.hpp:46-47).  The shares
+ * are formed from values still in registers, so the DotTask's pass over y and w is saved.
+ * `capacity` must be at least lsk_csr_spmv_dot_partials(rows, nnz, sizeof(T)) (which follows
+ * the same tile-size rule as the launch, options included); *count is written on the host.
+ * lsk_sum_partials_* gives the dot product.  Always the wave-tile form.  No counterpart in the
+ * reference. */
+int64_t lsk_csr_spmv_dot_partials(int64_t rows, int64_t nnz, int elem_size);
+int lsk_csr_spmv_dot_f32(int64_t rows, int64_t nnz, const int64_t *rects, int64_t k_base,
+                         const int64_t *col, const float *val, const float *x, int64_t x_lo,
+                         int64_t x_hi, float *y, int beta, const float *w, float *partials,
+                         int64_t capacity, int64_t *count, lsk_stream_t stream);
+int lsk_csr_spmv_dot_f64(int64_t rows, int64_t nnz, const int64_t *rects, int64_t k_base,
+                         const int64_t *col, const double *val, const double *x, int64_t x_lo,
+                         int64_t x_hi, double *y, int beta, const double *w, double *partials,
+                         int64_t capacity, int64_t *count, lsk_stream_t stream);
 
 /* Set-up-time tuning of the tile -> XCD placement for one CSR piece: runs the SpMV above (beta = 0,
  * y is overwritten with A x) a few times per candidate value of the "xcd_remap" option, timed with

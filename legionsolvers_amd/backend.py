@@ -79,6 +79,38 @@ class HipBackend:
         nf, p = self._futs(futs)
         _lib.call(f"lsk_xpay_dev_{_lib.suffix(y.dtype)}", y.numel(), nf, *p, _ptr(x), _ptr(y), self.stream())
 
+    # -- fused forms -----------------------------------------------------------------------
+    SQNORM_SLOTS = 2048  # partial sums lsk_axpy_sqnorm_* writes at most
+
+    def axpy_sqnorm(self, y: torch.Tensor, futs, x: torch.Tensor, partials: torch.Tensor) -> int:
+        """y <- fma(alpha, x, y); partials[:count] <- shares of sum(y_new^2).  Returns count."""
+        nf, p = self._futs(futs)
+        count = ctypes.c_int(0)
+        _lib.call(f"lsk_axpy_sqnorm_dev_{_lib.suffix(y.dtype)}", y.numel(), nf, *p, _ptr(x), _ptr(y),
+                  _ptr(partials), partials.numel(), ctypes.byref(count), self.stream())
+        return count.value
+
+    def csr_spmv_dot_slots(self, rows: int, nnz: int, dtype: torch.dtype) -> int:
+        return int(self.lib.lsk_csr_spmv_dot_partials(rows, nnz, 4 if dtype == torch.float32 else 8))
+
+    def csr_spmv_dot(self, rows: int, nnz: int, rects: torch.Tensor, k_base: int, col: torch.Tensor,
+                     val: torch.Tensor, x: torch.Tensor, x_lo: int, x_hi: int, y: torch.Tensor,
+                     beta: int, w: torch.Tensor, partials: torch.Tensor, placement: int = 0) -> int:
+        """y as csr_spmv; partials[:count] <- shares of sum(y_new * w).  Returns count."""
+        if placement != self._placement:
+            _lib.call("lsk_set_option", b"xcd_remap", placement)
+            self._placement = placement
+        count = ctypes.c_int64(0)
+        _lib.call(f"lsk_csr_spmv_dot_{_lib.suffix(val.dtype)}", rows, nnz, _ptr(rects), k_base, _ptr(col),
+                  _ptr(val), _ptr(x), x_lo, x_hi, _ptr(y), beta, _ptr(w), _ptr(partials), partials.numel(),
+                  ctypes.byref(count), self.stream())
+        return count.value
+
+    def sum_partials(self, count: int, partials, out: torch.Tensor) -> None:
+        """out[0] <- partials[0] + ... + partials[count-1] (count may be 0)."""
+        _lib.call(f"lsk_sum_partials_{_lib.suffix(out.dtype)}", count, _ptr(partials), _ptr(out),
+                  _ptr(self._ws), self._ws_bytes, self.stream())
+
     def dot(self, v: torch.Tensor, w: torch.Tensor, out: torch.Tensor) -> None:
         _lib.call(f"lsk_dot_{_lib.suffix(v.dtype)}", v.numel(), _ptr(v), _ptr(w), _ptr(out),
                   _ptr(self._ws), self._ws_bytes, self.stream())

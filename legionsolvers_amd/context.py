@@ -5,6 +5,7 @@ joins it to the other shards' processes.  One process drives one MI355X.
 """
 from __future__ import annotations
 
+import os
 from typing import Optional
 
 import torch
@@ -13,8 +14,13 @@ from .comm import Communicator
 
 
 class Context:
-    def __init__(self, device: Optional[torch.device] = None, group=None, backend=None):
+    def __init__(self, device: Optional[torch.device] = None, group=None, backend=None,
+                 fuse: Optional[bool] = None):
+        """fuse: let the planner use the fused leaf forms (product + dot, axpy + squared norm)
+        where a solver's next dot product can reuse them; default on, LSK_FUSE=0 turns it off.
+        Results change only in the order of the additions inside the dot products."""
         self.comm = Communicator(group)
+        self.fuse = (os.environ.get("LSK_FUSE", "1") != "0") if fuse is None else bool(fuse)
         if backend is None:
             from .backend import HipBackend
             if device is None:

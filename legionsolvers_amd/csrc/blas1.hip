@@ -295,6 +295,142 @@ int launch_dot(const char *name, int64_t n, const T *v, const T *w, T *result, v
     return LSK_OK;
 }
 
+// ------------------------------------------------- fused axpy + squared norm, sums -------
+//
+// y <- fma(alpha, x, y) as the axpy above, and out[block] <- this block's share of sum(y_new^2):
+// the values are in registers anyway, so the reduction that usually follows an axpy in a Krylov
+// step (CG's r <- r - a q; rr = r.r) costs no second pass over y.  The partials are summed by
+// sum_partials when (and if) the caller wants the norm.
+template <typename T, typename E, int EN>
+__global__ __launch_bounds__(kBlock) void axpy_sqnorm_kernel(int64_t n, Alpha<T> a, const T *x, T *y,
+                                                             T *__restrict__ out, int form) {
+    const T alpha = resolve_alpha(a);
+    const int64_t ne = n / EN;
+    const E *xe = reinterpret_cast<const E *>(x);
+    E *ye = reinterpret_cast<E *>(y);
+    const int64_t gstride = int64_t(gridDim.x) * kBlock;
+    const int64_t inner = form ? kBlock : gstride;
+    const int64_t outer = 4 * gstride;
+    int64_t i = form ? int64_t(blockIdx.x) * (4 * kBlock) + threadIdx.x
+                     : int64_t(blockIdx.x) * kBlock + threadIdx.x;
+    const bool first = (blockIdx.x == 0 && threadIdx.x == 0);
+    T acc[4] = {T(0), T(0), T(0), T(0)};
+    for (; i + 3 * inner < ne; i += outer) {
+        E xv[4], yv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            xv[u] = xe[i + u * inner];
+            yv[u] = ye[i + u * inner];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            E r;
+            if constexpr (EN == 1) r = apply<T, OP_AXPY>(alpha, xv[u], yv[u]);
+            else r = apply_v<T, OP_AXPY>(alpha, xv[u], yv[u]);
+            ye[i + u * inner] = r;
+            acc[u] = dot_v<T>(r, r, acc[u]);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int64_t j = i + u * inner;
+        if (j < ne) {
+            E r;
+            if constexpr (EN == 1) r = apply<T, OP_AXPY>(alpha, xe[j], ye[j]);
+            else r = apply_v<T, OP_AXPY>(alpha, xe[j], ye[j]);
+            ye[j] = r;
+            acc[u] = dot_v<T>(r, r, acc[u]);
+        }
+    }
+    if (EN > 1 && first) {
+        for (int64_t j = ne * EN; j < n; ++j) {
+            const T r = apply<T, OP_AXPY>(alpha, x[j], y[j]);
+            y[j] = r;
+            acc[1] = fma_t(r, r, acc[1]);
+        }
+    }
+    const T total = block_sum((acc[0] + acc[1]) + (acc[2] + acc[3]));
+    if (threadIdx.x == 0) out[blockIdx.x] = total;
+}
+
+template <typename T>
+int launch_axpy_sqnorm(const char *name, int64_t n, Alpha<T> a, const T *x, T *y, T *partials,
+                       int64_t capacity, int *count, lsk_stream_t stream) {
+    if (n < 0) return lsk::fail(LSK_ERR_ARG, "%s: negative length %lld", name, (long long)n);
+    if (!count) return lsk::fail(LSK_ERR_ARG, "%s: null count", name);
+    *count = 0;
+    if (n == 0) return LSK_OK;
+    if (!x || !y || !partials) return lsk::fail(LSK_ERR_ARG, "%s: null vector", name);
+    if (x == y) return lsk::fail(LSK_ERR_ARG, "%s: x and y must differ", name);
+    if (a.nf > 4) return lsk::fail(LSK_ERR_ARG, "%s: %d futures (0..4 allowed)", name, a.nf);
+    const T *fs[4] = {a.f0, a.f1, a.f2, a.f3};
+    for (int i = 0; i < a.nf; ++i)
+        if (!fs[i]) return lsk::fail(LSK_ERR_ARG, "%s: future %d is null", name, i);
+    using V = typename Vec<T>::type;
+    constexpr int VN = Vec<T>::N;
+    const bool vec = lsk::aligned16(y) && lsk::aligned16(x);
+    const int blocks = vec ? stream_grid(n / VN + 1) : stream_grid(n);
+    if (capacity < blocks)
+        return lsk::fail(LSK_ERR_ARG, "%s: room for %lld partial sums, %d needed", name, (long long)capacity, blocks);
+    hipStream_t s = lsk::as_stream(stream);
+    const int form = lsk::options().blas1_form;
+    if (vec) axpy_sqnorm_kernel<T, V, VN><<<blocks, kBlock, 0, s>>>(n, a, x, y, partials, form);
+    else axpy_sqnorm_kernel<T, T, 1><<<blocks, kBlock, 0, s>>>(n, a, x, y, partials, form);
+    LSK_LAUNCH_CHECK();
+    *count = blocks;
+    return LSK_OK;
+}
+
+// First stage of a long sum: block b adds the partials b*per .. (b+1)*per-1 left to right per
+// thread, then across the block in block_sum's fixed order.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void sum_kernel(int64_t count, int64_t per, const T *__restrict__ in,
+                                                     T *__restrict__ out) {
+    const int64_t lo = int64_t(blockIdx.x) * per;
+    const int64_t hi = lo + per < count ? lo + per : count;
+    T acc = T(0);
+    for (int64_t i = lo + threadIdx.x; i < hi; i += kBlock) acc += in[i];
+    const T total = block_sum(acc);
+    if (threadIdx.x == 0) out[blockIdx.x] = total;
+}
+
+// *result <- sum of `count` partial sums, in an order fixed by count alone.
+template <typename T>
+int launch_sum_partials(const char *name, int64_t count, const T *partials, T *result, void *workspace,
+                        size_t workspace_bytes, lsk_stream_t stream) {
+    if (count < 0) return lsk::fail(LSK_ERR_ARG, "%s: negative count", name);
+    if (!result) return lsk::fail(LSK_ERR_ARG, "%s: null result", name);
+    hipStream_t s = lsk::as_stream(stream);
+    if (count == 0) {
+        store_scalar_kernel<T><<<1, 1, 0, s>>>(result, T(0));
+        LSK_LAUNCH_CHECK();
+        return LSK_OK;
+    }
+    if (!partials) return lsk::fail(LSK_ERR_ARG, "%s: null partials", name);
+    if (count > 4 * lsk::kMaxGridBlocks) { // two stages
+        const size_t need = size_t(lsk::kMaxGridBlocks) * sizeof(T);
+        T *stage = static_cast<T *>(workspace);
+        if (stage) {
+            if (workspace_bytes < need)
+                return lsk::fail(LSK_ERR_ARG, "%s: workspace of %zu bytes, %zu needed", name, workspace_bytes, need);
+        } else {
+            lsk::DeviceState *st = nullptr;
+            int rc = lsk::device_state(&st);
+            if (rc != LSK_OK) return rc;
+            stage = static_cast<T *>(st->scratch);
+        }
+        const int64_t per = lsk::ceil_div(count, int64_t(lsk::kMaxGridBlocks));
+        const int blocks = static_cast<int>(lsk::ceil_div(count, per));
+        sum_kernel<T><<<blocks, kBlock, 0, s>>>(count, per, partials, stage);
+        LSK_LAUNCH_CHECK();
+        fold_kernel<T><<<1, kBlock, 0, s>>>(blocks, stage, result, FIN_NONE);
+    } else {
+        fold_kernel<T><<<1, kBlock, 0, s>>>(static_cast<int>(count), partials, result, FIN_NONE);
+    }
+    LSK_LAUNCH_CHECK();
+    return LSK_OK;
+}
+
 template <typename T>
 int dot_host(const char *name, int64_t n, const T *v, const T *w, T *result_host,
              lsk_stream_t stream) {
@@ -477,6 +613,23 @@ size_t lsk_dot_workspace_bytes(int64_t n) {
     }                                                                                             \
     int lsk_sum_scalars_##SUFFIX(int count, const T *in, T *out, lsk_stream_t s) {                \
         return launch_sum_scalars<T>(count, in, out, s);                                          \
+    }                                                                                             \
+    int lsk_axpy_sqnorm_##SUFFIX(int64_t n, T alpha, const T *x, T *y, T *partials,               \
+                                 int64_t capacity, int *count, lsk_stream_t s) {                  \
+        return launch_axpy_sqnorm<T>("lsk_axpy_sqnorm_" #SUFFIX, n, host_alpha<T>(alpha), x, y,   \
+                                     partials, capacity, count, s);                               \
+    }                                                                                             \
+    int lsk_axpy_sqnorm_dev_##SUFFIX(int64_t n, int nf, const T *f0, const T *f1, const T *f2,    \
+                                     const T *f3, const T *x, T *y, T *partials,                  \
+                                     int64_t capacity, int *count, lsk_stream_t s) {              \
+        return launch_axpy_sqnorm<T>("lsk_axpy_sqnorm_dev_" #SUFFIX, n,                           \
+                                     dev_alpha<T>(nf, f0, f1, f2, f3), x, y, partials, capacity,  \
+                                     count, s);                                                   \
+    }                                                                                             \
+    int lsk_sum_partials_##SUFFIX(int64_t count, const T *partials, T *result, void *ws,          \
+                                  size_t wsb, lsk_stream_t s) {                                   \
+        return launch_sum_partials<T>("lsk_sum_partials_" #SUFFIX, count, partials, result, ws,   \
+                                      wsb, s);                                                    \
     }
 
 LSK_BLAS1(f32, float)

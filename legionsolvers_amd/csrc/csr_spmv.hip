@@ -218,11 +218,13 @@ __global__ __launch_bounds__(kBlock) void csr_spmv_kernel(
 }
 
 // One row of the tile per wave, entries straight from HBM (wave-level form of rows_by_wave).
+// With w != nullptr lane 0 also adds y_new[r] * w[r] into *dot_acc.
 template <typename T>
 __device__ void wave_rows_direct(int nr, const Rect *__restrict__ rects, int64_t k_base,
                                  int64_t nnz, const int64_t *__restrict__ col,
                                  const T *__restrict__ val, const T *__restrict__ x, int64_t x_lo,
-                                 int64_t x_hi, T *__restrict__ y, int beta) {
+                                 int64_t x_hi, T *__restrict__ y, int beta,
+                                 const T *__restrict__ w = nullptr, T *dot_acc = nullptr) {
     const int lane = threadIdx.x % lsk::kWave;
     for (int r = 0; r < nr; ++r) {
         const Rect rc = rects[r];
@@ -234,7 +236,11 @@ __device__ void wave_rows_direct(int nr, const Rect *__restrict__ rects, int64_t
             if (c >= x_lo && c <= x_hi) acc = fma_t(val[k - k_base], x[c - x_lo], acc);
         }
         acc = lsk::wave_sum(acc);
-        if (lane == 0) y[r] = beta ? y[r] + acc : acc;
+        if (lane == 0) {
+            const T out = beta ? y[r] + acc : acc;
+            y[r] = out;
+            if (w) *dot_acc += out * w[r];
+        }
     }
 }
 
@@ -371,11 +377,16 @@ __device__ __forceinline__ T fold_range(const T *__restrict__ sp, int e0, int e1
 //      16-byte units per lane (stream_batch / stream_chunk);
 //   3. the rows' products are added out of LDS: 64/ROWS lanes per row when ROWS < 64, else every
 //      lane folds its own ROWS/64 rows; y is stored one lane per row.
-template <typename T, int LOG_ROWS, bool NT, int KMAX>
+//
+// DOT: the kernel also leaves, per wave, the sum over its rows of y_new[r] * w[r] in
+// partials[tile * 4 + wave] (0 for waves past the last row): the dot product a Krylov step
+// takes right after the product (CG's p.Ap) without a second pass over y and w.
+template <typename T, int LOG_ROWS, bool NT, int KMAX, bool DOT>
 __global__ __launch_bounds__(kBlock, 4) void csr_spmv_wave_kernel( // at least 4 waves per SIMD: <= 128 VGPRs
     int64_t rows, const Rect *__restrict__ rects, int64_t k_base, int64_t nnz,
     const int64_t *__restrict__ col, const T *__restrict__ val, const T *__restrict__ x,
-    int64_t x_lo, int64_t x_hi, T *__restrict__ y, int beta, int remap) {
+    int64_t x_lo, int64_t x_hi, T *__restrict__ y, int beta, int remap,
+    const T *__restrict__ w, T *__restrict__ partials) {
     constexpr int ROWS = 1 << LOG_ROWS;
     constexpr int RPL = ROWS > lsk::kWave ? ROWS / lsk::kWave : 1; // rects per lane
     constexpr int GW = ROWS < lsk::kWave ? lsk::kWave / ROWS : 1;  // lanes per row in the fold
@@ -384,12 +395,31 @@ __global__ __launch_bounds__(kBlock, 4) void csr_spmv_wave_kernel( // at least 4
 
     __shared__ T s_prod[WAVES][CAPW];
 
-    const int wave = threadIdx.x / lsk::kWave, lane = threadIdx.x % lsk::kWave;
+    // the wave number as a scalar: everything derived from it (first row, LDS base, partial
+    // slot) then lives in scalar registers
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / lsk::kWave);
+    const int lane = threadIdx.x % lsk::kWave;
     const unsigned tile = lsk::xcd_remap(blockIdx.x, gridDim.x, remap);
     const int64_t r0 = (int64_t(tile) * WAVES + wave) * ROWS;
-    if (r0 >= rows) return; // wave-uniform; nothing below synchronises across waves
+    // indexed by tile, not by workgroup: the order of the partial sums does not follow the placement
+    T *const my_partial = DOT ? partials + (int64_t(tile) * WAVES + wave) : nullptr;
+    if (r0 >= rows) { // wave-uniform; nothing below synchronises across waves
+        if (DOT && lane == 0) *my_partial = T(0);
+        return;
+    }
     const int nr = static_cast<int>(rows - r0 < ROWS ? rows - r0 : ROWS);
     T *sp = s_prod[wave];
+    T dot_acc = T(0); // this lane's share of sum_r y_new[r] * w[r]
+    const T *wt = DOT ? w + r0 : nullptr;
+    // w of the rows this lane will store, fetched now so that its latency hides behind the tile
+    T wv[RPL];
+    if constexpr (DOT) {
+#pragma unroll
+        for (int j = 0; j < RPL; ++j) {
+            const int row = RPL == 1 ? lane / GW : j * lsk::kWave + lane;
+            wv[j] = wt[row < nr ? row : nr - 1];
+        }
+    }
 
     // ---- 1. rects ------------------------------------------------------------------------
     Rect rc[RPL];
@@ -423,7 +453,8 @@ __global__ __launch_bounds__(kBlock, 4) void csr_spmv_wave_kernel( // at least 4
         if (row < nr - 1) ok = ok && (next_lo == rel_end[j]);
     }
     if (!__all(ok)) {
-        wave_rows_direct<T>(nr, rects + r0, k_base, nnz, col, val, x, x_lo, x_hi, y + r0, beta);
+        wave_rows_direct<T>(nr, rects + r0, k_base, nnz, col, val, x, x_lo, x_hi, y + r0, beta, wt, &dot_acc);
+        if (DOT && lane == 0) *my_partial = dot_acc;
         return;
     }
     const int64_t *colb = col + (k0 - k_base);
@@ -451,7 +482,8 @@ __global__ __launch_bounds__(kBlock, 4) void csr_spmv_wave_kernel( // at least 4
             m += __popcll(__ballot(fits));
         }
         if (m == 0) { // this row alone is longer than the buffer
-            wave_rows_direct<T>(1, rects + r0 + ra, k_base, nnz, col, val, x, x_lo, x_hi, y + r0 + ra, beta);
+            wave_rows_direct<T>(1, rects + r0 + ra, k_base, nnz, col, val, x, x_lo, x_hi, y + r0 + ra, beta,
+                                DOT ? wt + ra : nullptr, &dot_acc);
             ra += 1;
             continue;
         }
@@ -470,7 +502,9 @@ __global__ __launch_bounds__(kBlock, 4) void csr_spmv_wave_kernel( // at least 4
             }
             if (mine && g == 0) {
                 T *yp = y + r0 + row;
-                *yp = beta ? *yp + acc : acc;
+                const T out = beta ? *yp + acc : acc;
+                *yp = out;
+                if constexpr (DOT) dot_acc += out * wv[0];
             }
         } else {
 #pragma unroll
@@ -479,12 +513,18 @@ __global__ __launch_bounds__(kBlock, 4) void csr_spmv_wave_kernel( // at least 4
                 if (row >= ra && row < ra + m) {
                     const T acc = fold_range<T, CAPW>(sp, rel_lo[j] - base, rel_end[j] - base, 0, 1);
                     T *yp = y + r0 + row;
-                    *yp = beta ? *yp + acc : acc;
+                    const T out = beta ? *yp + acc : acc;
+                    *yp = out;
+                    if constexpr (DOT) dot_acc += out * wv[j];
                 }
             }
         }
         ra += m;
         if (ra < nr) wave_lds_fence(); // the next batch overwrites the buffer
+    }
+    if constexpr (DOT) {
+        dot_acc = lsk::wave_sum(dot_acc);
+        if (lane == 0) *my_partial = dot_acc;
     }
 }
 
@@ -494,10 +534,36 @@ __global__ __launch_bounds__(kBlock) void zero_kernel(int64_t n, T *__restrict__
     for (int64_t i = int64_t(blockIdx.x) * kBlock + threadIdx.x; i < n; i += stride) y[i] = T(0);
 }
 
+// Rows per wave of the wave-tile form (log2): as many as keep the tile's products inside the
+// wave's quarter of the LDS buffer at the piece's mean row length, a power of two in 1..256.
+// (A tile that turns out larger is taken in several batches, so the estimate only has to be
+// typical.)
+template <typename T>
+int pick_log_rows_per_wave(int64_t rows, int64_t nnz) {
+    const double mean = rows > 0 ? double(nnz) / double(rows) : 0.0;
+    const double want_w = mean > 0.0 ? 0.95 * (Cfg<T>::CAP / 4) / mean : 256.0;
+    int log_rw = 8;
+    while (log_rw > 0 && double(1 << log_rw) > want_w) --log_rw;
+    const int forced = lsk::options().csr_log_rw;
+    if (forced >= 0 && forced < log_rw) log_rw = forced; // only smaller tiles fit
+    return log_rw;
+}
+
+template <typename T>
+__global__ void store_zero_kernel(T *out) { *out = T(0); }
+
+// w != nullptr selects the fused form: besides y, partials[0 .. *count) receive per-wave sums
+// of y_new[r] * w[r] (w[0] pairs with the piece's first row).
 template <typename T>
 int launch_csr_spmv(const char *name, int64_t rows, int64_t nnz, const int64_t *rects,
                     int64_t k_base, const int64_t *col, const T *val, const T *x, int64_t x_lo,
-                    int64_t x_hi, T *y, int beta, lsk_stream_t stream) {
+                    int64_t x_hi, T *y, int beta, lsk_stream_t stream, const T *w = nullptr,
+                    T *partials = nullptr, int64_t capacity = 0, int64_t *count = nullptr) {
+    const bool fused = (w != nullptr);
+    if (fused) {
+        if (!partials || !count) return lsk::fail(LSK_ERR_ARG, "%s: null partials or count", name);
+        *count = 0;
+    }
     if (rows < 0 || nnz < 0)
         return lsk::fail(LSK_ERR_ARG, "%s: negative size (rows %lld, nnz %lld)", name,
                          (long long)rows, (long long)nnz);
@@ -512,11 +578,19 @@ int launch_csr_spmv(const char *name, int64_t rows, int64_t nnz, const int64_t *
         return lsk::fail(LSK_ERR_ALIGN, "%s: col/val must be naturally aligned", name);
 
     if (x_hi < x_lo) { // an empty input domain admits no entry: y <- beta * y
+        if (fused && beta != 0)
+            return lsk::fail(LSK_ERR_UNSUPPORTED, "%s: empty input window with beta = 1", name);
         if (beta == 0) {
             zero_kernel<T><<<static_cast<unsigned>(std::min<int64_t>(lsk::ceil_div(rows, kBlock),
                                                                   lsk::kMaxGridBlocks)),
                              kBlock, 0, lsk::as_stream(stream)>>>(rows, y);
             LSK_LAUNCH_CHECK();
+        }
+        if (fused) {
+            if (capacity < 1) return lsk::fail(LSK_ERR_ARG, "%s: no room for partial sums", name);
+            store_zero_kernel<T><<<1, 1, 0, lsk::as_stream(stream)>>>(partials);
+            LSK_LAUNCH_CHECK();
+            *count = 1;
         }
         return LSK_OK;
     }
@@ -524,25 +598,28 @@ int launch_csr_spmv(const char *name, int64_t rows, int64_t nnz, const int64_t *
     const Rect *rc = reinterpret_cast<const Rect *>(rects);
     hipStream_t s = lsk::as_stream(stream);
     const lsk::Options &tune = lsk::options();
-    if (tune.csr_variant == 1) {
-        // Rows per wave: as many as keep the tile's products inside the wave's quarter of
-        // the LDS buffer at the piece's mean row length, a power of two in 1..256.  (A tile that
-        // turns out larger is taken in several batches, so the estimate only has to be typical.)
-        const double want_w = mean > 0.0 ? 0.95 * (Cfg<T>::CAP / 4) / mean : 256.0;
-        int log_rw = 8;
-        while (log_rw > 0 && double(1 << log_rw) > want_w) --log_rw;
-        if (tune.csr_log_rw >= 0 && tune.csr_log_rw < log_rw) log_rw = tune.csr_log_rw; // only smaller tiles fit
+    if (tune.csr_variant == 1 || fused) {
+        const int log_rw = pick_log_rows_per_wave<T>(rows, nnz);
         const int64_t blocks_w = lsk::ceil_div(rows, int64_t(4) << log_rw);
         if (blocks_w > 0x7fffffffLL) return lsk::fail(LSK_ERR_UNSUPPORTED, "%s: too many rows", name);
+        if (fused && capacity < blocks_w * 4)
+            return lsk::fail(LSK_ERR_ARG, "%s: room for %lld partial sums, %lld needed", name,
+                             (long long)capacity, (long long)(blocks_w * 4));
         // Units per lane a mean tile needs: more than 4 -> the 8-unit instance.
         const double units = 1.05 * mean * double(1 << log_rw) / double(lsk::kWave * Cfg<T>::U);
         const bool wide = tune.csr_max_units == 0 ? units > 4.0 : tune.csr_max_units == 8;
 #define LSK_CSRW_LAUNCH(L, NT, KMAX)                                                              \
-    csr_spmv_wave_kernel<T, L, NT, KMAX><<<unsigned(blocks_w), kBlock, 0, s>>>(                   \
-        rows, rc, k_base, nnz, col, val, x, x_lo, x_hi, y, beta, tune.xcd_remap)
+    csr_spmv_wave_kernel<T, L, NT, KMAX, false><<<unsigned(blocks_w), kBlock, 0, s>>>(            \
+        rows, rc, k_base, nnz, col, val, x, x_lo, x_hi, y, beta, tune.xcd_remap, nullptr, nullptr)
+#define LSK_CSRW_LAUNCH_DOT(L, KMAX)                                                              \
+    csr_spmv_wave_kernel<T, L, false, KMAX, true><<<unsigned(blocks_w), kBlock, 0, s>>>(          \
+        rows, rc, k_base, nnz, col, val, x, x_lo, x_hi, y, beta, tune.xcd_remap, w, partials)
 #define LSK_CSRW_CASE(L)                                                                          \
     case L:                                                                                       \
-        if (tune.csr_nontemporal) {                                                               \
+        if (fused) {                                                                              \
+            if (wide) LSK_CSRW_LAUNCH_DOT(L, 8);                                                  \
+            else LSK_CSRW_LAUNCH_DOT(L, 4);                                                       \
+        } else if (tune.csr_nontemporal) {                                                        \
             if (wide) LSK_CSRW_LAUNCH(L, true, 8);                                                \
             else LSK_CSRW_LAUNCH(L, true, 4);                                                     \
         } else {                                                                                  \
@@ -562,8 +639,10 @@ int launch_csr_spmv(const char *name, int64_t rows, int64_t nnz, const int64_t *
             LSK_CSRW_CASE(8)
         }
 #undef LSK_CSRW_LAUNCH
+#undef LSK_CSRW_LAUNCH_DOT
 #undef LSK_CSRW_CASE
         LSK_LAUNCH_CHECK();
+        if (fused) *count = blocks_w * 4;
         return LSK_OK;
     }
 
@@ -658,6 +737,31 @@ int tune_csr_spmv(const char *name, int64_t rows, int64_t nnz, const int64_t *re
 } // namespace
 
 extern "C" {
+
+int64_t lsk_csr_spmv_dot_partials(int64_t rows, int64_t nnz, int elem_size) {
+    if (rows <= 0) return 1;
+    const int log_rw = elem_size == 4 ? pick_log_rows_per_wave<float>(rows, nnz)
+                                      : pick_log_rows_per_wave<double>(rows, nnz);
+    return std::max<int64_t>(lsk::ceil_div(rows, int64_t(4) << log_rw) * 4, 1);
+}
+
+int lsk_csr_spmv_dot_f32(int64_t rows, int64_t nnz, const int64_t *rects, int64_t k_base,
+                         const int64_t *col, const float *val, const float *x, int64_t x_lo,
+                         int64_t x_hi, float *y, int beta, const float *w, float *partials,
+                         int64_t capacity, int64_t *count, lsk_stream_t stream) {
+    if (!w) return lsk::fail(LSK_ERR_ARG, "lsk_csr_spmv_dot_f32: null w");
+    return launch_csr_spmv<float>("lsk_csr_spmv_dot_f32", rows, nnz, rects, k_base, col, val, x, x_lo, x_hi,
+                                  y, beta, stream, w, partials, capacity, count);
+}
+
+int lsk_csr_spmv_dot_f64(int64_t rows, int64_t nnz, const int64_t *rects, int64_t k_base,
+                         const int64_t *col, const double *val, const double *x, int64_t x_lo,
+                         int64_t x_hi, double *y, int beta, const double *w, double *partials,
+                         int64_t capacity, int64_t *count, lsk_stream_t stream) {
+    if (!w) return lsk::fail(LSK_ERR_ARG, "lsk_csr_spmv_dot_f64: null w");
+    return launch_csr_spmv<double>("lsk_csr_spmv_dot_f64", rows, nnz, rects, k_base, col, val, x, x_lo, x_hi,
+                                   y, beta, stream, w, partials, capacity, count);
+}
 
 int lsk_csr_spmv_tune_f32(int64_t rows, int64_t nnz, const int64_t *rects, int64_t k_base,
                           const int64_t *col, const float *val, const float *x, int64_t x_lo,

@@ -46,6 +46,12 @@ class PartitionedVector:
             self.own_lo, self.own_hi = 0, -1
         self.data = ctx.backend.empty(self.pad_lo + self.local_size + self.pad_hi, dtype)
         self.owned = self.data[self.pad_lo:self.pad_lo + self.local_size]
+        # Bookkeeping of the fused leaf forms: `version` counts the writes made through this
+        # object's methods; `_ready` describes partial sums of a dot product of this vector's
+        # CURRENT contents with `partner` (possibly itself) that a fused kernel left behind.
+        self.version = 0
+        self._ready = None
+        self._partial_bufs = {}
 
     # -- accessors (src/PartitionedVector.hpp:52-72) ------------------------------------
     def get_name(self) -> str:
@@ -68,6 +74,29 @@ class PartitionedVector:
         off = self.piece_offsets[i]
         return self.owned[off:off + self.piece_sizes[i]]
 
+    def _touch(self) -> None:
+        """This vector is about to be (or was just) written: forget what was known about it."""
+        self.version += 1
+        self._ready = None
+
+    def _partials(self, kind: str, i: int, slots: int) -> torch.Tensor:
+        buf = self._partial_bufs.get((kind, i))
+        if buf is None or buf.numel() < slots:
+            buf = self.ctx.backend.empty(max(slots, 1), self.dtype)
+            self._partial_bufs[(kind, i)] = buf
+        return buf
+
+    def _note_ready(self, partner: "PartitionedVector", pieces) -> None:
+        """pieces[i] = (partials tensor or None, count): shares of sum over piece i of
+        self * partner, valid for the current contents of both."""
+        self._ready = (partner, partner.version, pieces)
+
+    def _ready_for(self, other: "PartitionedVector"):
+        r = self._ready
+        if r is not None and r[0] is other and other.version == r[1]:
+            return r[2]
+        return None
+
     def _check_same_shape(self, x: "PartitionedVector") -> None:
         # assert(index_space == x.get_index_space()) ... (src/PartitionedVector.cpp:214-216)
         if self.index_space != x.index_space or self.index_partition != x.index_partition:
@@ -89,6 +118,7 @@ class PartitionedVector:
     def constant_fill(self, value) -> None:
         if isinstance(value, Scalar):
             value = value.get_value()
+        self._touch()
         for i in range(len(self.piece_sizes)):
             if self.piece_sizes[i]:
                 self.ctx.backend.fill(self.piece(i), value)
@@ -99,6 +129,7 @@ class PartitionedVector:
     def assign(self, x: "PartitionedVector") -> "PartitionedVector":
         """operator=(const PartitionedVector &): index copy, piece by piece."""
         self._check_same_shape(x)
+        self._touch()
         for i in range(len(self.piece_sizes)):
             if self.piece_sizes[i]:
                 self.ctx.backend.copy(self.piece(i), x.piece(i))
@@ -107,21 +138,36 @@ class PartitionedVector:
     # -- BLAS-1 (src/PartitionedVector.cpp:195-358) ---------------------------------------
     def scal(self, alpha) -> None:
         futs = self._scalars([alpha])
+        self._touch()
         for i in range(len(self.piece_sizes)):
             if self.piece_sizes[i]:
                 self.ctx.backend.scal(self.piece(i), futs)
 
-    def axpy(self, *args) -> None:
+    def axpy(self, *args, speculate: bool = False) -> None:
         """axpy(alpha, x) | axpy(numer, denom, x) | axpy(numer1, numer2, denom, x):
-        self <- fma(get_alpha(scalars), x, self)."""
+        self <- fma(get_alpha(scalars), x, self).
+
+        speculate: use the fused axpy + squared-norm leaf, so that a dot(self, self) that
+        follows before the next write only has to add up the partial sums."""
         *scalars, x = args
         if not 1 <= len(scalars) <= 3:
             raise TypeError("axpy takes 1 to 3 scalars and a vector")
         self._check_same_shape(x)
         futs = self._scalars(scalars)
+        be = self.ctx.backend
+        fused = speculate and x is not self and getattr(be, "axpy_sqnorm", None) is not None
+        self._touch()
+        pieces = []
         for i in range(len(self.piece_sizes)):
-            if self.piece_sizes[i]:
-                self.ctx.backend.axpy(self.piece(i), futs, x.piece(i))
+            if not self.piece_sizes[i]:
+                pieces.append((None, 0))
+            elif fused:
+                buf = self._partials("sq", i, be.SQNORM_SLOTS)
+                pieces.append((buf, be.axpy_sqnorm(self.piece(i), futs, x.piece(i), buf)))
+            else:
+                be.axpy(self.piece(i), futs, x.piece(i))
+        if fused:
+            self._note_ready(self, pieces)
 
     def xpay(self, *args) -> None:
         """xpay(alpha, x) | xpay(numer, denom, x): self <- fma(get_alpha(scalars), self, x)."""
@@ -130,6 +176,7 @@ class PartitionedVector:
             raise TypeError("xpay takes 1 or 2 scalars and a vector")
         self._check_same_shape(x)
         futs = self._scalars(scalars)
+        self._touch()
         for i in range(len(self.piece_sizes)):
             if self.piece_sizes[i]:
                 self.ctx.backend.xpay(self.piece(i), futs, x.piece(i))
@@ -140,12 +187,20 @@ class PartitionedVector:
         self._check_same_shape(x)
         be = self.ctx.backend
         n = len(self.piece_sizes)
+        ready = self._ready_for(x) or x._ready_for(self)  # partial sums a fused leaf left behind
+
+        def piece_dot(i, dst):
+            if ready is not None:
+                be.sum_partials(ready[i][1], ready[i][0], dst)
+            else:
+                be.dot(self.piece(i), x.piece(i), dst)
+
         if n == 1:
-            be.dot(self.piece(0), x.piece(0), out)
+            piece_dot(0, out)
         else:
             slots = be.empty(n, self.dtype)
             for i in range(n):
-                be.dot(self.piece(i), x.piece(i), slots[i:i + 1])
+                piece_dot(i, slots[i:i + 1])
             be.sum_scalars(slots, out)
 
     def dot(self, x: "PartitionedVector") -> Scalar:

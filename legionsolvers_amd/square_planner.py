@@ -48,6 +48,10 @@ class SquarePlanner:
         self.rhs_vectors: List[PartitionedVector] = []
         self.workspace_vectors: List[List[PartitionedVector]] = []
         self.row_partitioned_matrices: List[_MatrixEntry] = []
+        # bets of the fused product + dot (see _fused_dot_pays)
+        self._fused_dot_issued = 0
+        self._fused_dot_used = 0
+        self._fused_dot_pending = None
 
     def get_context(self):
         return self.ctx
@@ -160,8 +164,11 @@ class SquarePlanner:
         """axpy(dst, alpha, src) | axpy(dst, numer, denom, src) | axpy(dst, n1, n2, denom, src)."""
         *scalars, src_index = args
         scalars = [self._scalar(s) for s in scalars]
+        # Workspace vectors are only ever written through the planner, so the fused
+        # axpy + squared norm can serve a dot(dst, dst) that follows (CG: r.r after r -= a q).
+        speculate = self.ctx.fuse and dst_index >= 2
         for i in range(self.get_num_spaces()):
-            self.get_vector(dst_index, i).axpy(*scalars, self.get_vector(src_index, i))
+            self.get_vector(dst_index, i).axpy(*scalars, self.get_vector(src_index, i), speculate=speculate)
 
     def xpay(self, dst_index: int, *args) -> None:
         """xpay(dst, alpha, src) | xpay(dst, numer, denom, src)."""
@@ -176,6 +183,9 @@ class SquarePlanner:
         added left to right, as the reference's chain of AddScalarTasks does."""
         n = self.get_num_spaces()
         be = self.ctx.backend
+        if self._fused_dot_pending is not None and self._fused_dot_pending == frozenset((v_idx, w_idx)):
+            self._fused_dot_used += 1
+        self._fused_dot_pending = None
         slots = be.empty(n, self.dtype)
         for i in range(n):
             self.get_vector(v_idx, i).dot_local(self.get_vector(w_idx, i), slots[i:i + 1])
@@ -216,6 +226,16 @@ class SquarePlanner:
         always accumulates, onto a zero fill if it comes first.  The result equals the
         reference's zero_fill followed by accumulating matvecs."""
         touched = set()
+        writers = {}
+        for e in self.row_partitioned_matrices:
+            writers[e.range_index] = writers.get(e.range_index, 0) + 1
+        # dot(src, dst) usually follows (CG's p.Ap): where one CSR matrix alone produces a range
+        # space and both vectors are planner workspace, its product leaves that dot's partial
+        # sums behind -- for short rows only, where the saved pass over two vectors outweighs
+        # what the fused kernel costs (CSRMatrix.fuses_dot).
+        fuse = (self.ctx.fuse and dst_idx >= 2 and src_idx >= 2 and dst_idx != src_idx
+                and self._fused_dot_pays())
+        fused_any = False
         for e in self.row_partitioned_matrices:
             dst = self.get_vector(dst_idx, e.range_index)
             src = self.get_vector(src_idx, e.domain_index)
@@ -226,8 +246,23 @@ class SquarePlanner:
                 if first:
                     dst.zero_fill()
                 e.matrix.matvec(dst, x, x_lo, x_hi, e.kernel_partition, 1)
+            elif fuse and first and writers[e.range_index] == 1 and e.matrix.fuses_dot():
+                e.matrix.matvec(dst, x, x_lo, x_hi, e.kernel_partition, 0,
+                                dot_with=self.get_vector(src_idx, e.range_index))
+                fused_any = True
             else:
                 e.matrix.matvec(dst, x, x_lo, x_hi, e.kernel_partition, 0 if first else 1)
         for i in range(self.get_num_spaces()):
             if i not in touched:
                 self.get_vector(dst_idx, i).zero_fill()
+        if fused_any:
+            self._fused_dot_issued += 1
+            self._fused_dot_pending = frozenset((dst_idx, src_idx))
+        else:
+            self._fused_dot_pending = None
+
+    def _fused_dot_pays(self) -> bool:
+        """The fused product + dot is a bet on the caller's next dot product (CG wins it every
+        step, GMRES once in 31 products, BiCGStab never): after a few products, keep betting
+        only while at least half of the bets were won."""
+        return self._fused_dot_issued < 4 or 2 * self._fused_dot_used >= self._fused_dot_issued

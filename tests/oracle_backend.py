@@ -56,6 +56,29 @@ class OracleBackend:
     def xpay(self, y, futs, x):
         oracle.xpay(self._alpha(futs, y.dtype), _np(x), _np(y))
 
+    # fused forms: one partial sum each, formed by the oracle's own sequential dot
+    SQNORM_SLOTS = 1
+
+    def axpy_sqnorm(self, y, futs, x, partials):
+        self.axpy(y, futs, x)
+        partials[0] = float(oracle.dot(_np(y), _np(y)))
+        return 1
+
+    def csr_spmv_dot_slots(self, rows, nnz, dtype):
+        return 1
+
+    def csr_spmv_dot(self, rows, nnz, rects, k_base, col, val, x, x_lo, x_hi, y, beta, w, partials, placement=0):
+        self.csr_spmv(rows, nnz, rects, k_base, col, val, x, x_lo, x_hi, y, beta)
+        partials[0] = float(oracle.dot(_np(w), _np(y)))
+        return 1
+
+    def sum_partials(self, count, partials, out):
+        a = _np(partials)[:count] if count else np.zeros(0)
+        acc = a.dtype.type(0) if count else 0.0
+        for i in range(count):
+            acc = acc + a[i]
+        out[0] = float(acc)
+
     def dot(self, v, w, out):
         out[0] = float(oracle.dot(_np(v), _np(w))) if v.numel() else 0.0
 

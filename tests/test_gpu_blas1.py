@@ -269,3 +269,68 @@ def test_rccl_layer_single_rank():
     cnt = (ctypes.c_int64 * 1)(1)
     assert lib.lsk_halo_exchange_f64(comm, 1, bad_peer, ptrs, cnt, 0, None, None, None, stream()) == -2
     _lib.check(lib.lsk_comm_destroy(comm))
+
+
+@pytest.mark.parametrize("suf", ["f32", "f64"])
+@pytest.mark.parametrize("offset", [0, 1])
+def test_axpy_sqnorm_and_sum_partials(suf, offset):
+    """The fused axpy + squared norm: y bit-exact with the plain axpy (host and device alpha);
+    the partial sums add up to dot(y, y) within the dot tolerance, reproducibly."""
+    npdt, tdt = DT[suf]
+    tol = 1e-13 if suf == "f64" else 2e-6
+    rng = np.random.default_rng(17)
+    for n in SIZES + [(1 << 22) + 11]:
+        x = rng.standard_normal(n + offset).astype(npdt)
+        y = rng.standard_normal(n + offset).astype(npdt)
+        alpha = npdt(rng.standard_normal())
+        print(f"case axpy_sqnorm_{suf} n={n} offset={offset}", flush=True)
+        want = y.copy()
+        oracle.axpy(alpha, np.ascontiguousarray(x[offset:]), want[offset:])
+        exact = float(np.sum(want[offset:].astype(np.float64) ** 2))
+        results = []
+        for form in ("host", "dev", "dev"):
+            xd, yd = dev(x), dev(y)
+            partials = torch.full((2048,), 7.0, dtype=tdt, device="cuda")
+            count = ctypes.c_int(-1)
+            if form == "host":
+                _lib.call(f"lsk_axpy_sqnorm_{suf}", n, float(alpha), P(xd[offset:]), P(yd[offset:]), P(partials),
+                          2048, ctypes.byref(count), stream())
+            else:
+                # alpha = (f0 * f1) / f2 on the device, chosen to reproduce alpha exactly
+                f = dev(np.array([alpha, 1.0, 1.0], dtype=npdt))
+                _lib.call(f"lsk_axpy_sqnorm_dev_{suf}", n, 3, P(f[0:1]), P(f[1:2]), P(f[2:3]), None,
+                          P(xd[offset:]), P(yd[offset:]), P(partials), 2048, ctypes.byref(count), stream())
+            assert np.array_equal(bits(yd.cpu().numpy()), bits(want)), (n, form)
+            assert (count.value == 0) == (n == 0) and count.value <= 2048
+            out = torch.full((1,), -1.0, dtype=tdt, device="cuda")
+            _lib.call(f"lsk_sum_partials_{suf}", count.value, P(partials), P(out), None, 0, stream())
+            assert abs(float(out) - exact) <= tol * max(exact, 1e-300) + 1e-300, (n, form)
+            results.append(float(out))
+        assert results[1] == results[2] == results[0]  # bit-reproducible
+    # too little room for the partial sums is an error, not a silent truncation
+    xd, yd = dev(np.ones(1 << 20, npdt)), dev(np.ones(1 << 20, npdt))
+    small = torch.zeros(4, dtype=tdt, device="cuda")
+    count = ctypes.c_int(0)
+    assert _lib.lib().lsk_axpy_sqnorm_f64 is not None
+    rc = getattr(_lib.lib(), f"lsk_axpy_sqnorm_{suf}")(1 << 20, 1.0, P(xd), P(yd), P(small), 4, ctypes.byref(count), stream())
+    assert rc == -2
+
+
+@pytest.mark.parametrize("suf", ["f32", "f64"])
+def test_sum_partials_two_stage(suf):
+    """Counts that take the two-stage path, against an exactly rounded sum."""
+    npdt, tdt = DT[suf]
+    tol = 1e-13 if suf == "f64" else 2e-6
+    rng = np.random.default_rng(19)
+    for count in (0, 1, 255, 8192, 8193, 100_003, 4_194_304):
+        v = rng.standard_normal(count).astype(npdt)
+        print(f"case sum_partials_{suf} count={count}", flush=True)
+        out = torch.full((1,), -1.0, dtype=tdt, device="cuda")
+        vd = dev(v) if count else torch.zeros(1, dtype=tdt, device="cuda")
+        ws = torch.empty(_lib.lib().lsk_dot_workspace_bytes(0), dtype=torch.uint8, device="cuda")
+        _lib.call(f"lsk_sum_partials_{suf}", count, P(vd), P(out), P(ws), ws.numel(), stream())
+        exact = float(np.sum(v.astype(np.float64)))
+        assert abs(float(out) - exact) <= tol * float(np.sum(np.abs(v.astype(np.float64)))) + 1e-300
+        out2 = torch.full((1,), -1.0, dtype=tdt, device="cuda")
+        _lib.call(f"lsk_sum_partials_{suf}", count, P(vd), P(out2), None, 0, stream())
+        assert float(out2) == float(out)

@@ -292,6 +292,69 @@ def test_coo_spmv(suf, coo_variant):
 
 
 @pytest.mark.parametrize("suf", ["f32", "f64"])
+def test_csr_spmv_dot(suf):
+    """The fused product + dot: y bit-identical with the plain product, the partial sums add up
+    to dot(y, w); regular tiles, batched tiles, irregular rows, empty pieces, beta = 1."""
+    npdt, tdt, tol = DT[suf]
+    rng = np.random.default_rng(33)
+    n_cols = 5000
+    cases = {}
+    offs, cfs = oracle.benchmark_stencil_offsets(4)
+    r, _, c, v = oracle.linearized_stencil((20, 18, 22), offs, cfs, dtype=npdt)
+    cases["stencil27"] = (r, c, v, r.shape[0])
+    offs, cfs = oracle.benchmark_stencil_offsets(3)
+    r, _, c, v = oracle.linearized_stencil((30, 31, 29), offs, cfs, dtype=npdt)
+    cases["stencil7"] = (r, c, v, r.shape[0])
+    lens = rng.integers(0, 6, size=3000)
+    lens[::97] = 3000
+    starts = np.concatenate([[0], np.cumsum(lens)])
+    cases["short-and-long"] = (np.stack([starts[:-1], starts[1:] - 1], axis=1).astype(np.int64),
+                               rng.integers(0, n_cols, size=int(starts[-1])).astype(np.int64),
+                               rng.standard_normal(int(starts[-1])).astype(npdt), n_cols)
+    lens = rng.integers(0, 40, size=700)
+    starts = np.concatenate([[0], np.cumsum(lens)])
+    rects = np.stack([starts[:-1], starts[1:] - 1], axis=1).astype(np.int64)
+    cases["permuted"] = (np.ascontiguousarray(rects[rng.permutation(700)]),
+                         rng.integers(0, n_cols, size=int(starts[-1])).astype(np.int64),
+                         rng.standard_normal(int(starts[-1])).astype(npdt), n_cols)
+    for name, (rects, col, val, ncol) in cases.items():
+        rows = rects.shape[0]
+        x = rng.standard_normal(ncol).astype(npdt)
+        w = rng.standard_normal(rows).astype(npdt)
+        y0 = rng.standard_normal(rows).astype(npdt)
+        for beta in (0, 1):
+            print(f"case csr_spmv_dot_{suf} {name} rows={rows} beta={beta}", flush=True)
+            rd, cd, vd, xd, wd = dev(rects), dev(col), dev(val), dev(x), dev(w)
+            y_plain, y_fused = dev(y0), dev(y0)
+            _lib.call(f"lsk_csr_spmv_{suf}", rows, val.size, P(rd), 0, P(cd), P(vd), P(xd), 0, ncol - 1,
+                      P(y_plain), beta, stream())
+            slots = _lib.lib().lsk_csr_spmv_dot_partials(rows, val.size, np.dtype(npdt).itemsize)
+            partials = torch.full((slots,), 5.0, dtype=tdt, device="cuda")
+            count = ctypes.c_int64(-1)
+            _lib.call(f"lsk_csr_spmv_dot_{suf}", rows, val.size, P(rd), 0, P(cd), P(vd), P(xd), 0, ncol - 1,
+                      P(y_fused), beta, P(wd), P(partials), slots, ctypes.byref(count), stream())
+            assert 0 < count.value <= slots
+            assert torch.equal(y_plain, y_fused)
+            out = torch.zeros(1, dtype=tdt, device="cuda")
+            _lib.call(f"lsk_sum_partials_{suf}", count.value, P(partials), P(out), None, 0, stream())
+            yh = y_fused.cpu().numpy().astype(np.float64)
+            exact = float(np.sum(yh * w))
+            bound = float(np.sum(np.abs(yh * w)))
+            assert abs(float(out) - exact) <= (1e-13 if suf == "f64" else 2e-6) * bound + 1e-300
+            # one slot too few is refused
+            rc = getattr(_lib.lib(), f"lsk_csr_spmv_dot_{suf}")(
+                rows, val.size, P(rd), 0, P(cd), P(vd), P(xd), 0, ncol - 1, P(y_fused), beta, P(wd),
+                P(partials), count.value - 1, ctypes.byref(count), stream())
+            assert rc == -2
+    # no rows: nothing to add up
+    count = ctypes.c_int64(-1)
+    one = torch.zeros(1, dtype=tdt, device="cuda")
+    _lib.call(f"lsk_csr_spmv_dot_{suf}", 0, 0, None, 0, None, None, None, 0, -1, None, 0, P(one), P(one), 1,
+              ctypes.byref(count), stream())
+    assert count.value == 0
+
+
+@pytest.mark.parametrize("suf", ["f32", "f64"])
 def test_csr_spmv_tune(suf):
     """The set-up-time placement tuner: returns one of its candidates with a positive time,
     leaves y = A x behind and the library option as it was."""
