@@ -320,6 +320,17 @@ int lsk_coo_spmv_f64(int64_t nnz, const int64_t *row, const int64_t *col, const 
 int lsk_index_bounds_i64(int64_t n, const int64_t *idx, int64_t *out_minmax,
                          lsk_stream_t stream);
 
+/* Which rows of a CSR piece read columns outside lo..hi: out[0] <- the largest row index (0-based
+ * in the piece) that has a column below lo, or -1; out[1] <- the smallest row index that has a
+ * column above hi, or `rows`.  Rows strictly between them read only lo..hi.  With lo..hi = the
+ * interval of x a process owns, those are the rows whose product does not wait for the ghost
+ * cells: the caller launches them while the halo is still in flight.  What Legion does implicitly
+ * by starting a matvec point task as soon as ITS ghost copy has landed
+ * (src/CSRMatrix.cpp:202-211).  Arguments as lsk_csr_spmv_*. */
+int lsk_csr_halo_rows_i64(int64_t rows, int64_t nnz, const int64_t *rects, int64_t k_base,
+                          const int64_t *col, int64_t lo, int64_t hi, int64_t *out,
+                          lsk_stream_t stream);
+
 /* Linearised stencil matrices, bit-identical to FillLinearizedCSRStencilTask /
  * FillLinearizedCOOStencilTask with IndexOrder::ROW_MAJOR (src/StencilGenerator.cpp:129-242,
  * 379-517): grid bounds [0,extent[d]) in `dim` (1..3) dimensions, row id = row-major

@@ -70,6 +70,7 @@ PROTOTYPES = {
     "lsk_csr_spmv_dot_partials": (_i64, [_i64, _i64, _i]),
     "lsk_rects_to_indptr_i64": (_i, [_i64, _p, _p, _p]),
     "lsk_index_bounds_i64": (_i, [_i64, _p, _p, _p]),
+    "lsk_csr_halo_rows_i64": (_i, [_i64, _i64, _p, _i64, _p, _i64, _i64, _p, _p]),
     "lsk_stencil_count": (_i, [_i, _p, _i, _p, _i64, _i64, _p, _p]),
     "lsk_rects_from_counts_i64": (_i, [_i64, _p, _p, _i64, _p, _p]),
     "lsk_task_id_t": (_i64, [_i, _i]),

@@ -148,6 +148,16 @@ class HipBackend:
                   _ptr(x), x_lo, x_hi, _ptr(y), y_lo, y_hi, self.stream())
 
     # -- set-up ------------------------------------------------------------------------------
+    def csr_halo_rows(self, rows: int, nnz: int, rects: torch.Tensor, k_base: int, col: torch.Tensor,
+                      lo: int, hi: int) -> Tuple[int, int]:
+        """(largest row with a column below lo or -1, smallest row with a column above hi or
+        rows) of a CSR piece.  Synchronises."""
+        out = torch.empty(2, dtype=torch.int64, device=self.device)
+        _lib.call("lsk_csr_halo_rows_i64", rows, nnz, _ptr(rects), k_base, _ptr(col), lo, hi, _ptr(out),
+                  self.stream())
+        below, above = out.tolist()
+        return int(below), int(above)
+
     def index_bounds(self, idx: torch.Tensor) -> Tuple[int, int]:
         """(min, max) of an index field; (0, -1) when it is empty.  Synchronises."""
         if idx.numel() == 0:

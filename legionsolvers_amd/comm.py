@@ -120,14 +120,23 @@ class Communicator:
 
     def exchange(self, sends: Sequence[Tuple[int, torch.Tensor]],
                  recvs: Sequence[Tuple[int, torch.Tensor]]) -> None:
-        """Grouped point-to-point exchange: (peer, contiguous tensor view) pairs.  Receives
-        are posted in ascending peer order and sends likewise, so that both sides of every
-        pair agree on the order of the operations between them."""
+        """Grouped point-to-point exchange: (peer, contiguous tensor view) pairs."""
+        self.exchange_finish(self.exchange_start(sends, recvs))
+
+    def exchange_start(self, sends: Sequence[Tuple[int, torch.Tensor]],
+                       recvs: Sequence[Tuple[int, torch.Tensor]]):
+        """Posts the exchange and returns a handle for exchange_finish.  With RCCL the transfers
+        run on the communicator's own stream, ordered after everything already enqueued on the
+        current stream; kernels enqueued on the current stream between start and finish overlap
+        with them and must not touch the receive views.  Receives are posted in ascending peer
+        order and sends likewise, so that both sides of every pair agree on the order of the
+        operations between them."""
         if self.world_size == 1 or (not sends and not recvs):
-            return
+            return None
         recvs = sorted(recvs, key=lambda it: it[0])
         sends = sorted(sends, key=lambda it: it[0])
         staged = any(self._staged(t) for _, t in list(recvs) + list(sends))
+        landing = None
         if staged:  # .cpu() synchronises with the stream that produced the data
             landing = [(peer, t, torch.empty(t.shape, dtype=t.dtype)) for peer, t in recvs]
             recvs = [(peer, host) for peer, _, host in landing]
@@ -137,9 +146,16 @@ class Communicator:
             ops.append(dist.P2POp(dist.irecv, t, self._global_rank(peer), group=self.group))
         for peer, t in sends:
             ops.append(dist.P2POp(dist.isend, t, self._global_rank(peer), group=self.group))
-        for work in dist.batch_isend_irecv(ops):
+        return dist.batch_isend_irecv(ops), landing, sends
+
+    def exchange_finish(self, handle) -> None:
+        """Makes the current stream (and, for host transports, the host) wait for the exchange."""
+        if handle is None:
+            return
+        works, landing, _keep_alive = handle
+        for work in works:
             work.wait()
-        if staged:
+        if landing is not None:
             for _, t, host in landing:
                 t.copy_(host)
 

@@ -192,9 +192,71 @@ int launch_fill(const char *name, int dim, const int64_t *extent, int noffsets,
     return LSK_OK;
 }
 
+// Which rows of a CSR piece read columns outside lo..hi?  out[0] <- largest row index with a
+// column below lo (-1 if none), out[1] <- smallest row index with a column above hi (rows if
+// none).  One thread per row; rects are clipped to the piece.
+__global__ void halo_rows_init_kernel(long long *out, long long rows) {
+    out[0] = -1;
+    out[1] = rows;
+}
+
+__global__ __launch_bounds__(kBlock) void halo_rows_kernel(long long rows, long long nnz,
+                                                           const long long *__restrict__ rects,
+                                                           long long k_base,
+                                                           const long long *__restrict__ col,
+                                                           long long lo, long long hi,
+                                                           long long *__restrict__ out) {
+    long long last_below = -1, first_above = rows;
+    const long long stride = static_cast<long long>(gridDim.x) * kBlock;
+    for (long long r = static_cast<long long>(blockIdx.x) * kBlock + threadIdx.x; r < rows; r += stride) {
+        long long k0 = rects[2 * r] - k_base, k1 = rects[2 * r + 1] - k_base;
+        k0 = k0 < 0 ? 0 : k0;
+        k1 = k1 > nnz - 1 ? nnz - 1 : k1;
+        bool below = false, above = false;
+        for (long long k = k0; k <= k1; ++k) {
+            const long long c = col[k];
+            below = below || c < lo;
+            above = above || c > hi;
+        }
+        if (below) last_below = r; // r ascends per thread
+        if (above && r < first_above) first_above = r;
+    }
+#pragma unroll
+    for (int off = lsk::kWave / 2; off > 0; off >>= 1) {
+        const long long ob = __shfl_xor(last_below, off, lsk::kWave);
+        const long long oa = __shfl_xor(first_above, off, lsk::kWave);
+        last_below = ob > last_below ? ob : last_below;
+        first_above = oa < first_above ? oa : first_above;
+    }
+    if (threadIdx.x % lsk::kWave == 0) {
+        if (last_below >= 0) atomicMax(&out[0], last_below);
+        if (first_above < rows) atomicMin(&out[1], first_above);
+    }
+}
+
 } // namespace
 
 extern "C" {
+
+int lsk_csr_halo_rows_i64(int64_t rows, int64_t nnz, const int64_t *rects, int64_t k_base,
+                          const int64_t *col, int64_t lo, int64_t hi, int64_t *out,
+                          lsk_stream_t stream) {
+    if (rows < 0 || nnz < 0) return lsk::fail(LSK_ERR_ARG, "lsk_csr_halo_rows_i64: negative size");
+    if (!out) return lsk::fail(LSK_ERR_ARG, "lsk_csr_halo_rows_i64: null output");
+    hipStream_t s = lsk::as_stream(stream);
+    halo_rows_init_kernel<<<1, 1, 0, s>>>(reinterpret_cast<long long *>(out), rows);
+    LSK_LAUNCH_CHECK();
+    if (rows == 0 || nnz == 0) return LSK_OK;
+    if (!rects || !col) return lsk::fail(LSK_ERR_ARG, "lsk_csr_halo_rows_i64: null input");
+    int blocks = grid_for(rows);
+    if (blocks > 16 * lsk::kMaxGridBlocks) blocks = 16 * lsk::kMaxGridBlocks;
+    halo_rows_kernel<<<blocks, kBlock, 0, s>>>(rows, nnz, reinterpret_cast<const long long *>(rects), k_base,
+                                               reinterpret_cast<const long long *>(col), lo, hi,
+                                               reinterpret_cast<long long *>(out));
+    LSK_LAUNCH_CHECK();
+    return LSK_OK;
+}
+
 
 int lsk_stencil_count(int dim, const int64_t *extent, int noffsets, const int64_t *offsets,
                       int64_t row_lo, int64_t row_hi, int64_t *counts, lsk_stream_t stream) {

@@ -108,6 +108,45 @@ class CSRMatrix(AbstractMatrix):
             self.placement[c], _ = tuner(p.volume, nnz, self.rects[r0:r0 + p.volume], k_lo,
                                          self.col[off:off + nnz], self.val[off:off + nnz], x, x_lo, x_hi, y)
 
+    def halo_split(self, own_lo: int, own_hi: int, kernel_partition, range_partition):
+        """For every local piece, its rows in three runs: [0, a) read ghost cells below own_lo,
+        [a, rows - b) read only own_lo..own_hi, [rows - b, rows) read ghost cells above own_hi;
+        each run with the kernel interval its rects cover.  The middle runs can be multiplied
+        while the halo is still in flight.  Returns {piece: [(phase, r_begin, r_end, k_lo, k_hi)]}
+        with phase 0 = needs no ghost cell, 1 = does, or None when the rects of a piece are not
+        back to back (then a run's kernel interval is not simply its first and last rect)."""
+        be = self.ctx.backend
+        finder = getattr(be, "csr_halo_rows", None)
+        if finder is None:
+            return None
+        out = {}
+        for i, c in enumerate(kernel_partition.colors):
+            p = range_partition.pieces[c]
+            rows = p.volume
+            k_lo, k_hi = kernel_partition.intervals[i]
+            nnz = max(k_hi - k_lo + 1, 0)
+            if rows == 0 or nnz == 0:
+                continue
+            r0 = p.lo[0] - self.row_lo
+            rects = self.rects[r0:r0 + rows]
+            if rows > 1 and not bool((rects[1:, 0] == rects[:-1, 1] + 1).all()):
+                return None
+            off = k_lo - self.k_base
+            below, above = finder(rows, nnz, rects, k_lo, self.col[off:off + nnz], own_lo, own_hi)
+            a, b0 = below + 1, above          # [0, a) and [b0, rows) need ghost cells
+            if a >= b0:                       # they meet: nothing to run early
+                out[i] = [(1, 0, rows, k_lo, k_hi)]
+                continue
+            cuts = [0, a, b0, rows]
+            edge = rects[[min(a, rows - 1), min(b0, rows - 1)], 0].tolist()  # first entries of rows a, b0
+            k_cut = [k_lo, edge[0] if a < rows else k_hi + 1, edge[1] if b0 < rows else k_hi + 1, k_hi + 1]
+            runs = []
+            for j, phase in enumerate((1, 0, 1)):
+                if cuts[j + 1] > cuts[j]:
+                    runs.append((phase, cuts[j], cuts[j + 1], k_cut[j], k_cut[j + 1] - 1))
+            out[i] = runs
+        return out
+
     def create_kernel_partition_from_range_partition(self, range_partition):
         """Image-range of the rowptr rects over each piece's rows (src/CSRMatrix.cpp:89-109)."""
         colors = range_partition.colors_of_rank(self.ctx.rank, self.ctx.world_size)
@@ -127,15 +166,20 @@ class CSRMatrix(AbstractMatrix):
         """Image of the column field over each kernel piece (src/CSRMatrix.cpp:112-132)."""
         return _ghost_from_kernel(self.ctx, self.col, self.k_base, domain_space, kernel_partition)
 
-    def matvec(self, dst, x, x_lo, x_hi, kernel_partition, beta, range_partition=None, dot_with=None):
+    def matvec(self, dst, x, x_lo, x_hi, kernel_partition, beta, range_partition=None, dot_with=None,
+               split=None, phase=None):
         """CSRMatrix::matvec (src/CSRMatrix.cpp:158-214): one csr_matvec leaf per piece.
 
         dot_with: a vector on dst's partition; the fused product + dot leaf then also leaves
         the partial sums of dot(dst, dot_with) with dst (a speed hint for the dot product a
-        Krylov step takes next; only with beta = 0)."""
+        Krylov step takes next; only with beta = 0).
+        split, phase: with the result of halo_split, launch only the runs of rows of that phase
+        (0: those that need no ghost cell, 1: the others); both phases together are the whole
+        product."""
         range_partition = range_partition or dst.index_partition
         be = self.ctx.backend
-        fused = dot_with is not None and beta == 0 and getattr(be, "csr_spmv_dot", None) is not None
+        fused = (dot_with is not None and beta == 0 and split is None
+                 and getattr(be, "csr_spmv_dot", None) is not None)
         touch = getattr(dst, "_touch", None)
         if touch is not None:
             touch()
@@ -149,6 +193,18 @@ class CSRMatrix(AbstractMatrix):
             r0 = p.lo[0] - self.row_lo
             k_lo, k_hi = kernel_partition.intervals[i]
             nnz = max(k_hi - k_lo + 1, 0)
+            if split is not None and i in split:
+                for run_phase, ra, rb, ka, kb in split[i]:
+                    if run_phase != phase:
+                        continue
+                    n_run = max(kb - ka + 1, 0)
+                    off = (ka - self.k_base) if n_run else 0
+                    be.csr_spmv(rb - ra, n_run, self.rects[r0 + ra:r0 + rb], ka if n_run else self.k_base,
+                                self.col[off:off + n_run], self.val[off:off + n_run], x, x_lo, x_hi,
+                                dst.piece(i)[ra:rb], beta, self.placement.get(c, 0))
+                continue
+            if split is not None and phase == 0:
+                continue  # a piece without a split entry (no entries) goes with the late phase
             off = (k_lo - self.k_base) if nnz else 0
             args = (rows, nnz, self.rects[r0:r0 + rows], k_lo if nnz else self.k_base,
                     self.col[off:off + nnz], self.val[off:off + nnz], x, x_lo, x_hi, dst.piece(i), beta)

@@ -9,6 +9,7 @@ room of the source vector.
 """
 from __future__ import annotations
 
+import os
 from typing import List, Tuple
 
 import torch
@@ -28,13 +29,15 @@ def _hull(intervals) -> Tuple[int, int]:
 
 
 class _MatrixEntry:
-    def __init__(self, matrix, domain_index, range_index, kernel_partition, ghost_partition, plan):
+    def __init__(self, matrix, domain_index, range_index, kernel_partition, ghost_partition, plan,
+                 split=None):
         self.matrix = matrix
         self.domain_index = domain_index
         self.range_index = range_index
         self.kernel_partition: PiecePartition = kernel_partition
         self.ghost_partition: PiecePartition = ghost_partition
         self.plan: HaloPlan = plan
+        self.split = split   # CSRMatrix.halo_split: rows that can be multiplied before the halo lands
         self.staging = None  # ghost buffer for source vectors without halo room
 
 
@@ -111,8 +114,15 @@ class SquarePlanner:
             window = _hull(ghost_partition.intervals)
             tune(window[0], window[1], kernel_partition, range_partition)
             matrix._tuned = True
+        split = None
+        if plan.recvs and getattr(matrix, "halo_split", None) is not None \
+                and os.environ.get("LSK_OVERLAP", "1") != "0":
+            own_lo, own_hi = domain_partition.rank_interval(rank, world)
+            split = matrix.halo_split(own_lo, own_hi, kernel_partition, range_partition)
+            if split is not None and not any(run[0] == 0 for runs in split.values() for run in runs):
+                split = None  # every row waits for the halo anyway
         self.row_partitioned_matrices.append(
-            _MatrixEntry(matrix, domain_index, range_index, kernel_partition, ghost_partition, plan))
+            _MatrixEntry(matrix, domain_index, range_index, kernel_partition, ghost_partition, plan, split))
 
     def _halo_pad(self, space_index: int) -> Tuple[int, int]:
         lo = hi = 0
@@ -198,12 +208,13 @@ class SquarePlanner:
 
     # -- matvec (src/SquarePlanner.hpp:340-357) ---------------------------------------------
     def _gather_ghost(self, e: _MatrixEntry, src: PartitionedVector):
-        """Returns (x tensor, x_lo, x_hi): the ghost instance of `src` for matrix entry `e`,
-        after bringing in the cells other ranks own."""
+        """Returns (x tensor, x_lo, x_hi, handle): the ghost instance of `src` for matrix entry
+        `e`, with the transfer of the cells other ranks own posted; it has landed once
+        comm.exchange_finish(handle) has been called (handle None: nothing to wait for)."""
         plan = e.plan
         own_lo, own_hi = src.own_lo, src.own_hi
         if not plan.recvs and not plan.sends:
-            return src.owned, own_lo, own_hi
+            return src.owned, own_lo, own_hi, None
         if src.pad_lo >= plan.pad_lo and src.pad_hi >= plan.pad_hi:
             buf, base = src.data, own_lo - src.pad_lo      # gather in place
         else:
@@ -215,10 +226,10 @@ class SquarePlanner:
                 self.ctx.backend.copy(buf[plan.pad_lo:plan.pad_lo + src.local_size], src.owned)
         sends = [(t.peer, src.owned[t.start - own_lo:t.start - own_lo + t.count]) for t in plan.sends]
         recvs = [(t.peer, buf[t.start - base:t.start - base + t.count]) for t in plan.recvs]
-        self.ctx.comm.exchange(sends, recvs)
+        handle = self.ctx.comm.exchange_start(sends, recvs)
         x_lo = own_lo - plan.pad_lo
         x_hi = own_hi + plan.pad_hi
-        return buf[x_lo - base:x_hi - base + 1], x_lo, x_hi
+        return buf[x_lo - base:x_hi - base + 1], x_lo, x_hi, handle
 
     def matvec(self, dst_idx: int, src_idx: int) -> None:
         """dst <- A src over all registered matrices.  The first CSR matrix into a range space
@@ -241,16 +252,26 @@ class SquarePlanner:
             src = self.get_vector(src_idx, e.domain_index)
             first = e.range_index not in touched
             touched.add(e.range_index)
-            x, x_lo, x_hi = self._gather_ghost(e, src)
+            x, x_lo, x_hi, handle = self._gather_ghost(e, src)
+            comm = self.ctx.comm
             if isinstance(e.matrix, COOMatrix):
+                comm.exchange_finish(handle)
                 if first:
                     dst.zero_fill()
                 e.matrix.matvec(dst, x, x_lo, x_hi, e.kernel_partition, 1)
             elif fuse and first and writers[e.range_index] == 1 and e.matrix.fuses_dot():
+                comm.exchange_finish(handle)
                 e.matrix.matvec(dst, x, x_lo, x_hi, e.kernel_partition, 0,
                                 dot_with=self.get_vector(src_idx, e.range_index))
                 fused_any = True
+            elif e.split is not None and handle is not None:
+                # rows that read no ghost cell are multiplied while the halo is in flight
+                beta = 0 if first else 1
+                e.matrix.matvec(dst, x, x_lo, x_hi, e.kernel_partition, beta, split=e.split, phase=0)
+                comm.exchange_finish(handle)
+                e.matrix.matvec(dst, x, x_lo, x_hi, e.kernel_partition, beta, split=e.split, phase=1)
             else:
+                comm.exchange_finish(handle)
                 e.matrix.matvec(dst, x, x_lo, x_hi, e.kernel_partition, 0 if first else 1)
         for i in range(self.get_num_spaces()):
             if i not in touched:

@@ -99,6 +99,20 @@ class OracleBackend:
     def coo_spmv(self, nnz, row, col, val, x, x_lo, x_hi, y, y_lo, y_hi):
         oracle.coo_matvec(_np(row), _np(col), _np(val), _np(x), x_lo, x_hi, _np(y), y_lo, y_hi)
 
+    def csr_halo_rows(self, rows, nnz, rects, k_base, col, lo, hi):
+        r, c = _np(rects), _np(col)
+        below, above = -1, rows
+        for i in range(rows):
+            k0, k1 = max(int(r[i, 0]) - k_base, 0), min(int(r[i, 1]) - k_base, nnz - 1)
+            if k1 < k0:
+                continue
+            seg = c[k0:k1 + 1]
+            if (seg < lo).any():
+                below = i
+            if (seg > hi).any() and above == rows:
+                above = i
+        return below, above
+
     def index_bounds(self, idx):
         return part.bounds(_np(idx))
 

@@ -390,6 +390,33 @@ def test_csr_spmv_tune(suf):
         assert np.array_equal(r, results[0])
 
 
+def test_csr_halo_rows():
+    """Rows of a piece that read columns outside an interval, against a direct numpy scan."""
+    offs, cfs = oracle.benchmark_stencil_offsets(4)
+    rects, _, col, _ = oracle.linearized_stencil((9, 7, 8), offs, cfs)
+    n = rects.shape[0]
+    rd, cd = dev(rects), dev(col)
+    for (r0, r1, lo, hi) in [(0, n - 1, 0, n - 1), (100, 299, 100, 299), (100, 299, 0, n - 1), (100, 299, 150, 160),
+                             (0, 55, 0, 55), (n - 56, n - 1, n - 56, n - 1), (200, 200, 0, 10), (10, 30, 500, 600)]:
+        piece = np.ascontiguousarray(rects[r0:r1 + 1])
+        rows = piece.shape[0]
+        k_lo, k_hi = int(piece[0, 0]), int(piece[-1, 1])
+        below, above = -1, rows
+        for i in range(rows):
+            seg = col[piece[i, 0]:piece[i, 1] + 1]
+            if (seg < lo).any():
+                below = i
+            if (seg > hi).any() and above == rows:
+                above = i
+        out = torch.zeros(2, dtype=torch.int64, device="cuda")
+        print(f"case csr_halo_rows rows=[{r0},{r1}] interval=[{lo},{hi}]", flush=True)
+        _lib.call("lsk_csr_halo_rows_i64", rows, k_hi - k_lo + 1, P(rd[r0:r1 + 1]), k_lo, P(cd[k_lo:k_hi + 1]),
+                  lo, hi, P(out), stream())
+        assert out.tolist() == [below, above]
+    _lib.call("lsk_csr_halo_rows_i64", 0, 0, None, 0, None, 0, 5, P(out), stream())
+    assert out.tolist() == [-1, 0]
+
+
 def test_rects_to_indptr_bit_exact():
     offs, cfs = oracle.benchmark_stencil_offsets(4)
     rects, _, _, _ = oracle.linearized_stencil((5, 6, 7), offs, cfs)

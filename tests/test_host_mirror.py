@@ -224,20 +224,27 @@ def _worker8(rank, world, port, out_dir):
     try:
         ctx = Context(backend=OracleBackend())
         results = {}
-        # BenchmarkStencil's layout, one row block per rank.  (16, 8, 8): two grid planes per
-        # rank, halos from the two neighbours; (4, 8, 8): half a plane per rank, so the halo
+        # BenchmarkStencil's layout, one row block per rank.  (32, 8, 8): four grid planes per
+        # rank, halos from the two neighbours, the two inner planes need none; (4, 8, 8): half a plane per rank, so the halo
         # (up to 73 cells) reaches three ranks away on each side.
-        for extent in ((16, 8, 8), (4, 8, 8)):
+        for extent in ((32, 8, 8), (4, 8, 8)):
             rects, row, col, val, n = hc.stencil_problem(4, extent)
             pl = hc.mirror_planner(ctx, "csr", rects, row, col, val, n, world, np.float64)
             plan = pl.row_partitioned_matrices[0].plan
             per = n // world
             mine = col[rects[rank * per, 0]:rects[(rank + 1) * per - 1, 1] + 1]
             want_peers = [q for q in range(int(mine.min()) // per, int(mine.max()) // per + 1) if q != rank]
-            if extent[0] == 16:
+            if extent[0] == 32:
                 assert want_peers == [q for q in (rank - 1, rank + 1) if 0 <= q < world]
             elif 2 <= rank <= 5:
                 assert max(abs(q - rank) for q in want_peers) >= 2
+            split = pl.row_partitioned_matrices[0].split
+            if extent[0] == 32:   # rows that read no ghost cell run ahead of the halo
+                runs = split[0]
+                assert [r[0] for r in runs] == ([0, 1] if rank == 0 else [1, 0] if rank == world - 1 else [1, 0, 1])
+                assert sum(r[2] - r[1] for r in runs) == per
+            else:                 # half a plane per rank: every row needs the halo
+                assert split is None
             assert sorted(t.peer for t in plan.recvs) == want_peers, (rank, plan.recvs)
             assert sorted(t.peer for t in plan.sends) == want_peers, (rank, plan.sends)
             solver = CGSolver(pl)
@@ -257,7 +264,7 @@ def test_eight_rank_gloo_matches_oracle(tmp_path):
     all-reduce) on CPU tensors, against the oracle with 8 pieces."""
     mp.spawn(_worker8, args=(8, _free_port(), str(tmp_path)), nprocs=8, join=True)
     res = torch.load(os.path.join(tmp_path, "results8.pt"), weights_only=False)
-    for extent in ((16, 8, 8), (4, 8, 8)):
+    for extent in ((32, 8, 8), (4, 8, 8)):
         rects, row, col, val, n = hc.stencil_problem(4, extent)
         opl = hc.oracle_planner("csr", rects, row, col, val, n, 8, np.float64)
         so = S.CGSolver(opl)

@@ -30,6 +30,8 @@ def main():
         spaces = 2 if solver_name == "cg" else 1
         opl = hc.oracle_planner(kind, rects, row, col, val, n, pieces, np.float64, rhs, spaces)
         mpl = hc.mirror_planner(ctx, kind, rects, row, col, val, n, pieces, np.float64, rhs, spaces)
+        if kind == "csr":  # 27-point rows: not fused, so the halo overlap path is the one that runs
+            assert mpl.row_partitioned_matrices[0].split is not None
         if solver_name == "cg":
             so, sm, steps = S.CGSolver(opl), CGSolver(mpl), 8
         elif solver_name == "bicgstab":
