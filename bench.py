@@ -159,7 +159,7 @@ def main():
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-            "kernel": "csr_spmv_wave_kernel<double,5,false,8>", "ms_per_launch": t_spmv * 1e3,
+            "kernel": "csr_spmv_wave_kernel<double, 5, false, 8, false>", "ms_per_launch": t_spmv * 1e3,
             "algorithmic_bytes_per_launch": algo_bytes,
             "tile_placement": sorted(set(matrix.placement.values())) or [0],
         },

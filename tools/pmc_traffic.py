@@ -27,6 +27,7 @@ def means(path, counter):
 
 def main():
     fetch, write, out = sys.argv[1:4]
+    placement = sys.argv[4] if len(sys.argv) > 4 else None
     rows, nnz = 512 ** 3, (3 * 512 - 2) ** 3
     f, w = means(fetch, "FETCH_SIZE"), means(write, "WRITE_SIZE")
     dot_true = 2 * rows * 8
@@ -36,6 +37,7 @@ def main():
     algo = nnz * 16 + rows * 32
     json.dump({
         "workload": "csr_spmv f64, 27-pt 512^3, 1 GPU",
+        "tile_placement": placement,
         "FETCH_SIZE_KB_mean": f["spmv"], "WRITE_SIZE_KB_mean": w["spmv"],
         "calibration": {"kernel": f"dot_kernel f64 (reads 2*rows*8 = {dot_true} B)",
                         "FETCH_SIZE_KB_mean": f["dot"], "ratio_true_over_reported": ratio},
