@@ -3,17 +3,20 @@
 // (src/CSRMatrixTasks.cu:14-156, src/CuSPARSEHelpers.hpp:9-101).  No rect->indptr rebasing
 // pass, no descriptors, no workspace: one kernel launch per call.
 //
-// Work split: a workgroup (4 wave64) owns R consecutive rows.  When those rows tile one
-// contiguous run of kernel entries that fits the LDS product buffer (the normal case for a
-// CSR piece) it takes the streaming path:
-//   1. lanes load the rects (one 16-byte load per row) and publish row offsets in LDS;
-//   2. the run of entries is read front to back with 16-byte loads of col and val, four
-//      independent loads per array per lane in flight, x gathered through L2, and the
-//      products parked in LDS;
-//   3. 256/R lanes per row add that row's products out of LDS and one lane stores y.
-// Otherwise (gaps or overlaps between rects, or a run longer than the buffer) each wave
-// walks whole rows straight from HBM.  Both paths skip entries whose column lies outside
-// x_lo..x_hi, as the reference's CPU body does (src/CSRMatrixTasks.cpp:88).
+// Two forms (option csr.variant):
+//
+//   wave tiles (default; csr_spmv_wave_kernel): every wave64 owns 1..256 consecutive rows and works
+//   alone -- rects by 16-byte loads, the rows' contiguous run of entries by aligned 16-byte loads
+//   of col and val (a whole tile in flight at once), x gathered through L2, products through a
+//   wave-private LDS buffer, rows added up out of LDS, no workgroup barrier anywhere.  Optionally
+//   fused with the dot product of the result and another vector.
+//
+//   workgroup tiles (csr_spmv_kernel): the four waves of a workgroup share R rows and one LDS
+//   buffer, with barriers between the phases.  Kept for comparison.
+//
+// Rows whose rects are not back to back (gaps, overlaps, permuted) and single rows longer than
+// the LDS buffer are walked one wave per row straight from HBM.  All paths skip entries whose
+// column lies outside x_lo..x_hi, as the reference's CPU body does (src/CSRMatrixTasks.cpp:88).
 //
 // HBM bytes per call: nnz*(8 + sizeof(T)) + rows*(16 + sizeof(T)) + the x window.
 #include <algorithm>
