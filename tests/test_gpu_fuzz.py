@@ -1,0 +1,126 @@
+"""Randomised parity sweep of the SpMV kernels against the CPU oracle: many small matrices with
+row-length distributions chosen to hit every path of the wave-tile kernel (1..256 rows per wave,
+one or several rects per lane, tiles taken whole / in batches / row by row, pieces that start in
+the middle of larger arrays, input windows narrower than the columns), both entry types, both
+values of beta, and the same matrices as row-sorted and shuffled COO.  Seeds are fixed."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from legionsolvers_amd import _lib
+
+pytestmark = pytest.mark.gpu
+
+DT = {"f32": (np.float32, torch.float32, 1e-5), "f64": (np.float64, torch.float64, 1e-13)}
+
+
+def P(t):
+    return ctypes.c_void_p(t.data_ptr() if t is not None else 0)
+
+
+def stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def row_lengths(rng, kind, rows):
+    if kind == "tiny":
+        return rng.integers(0, 4, size=rows)
+    if kind == "stencil-like":
+        return np.full(rows, int(rng.integers(3, 30)))
+    if kind == "uniform":
+        return rng.integers(0, int(rng.integers(2, 120)), size=rows)
+    if kind == "heavy-tail":
+        lens = (rng.pareto(1.2, size=rows) * 3).astype(np.int64)
+        return np.minimum(lens, 5000)
+    if kind == "long":
+        return rng.integers(600, 2500, size=rows)
+    if kind == "mostly-empty":
+        lens = np.zeros(rows, dtype=np.int64)
+        lens[rng.integers(0, rows, size=max(rows // 20, 1))] = rng.integers(1, 50)
+        return lens
+    raise ValueError(kind)
+
+
+KINDS = ["tiny", "stencil-like", "uniform", "heavy-tail", "long", "mostly-empty"]
+
+
+@pytest.mark.parametrize("suf", ["f32", "f64"])
+@pytest.mark.parametrize("kind", KINDS)
+def test_spmv_random_structures(gpu_ctx, suf, kind):
+    npdt, tdt, tol = DT[suf]
+    for seed in range(6):
+        rng = np.random.default_rng(1000 * KINDS.index(kind) + seed)
+        rows = int(rng.integers(1, 40 if kind == "long" else 3000))
+        n_cols = int(rng.integers(1, 4000))
+        lens = row_lengths(rng, kind, rows)
+        pre, post = int(rng.integers(0, 50)), int(rng.integers(0, 50))  # the piece sits inside larger arrays
+        k_base = int(rng.integers(0, 1000))
+        starts = np.concatenate([[0], np.cumsum(lens)]) + k_base + pre
+        nnz = int(lens.sum()) + pre + post
+        rects = np.stack([starts[:-1], starts[1:] - 1], axis=1).astype(np.int64)
+        col = rng.integers(0, n_cols, size=nnz).astype(np.int64)
+        val = rng.standard_normal(nnz).astype(npdt)
+        # input window: sometimes the whole column range, sometimes a narrower one (guards)
+        if rng.random() < 0.5:
+            x_lo, x_hi = 0, n_cols - 1
+        else:
+            x_lo = int(rng.integers(0, n_cols))
+            x_hi = int(rng.integers(x_lo, n_cols))
+        x = rng.standard_normal(x_hi - x_lo + 1).astype(npdt)
+        y0 = rng.standard_normal(rows).astype(npdt)
+        beta = int(rng.integers(0, 2))
+        print(f"case fuzz csr {suf} {kind} seed={seed} rows={rows} nnz={nnz} k_base={k_base} "
+              f"x=[{x_lo},{x_hi}] beta={beta}", flush=True)
+        want = y0.copy()
+        oracle.csr_matvec(rects, k_base, col, val, x, x_lo, x_hi, want, beta=beta)
+        bound = np.zeros(rows, dtype=npdt)
+        oracle.csr_matvec(rects, k_base, col, np.abs(val), np.abs(x), x_lo, x_hi, bound, beta=0)
+        lim = tol * (bound.astype(np.float64) + np.abs(y0) + 1e-300)
+        rd, cd, vd, xd = dev(rects), dev(col), dev(val), dev(x)
+        for variant in (1, 0):
+            _lib.call("lsk_set_option", b"csr.variant", variant)
+            yd = dev(y0)
+            _lib.call(f"lsk_csr_spmv_{suf}", rows, nnz, P(rd), k_base, P(cd), P(vd), P(xd), x_lo, x_hi, P(yd),
+                      beta, stream())
+            err = np.abs(yd.cpu().numpy().astype(np.float64) - want.astype(np.float64))
+            assert np.all(err <= lim), (variant, float(err.max()), int(np.argmax(err - lim)))
+        _lib.call("lsk_set_option", b"csr.variant", 1)
+        # fused product + dot on the same piece
+        w = rng.standard_normal(rows).astype(npdt)
+        slots = _lib.lib().lsk_csr_spmv_dot_partials(rows, nnz, np.dtype(npdt).itemsize)
+        partials = torch.zeros(slots, dtype=tdt, device="cuda")
+        count = ctypes.c_int64(0)
+        yd, wd = dev(y0), dev(w)
+        _lib.call(f"lsk_csr_spmv_dot_{suf}", rows, nnz, P(rd), k_base, P(cd), P(vd), P(xd), x_lo, x_hi, P(yd),
+                  beta, P(wd), P(partials), slots, ctypes.byref(count), stream())
+        out = torch.zeros(1, dtype=tdt, device="cuda")
+        _lib.call(f"lsk_sum_partials_{suf}", count.value, P(partials), P(out), None, 0, stream())
+        yh = yd.cpu().numpy().astype(np.float64)
+        assert np.all(np.abs(yh - want.astype(np.float64)) <= lim)
+        assert abs(float(out) - float(np.sum(yh * w))) <= (1e-12 if suf == "f64" else 1e-5) * float(np.sum(np.abs(yh * w))) + 1e-300
+        # the same entries as COO (row-sorted, then shuffled), accumulating into y0
+        live = lens.sum()
+        if live:
+            r_coo = np.repeat(np.arange(rows, dtype=np.int64), lens)
+            sl = slice(pre, pre + live)
+            for order in (np.arange(live), rng.permutation(live)):
+                rc, cc, vc = r_coo[order].copy(), col[sl][order].copy(), val[sl][order].copy()
+                want_c = y0.copy()
+                oracle.coo_matvec(rc, cc, vc, x, x_lo, x_hi, want_c, 0, rows - 1)
+                rcd, ccd, vcd = dev(rc), dev(cc), dev(vc)  # kept alive across the asynchronous launch
+                for variant in (1, 0):
+                    _lib.call("lsk_set_option", b"coo.variant", variant)
+                    yd = dev(y0)
+                    _lib.call(f"lsk_coo_spmv_{suf}", int(live), P(rcd), P(ccd), P(vcd), P(xd), x_lo, x_hi,
+                              P(yd), 0, rows - 1, stream())
+                    torch.cuda.synchronize()
+                    err = np.abs(yd.cpu().numpy().astype(np.float64) - want_c.astype(np.float64))
+                    assert np.all(err <= lim * 4), ("coo", variant, float(err.max()))
+            _lib.call("lsk_set_option", b"coo.variant", 1)
