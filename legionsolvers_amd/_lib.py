@@ -14,7 +14,7 @@ import re
 import torch  # noqa: F401  (must precede the CDLL below, see module docstring)
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG_DIR, "liblsk.so")
+LIB_PATH = os.environ.get("LSK_LIBRARY") or os.path.join(PKG_DIR, "liblsk.so")  # LSK_LIBRARY: another build of it
 HEADER_PATH = os.path.join(os.path.dirname(PKG_DIR), "include", "lsk.h")
 
 LSK_OK = 0

@@ -385,7 +385,10 @@ __device__ __forceinline__ T fold_range(const T *__restrict__ sp, int e0, int e1
 // partials[tile * 4 + wave] (0 for waves past the last row): the dot product a Krylov step
 // takes right after the product (CG's p.Ap) without a second pass over y and w.
 template <typename T, int LOG_ROWS, bool NT, int KMAX, bool DOT>
-__global__ __launch_bounds__(kBlock, 4) void csr_spmv_wave_kernel( // at least 4 waves per SIMD: <= 128 VGPRs
+#ifndef LSK_MIN_WAVES
+#define LSK_MIN_WAVES 4
+#endif
+__global__ __launch_bounds__(kBlock, LSK_MIN_WAVES) void csr_spmv_wave_kernel( // at least 4 waves per SIMD: <= 128 VGPRs
     int64_t rows, const Rect *__restrict__ rects, int64_t k_base, int64_t nnz,
     const int64_t *__restrict__ col, const T *__restrict__ val, const T *__restrict__ x,
     int64_t x_lo, int64_t x_hi, T *__restrict__ y, int beta, int remap,
