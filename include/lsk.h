@@ -61,7 +61,9 @@ void lsk_set_abort_on_error(int enable);
  * keeps in flight: 0 = chosen from the mean tile size, 4 or 8), "blas1.form" (0 grid-strided | 1 contiguous chunk per
  * workgroup, default 1), "coo.variant" (0 workgroup chunks through LDS | 1 wave-wide segmented
  * scan, default 1).  No counterpart in the reference
- * (cuSPARSE picks its own algorithm behind CUSPARSE_SPMV_ALG_DEFAULT). */
+ * (cuSPARSE picks its own algorithm behind CUSPARSE_SPMV_ALG_DEFAULT).  Options are
+ * process-wide and read at launch time without synchronisation: set them from the thread that
+ * launches, between launches. */
 int lsk_set_option(const char *key, int value);
 int lsk_get_option(const char *key, int *value);
 

@@ -9,6 +9,7 @@ and neighbouring pieces of one rank need no copy at all.
 """
 from __future__ import annotations
 
+import weakref
 from typing import List, Tuple
 
 import torch
@@ -89,11 +90,11 @@ class PartitionedVector:
     def _note_ready(self, partner: "PartitionedVector", pieces) -> None:
         """pieces[i] = (partials tensor or None, count): shares of sum over piece i of
         self * partner, valid for the current contents of both."""
-        self._ready = (partner, partner.version, pieces)
+        self._ready = (weakref.ref(partner), partner.version, pieces)  # weak: partner may be self
 
     def _ready_for(self, other: "PartitionedVector"):
         r = self._ready
-        if r is not None and r[0] is other and other.version == r[1]:
+        if r is not None and r[0]() is other and other.version == r[1]:
             return r[2]
         return None
 
