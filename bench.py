@@ -11,8 +11,10 @@ equal row blocks, one per rank (strong scaling).  Inputs (matrix, rhs = 1, x0 = 
 on the device and resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
 
 Besides the contract's fields the line carries:
-  roofline      the CSR SpMV kernel against the HBM roof: algorithmic bytes of one launch
-                (nnz*16 + rows*32 on this rank) / its mean duration from HIP events
+  roofline      the CSR SpMV kernel of the timed steps against the HBM roof: algorithmic bytes of
+                one launch in the layout it reads (nnz*12 + rows*32 on this rank with the set-up-time
+                32-bit columns, nnz*16 + rows*32 without) / its mean duration from HIP events
+  roofline_int64_columns   the same for the kernel that reads the reference's 64-bit column field
   cpu_baseline  the CPU oracle's CG step (OpenMP over row blocks) on a bounded 27-point sample,
                 rank 0 at N = 1 only
 """
@@ -37,13 +39,29 @@ from legionsolvers_amd import benchmark_stencil as bs  # noqa: E402
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak
 
 
-def spmv_kernel_time(ctx, matrix, planner, reps: int) -> float:
+def spmv_kernel_time(ctx, matrix, planner, reps: int, compressed: bool = True) -> float:
     """Mean seconds of one CSR SpMV launch on this rank (the kernel alone, no halo traffic),
-    from HIP events recorded on the launch stream."""
+    from HIP events recorded on the launch stream.  compressed=False times the form that reads
+    the reference's 64-bit column field instead of the set-up-time 32-bit copy."""
     entry = planner.row_partitioned_matrices[0]
     src = planner.get_vector(2, 0)  # P
     dst = planner.get_vector(3, 0)  # Q
-    x, x_lo, x_hi = src.data, src.own_lo - src.pad_lo, src.own_hi + src.pad_hi
+    plan = entry.plan
+    x_lo, x_hi = src.own_lo, src.own_hi          # the window the planner's products use
+    if plan.recvs or plan.sends:
+        x_lo, x_hi = x_lo - plan.pad_lo, x_hi + plan.pad_hi
+    base = src.own_lo - src.pad_lo
+    x = src.data[x_lo - base:x_hi - base + 1]
+    if not compressed:
+        held, matrix.col32_window = matrix.col32_window, None
+        try:
+            return spmv_kernel_time_inner(ctx, matrix, entry, dst, x, x_lo, x_hi, reps)
+        finally:
+            matrix.col32_window = held
+    return spmv_kernel_time_inner(ctx, matrix, entry, dst, x, x_lo, x_hi, reps)
+
+
+def spmv_kernel_time_inner(ctx, matrix, entry, dst, x, x_lo, x_hi, reps: int) -> float:
     for _ in range(3):
         matrix.matvec(dst, x, x_lo, x_hi, entry.kernel_partition, 0)
     start = torch.cuda.Event(enable_timing=True)
@@ -118,14 +136,22 @@ def main():
     rr = solver.residual_norm_squared[-1].get_value()
 
     # the dominant kernel against its roofline (this rank's launch)
-    t_spmv = spmv_kernel_time(ctx, matrix, planner, reps=20)
-    algo_bytes = matrix.nnz * 16 + matrix.rows * 32
+    # (bytes of the layout the kernel reads: 4-byte columns when the set-up copy exists, else 8)
+    compressed = matrix.col32 is not None
+    col_bytes = 4 if compressed else 8
+    t_spmv = spmv_kernel_time(ctx, matrix, planner, reps=20, compressed=compressed)
+    algo_bytes = matrix.nnz * (8 + col_bytes) + matrix.rows * 32
     achieved = algo_bytes / t_spmv / 1e9
-    spmv_gbps_job = (nnz_total * 16 + rows * 32) / ctx.comm.max_over_ranks(t_spmv, ctx.device) / 1e9
-    traffic = None
+    spmv_gbps_job = (nnz_total * (8 + col_bytes) + rows * 32) / ctx.comm.max_over_ranks(t_spmv, ctx.device) / 1e9
+    # the same product on the reference's own 64-bit column field, for comparison
+    t_spmv64 = spmv_kernel_time(ctx, matrix, planner, reps=20, compressed=False) if compressed else t_spmv
+    algo_bytes64 = matrix.nnz * 16 + matrix.rows * 32
+    traffic = traffic64 = None
     traffic_file = os.path.join(REPO, "profiles", "spmv_hbm_traffic.json")
     if world == 1 and n1 == 512 and os.path.exists(traffic_file):
-        traffic = json.load(open(traffic_file)).get("bytes_per_launch")
+        measured = json.load(open(traffic_file))
+        traffic64 = measured.get("bytes_per_launch")
+        traffic = measured.get("bytes_per_launch_c32") if compressed else traffic64
 
     # the reference's own set-up: two identical systems per step
     del solver, planner
@@ -152,6 +178,8 @@ def main():
                         "3-D 27-pt stencil, fp64 CSR with int64 indices and 16-byte row rects, "
                         "rhs=1, x0=0, one row block per GPU",
             "rows": rows, "nnz": nnz_total, "pieces": world,
+            "column_layout": ("32-bit window-relative copy of the int64 column field, made once at set-up "
+                              "(bit-identical products)") if compressed else "int64 global columns as handed over",
         },
         "spmv_gbps": spmv_gbps_job,
         "two_system_iters_per_s": two_system,
@@ -159,9 +187,17 @@ def main():
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-            "kernel": "csr_spmv_wave_kernel<double, 5, false, 8, false>", "ms_per_launch": t_spmv * 1e3,
+            "kernel": ("csr_spmv_wave_kernel<double, unsigned int, 5, false, 8, false>" if compressed
+                       else "csr_spmv_wave_kernel<double, long, 5, false, 8, false>"),
+            "ms_per_launch": t_spmv * 1e3,
             "algorithmic_bytes_per_launch": algo_bytes,
             "tile_placement": sorted(set(matrix.placement.values())) or [0],
+        },
+        "roofline_int64_columns": {
+            "bound": "hbm", "achieved": algo_bytes64 / t_spmv64 / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": algo_bytes64 / t_spmv64 / 1e9 / HBM_PEAK_GBPS, "traffic": traffic64,
+            "kernel": "csr_spmv_wave_kernel<double, long, 5, false, 8, false>", "ms_per_launch": t_spmv64 * 1e3,
+            "algorithmic_bytes_per_launch": algo_bytes64,
         },
     }
     if ctx.rank == 0 and world == 1 and not args.no_cpu_baseline:

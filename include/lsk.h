@@ -291,6 +291,41 @@ int lsk_csr_spmv_tune_f64(int64_t rows, int64_t nnz, const int64_t *rects, int64
                           const int64_t *col, const double *val, const double *x, int64_t x_lo,
                           int64_t x_hi, double *y, lsk_stream_t stream, int *remap_out, float *ms_out);
 
+/* Compressed columns: the set-up-time replacement for the per-call rebasing of
+ * src/CuSPARSEHelpers.hpp:71-80 (the reference converts its 64-bit global indices for cuSPARSE
+ * on EVERY call; here the conversion is done once and kept by the caller beside the matrix).
+ * lsk_csr_compress_cols_u32 writes col32[k] = col[k] - x_lo for columns inside x_lo..x_hi and
+ * 0xffffffff for the others (which every product skips, as the 64-bit form skips them); the
+ * window must span fewer than 2^32 - 1 columns (else LSK_ERR_UNSUPPORTED and the caller stays
+ * with the 64-bit form).  lsk_csr_spmv_c32_* is lsk_csr_spmv_* on that array: `x` points at the
+ * window's first element, `x_extent` = x_hi - x_lo + 1 of the compression.  It reads 4 bytes of
+ * index per entry instead of 8; tiles and the order of additions are the same, so y is
+ * bit-identical to lsk_csr_spmv_*.  _dot_ and _tune_ as the 64-bit entry points of those names. */
+int lsk_csr_compress_cols_u32(int64_t nnz, const int64_t *col, int64_t x_lo, int64_t x_hi,
+                              uint32_t *col32, lsk_stream_t stream);
+int lsk_csr_spmv_c32_f32(int64_t rows, int64_t nnz, const int64_t *rects, int64_t k_base,
+                         const uint32_t *col32, const float *val, const float *x, int64_t x_extent,
+                         float *y, int beta, lsk_stream_t stream);
+int lsk_csr_spmv_c32_f64(int64_t rows, int64_t nnz, const int64_t *rects, int64_t k_base,
+                         const uint32_t *col32, const double *val, const double *x, int64_t x_extent,
+                         double *y, int beta, lsk_stream_t stream);
+int lsk_csr_spmv_c32_dot_f32(int64_t rows, int64_t nnz, const int64_t *rects, int64_t k_base,
+                             const uint32_t *col32, const float *val, const float *x,
+                             int64_t x_extent, float *y, int beta, const float *w, float *partials,
+                             int64_t capacity, int64_t *count, lsk_stream_t stream);
+int lsk_csr_spmv_c32_dot_f64(int64_t rows, int64_t nnz, const int64_t *rects, int64_t k_base,
+                             const uint32_t *col32, const double *val, const double *x,
+                             int64_t x_extent, double *y, int beta, const double *w, double *partials,
+                             int64_t capacity, int64_t *count, lsk_stream_t stream);
+int lsk_csr_spmv_c32_tune_f32(int64_t rows, int64_t nnz, const int64_t *rects, int64_t k_base,
+                              const uint32_t *col32, const float *val, const float *x,
+                              int64_t x_extent, float *y, lsk_stream_t stream, int *remap_out,
+                              float *ms_out);
+int lsk_csr_spmv_c32_tune_f64(int64_t rows, int64_t nnz, const int64_t *rects, int64_t k_base,
+                              const uint32_t *col32, const double *val, const double *x,
+                              int64_t x_extent, double *y, lsk_stream_t stream, int *remap_out,
+                              float *ms_out);
+
 /* indptr[i] = rects[i].lo - rects[0].lo for i < rows; indptr[rows] = rects[rows-1].hi + 1
  * - rects[0].lo.  Bit-exact restatement of convertGlobalRowptrToLocalIndPtr
  * (src/CuSPARSEHelpers.hpp:9-31) for callers that want a classic CSR offset array; the

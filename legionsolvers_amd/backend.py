@@ -101,6 +101,11 @@ class HipBackend:
             _lib.call("lsk_set_option", b"xcd_remap", placement)
             self._placement = placement
         count = ctypes.c_int64(0)
+        if col.dtype == torch.int32:
+            _lib.call(f"lsk_csr_spmv_c32_dot_{_lib.suffix(val.dtype)}", rows, nnz, _ptr(rects), k_base, _ptr(col),
+                      _ptr(val), _ptr(x), x_hi - x_lo + 1, _ptr(y), beta, _ptr(w), _ptr(partials),
+                      partials.numel(), ctypes.byref(count), self.stream())
+            return count.value
         _lib.call(f"lsk_csr_spmv_dot_{_lib.suffix(val.dtype)}", rows, nnz, _ptr(rects), k_base, _ptr(col),
                   _ptr(val), _ptr(x), x_lo, x_hi, _ptr(y), beta, _ptr(w), _ptr(partials), partials.numel(),
                   ctypes.byref(count), self.stream())
@@ -125,10 +130,16 @@ class HipBackend:
     def csr_spmv(self, rows: int, nnz: int, rects: torch.Tensor, k_base: int, col: torch.Tensor,
                  val: torch.Tensor, x: torch.Tensor, x_lo: int, x_hi: int, y: torch.Tensor,
                  beta: int, placement: int = 0) -> None:
-        """`placement`: the piece's tile -> XCD placement found by csr_spmv_tune (a speed hint)."""
+        """`placement`: the piece's tile -> XCD placement found by csr_spmv_tune (a speed hint).
+        `col`: int64 global column ids, or the int32-typed array csr_compress_cols made for the
+        window x_lo..x_hi (x[0] is the window's first element either way)."""
         if placement != self._placement:
             _lib.call("lsk_set_option", b"xcd_remap", placement)
             self._placement = placement
+        if col.dtype == torch.int32:
+            _lib.call(f"lsk_csr_spmv_c32_{_lib.suffix(val.dtype)}", rows, nnz, _ptr(rects), k_base, _ptr(col),
+                      _ptr(val), _ptr(x), x_hi - x_lo + 1, _ptr(y), beta, self.stream())
+            return
         _lib.call(f"lsk_csr_spmv_{_lib.suffix(val.dtype)}", rows, nnz, _ptr(rects), k_base, _ptr(col),
                   _ptr(val), _ptr(x), x_lo, x_hi, _ptr(y), beta, self.stream())
 
@@ -138,6 +149,11 @@ class HipBackend:
         """(placement, milliseconds per launch) of the fastest tile -> XCD placement for this
         piece; y is overwritten.  Synchronises."""
         remap, ms = ctypes.c_int(0), ctypes.c_float(0.0)
+        if col.dtype == torch.int32:
+            _lib.call(f"lsk_csr_spmv_c32_tune_{_lib.suffix(val.dtype)}", rows, nnz, _ptr(rects), k_base, _ptr(col),
+                      _ptr(val), _ptr(x), x_hi - x_lo + 1, _ptr(y), self.stream(), ctypes.byref(remap),
+                      ctypes.byref(ms))
+            return remap.value, ms.value
         _lib.call(f"lsk_csr_spmv_tune_{_lib.suffix(val.dtype)}", rows, nnz, _ptr(rects), k_base, _ptr(col),
                   _ptr(val), _ptr(x), x_lo, x_hi, _ptr(y), self.stream(), ctypes.byref(remap), ctypes.byref(ms))
         return remap.value, ms.value
@@ -148,6 +164,15 @@ class HipBackend:
                   _ptr(x), x_lo, x_hi, _ptr(y), y_lo, y_hi, self.stream())
 
     # -- set-up ------------------------------------------------------------------------------
+    COMPRESS_MAX_EXTENT = 0xFFFFFFFF - 1  # widest window 32-bit column offsets can address
+
+    def csr_compress_cols(self, col: torch.Tensor, x_lo: int, x_hi: int) -> torch.Tensor:
+        """The column field as 32-bit offsets into the window x_lo..x_hi (bit pattern of
+        uint32 in an int32 tensor; 0xffffffff marks a column outside the window)."""
+        out = torch.empty(col.numel(), dtype=torch.int32, device=self.device)
+        _lib.call("lsk_csr_compress_cols_u32", col.numel(), _ptr(col), x_lo, x_hi, _ptr(out), self.stream())
+        return out
+
     def csr_halo_rows(self, rows: int, nnz: int, rects: torch.Tensor, k_base: int, col: torch.Tensor,
                       lo: int, hi: int) -> Tuple[int, int]:
         """(largest row with a column below lo or -1, smallest row with a column above hi or

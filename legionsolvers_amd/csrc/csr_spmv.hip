@@ -18,7 +18,13 @@
 // the LDS buffer are walked one wave per row straight from HBM.  All paths skip entries whose
 // column lies outside x_lo..x_hi, as the reference's CPU body does (src/CSRMatrixTasks.cpp:88).
 //
-// HBM bytes per call: nnz*(8 + sizeof(T)) + rows*(16 + sizeof(T)) + the x window.
+// Compressed columns (lsk_csr_compress_cols_u32 + lsk_csr_spmv_c32_*): a set-up pass rewrites the
+// 64-bit global column ids once as 32-bit offsets into the x window (0xffffffff = outside it);
+// the wave-tile kernel then reads 4 instead of 8 bytes of index per entry.  Same tiles, same
+// order of additions: results are bit-identical to the 64-bit form.
+//
+// HBM bytes per call: nnz*(8 + sizeof(T)) + rows*(16 + sizeof(T)) + the x window
+// (compressed columns: nnz*(4 + sizeof(T)) + ...).
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -47,6 +53,23 @@ typedef long long ll2_t __attribute__((ext_vector_type(2)));
 // The same, promised only 8-byte alignment: col pairs sit at the val units' entries, whose
 // 16-byte phase may differ from the col array's.
 typedef ll2_t ll2_a8_t __attribute__((aligned(8)));
+typedef unsigned int u4_t __attribute__((ext_vector_type(4)));
+// val words of the compressed form sit at the col quads' entries: natural alignment only.
+typedef d2_t d2_a8_t __attribute__((aligned(8)));
+typedef f4_t f4_a4_t __attribute__((aligned(4)));
+
+// Column field: 64-bit global ids checked against x_lo..x_hi, or 32-bit offsets into the window
+// (x_lo = 0, x_hi = extent - 1 < 0xffffffff; the marker 0xffffffff fails the check).
+template <typename CT> struct ColOps;
+template <> struct ColOps<int64_t> {
+    static __device__ __forceinline__ bool in(int64_t c, int64_t lo, int64_t hi) { return c >= lo && c <= hi; }
+    static __device__ __forceinline__ int64_t off(int64_t c, int64_t lo) { return c - lo; }
+};
+template <> struct ColOps<uint32_t> {
+    static __device__ __forceinline__ bool in(uint32_t c, int64_t, int64_t hi) { return c <= static_cast<uint32_t>(hi); }
+    static __device__ __forceinline__ uint32_t off(uint32_t c, int64_t) { return c; }
+};
+
 template <typename T> struct Native;
 template <> struct Native<double> { using V = d2_t; };
 template <> struct Native<float> { using V = f4_t; };
@@ -59,6 +82,17 @@ __device__ __forceinline__ VT vload(const VT *p) {
 
 template <bool NT> __device__ __forceinline__ ll2_t load_col_pair(const int64_t *p) {
     const ll2_a8_t *q = reinterpret_cast<const ll2_a8_t *>(p);
+    if constexpr (NT) return __builtin_nontemporal_load(q);
+    else return *q;
+}
+
+template <bool NT> __device__ __forceinline__ d2_t load_val_pair_a8(const double *p) {
+    const d2_a8_t *q = reinterpret_cast<const d2_a8_t *>(p);
+    if constexpr (NT) return __builtin_nontemporal_load(q);
+    else return *q;
+}
+template <bool NT> __device__ __forceinline__ f4_t load_val_quad_a4(const float *p) {
+    const f4_a4_t *q = reinterpret_cast<const f4_a4_t *>(p);
     if constexpr (NT) return __builtin_nontemporal_load(q);
     else return *q;
 }
@@ -222,9 +256,9 @@ __global__ __launch_bounds__(kBlock) void csr_spmv_kernel(
 
 // One row of the tile per wave, entries straight from HBM (wave-level form of rows_by_wave).
 // With w != nullptr lane 0 also adds y_new[r] * w[r] into *dot_acc.
-template <typename T>
+template <typename T, typename CT>
 __device__ void wave_rows_direct(int nr, const Rect *__restrict__ rects, int64_t k_base,
-                                 int64_t nnz, const int64_t *__restrict__ col,
+                                 int64_t nnz, const CT *__restrict__ col,
                                  const T *__restrict__ val, const T *__restrict__ x, int64_t x_lo,
                                  int64_t x_hi, T *__restrict__ y, int beta,
                                  const T *__restrict__ w = nullptr, T *dot_acc = nullptr) {
@@ -235,8 +269,8 @@ __device__ void wave_rows_direct(int nr, const Rect *__restrict__ rects, int64_t
         const int64_t lo = rc.lo > k_base ? rc.lo : k_base;
         const int64_t hi = rc.hi < k_base + nnz - 1 ? rc.hi : k_base + nnz - 1;
         for (int64_t k = lo + lane; k <= hi; k += lsk::kWave) {
-            const int64_t c = col[k - k_base];
-            if (c >= x_lo && c <= x_hi) acc = fma_t(val[k - k_base], x[c - x_lo], acc);
+            const CT c = col[k - k_base];
+            if (ColOps<CT>::in(c, x_lo, x_hi)) acc = fma_t(val[k - k_base], x[ColOps<CT>::off(c, x_lo)], acc);
         }
         acc = lsk::wave_sum(acc);
         if (lane == 0) {
@@ -305,14 +339,72 @@ __device__ __forceinline__ void stream_chunk(int ubase, int lane, int nfull,
     }
 }
 
+// The same for 32-bit columns: the unit's U column offsets come as one 8- or 16-byte load
+// (4-byte aligned: the val word fixes the unit's phase).
+typedef unsigned int u2_t __attribute__((ext_vector_type(2)));
+typedef u2_t u2_a4_t __attribute__((aligned(4)));
+typedef u4_t u4_a4_t __attribute__((aligned(4)));
+template <bool NT> __device__ __forceinline__ u2_t load_col32_unit(const uint32_t *p, u2_t) {
+    const u2_a4_t *q = reinterpret_cast<const u2_a4_t *>(p);
+    if constexpr (NT) return __builtin_nontemporal_load(q);
+    else return *q;
+}
+template <bool NT> __device__ __forceinline__ u4_t load_col32_unit(const uint32_t *p, u4_t) {
+    const u4_a4_t *q = reinterpret_cast<const u4_a4_t *>(p);
+    if constexpr (NT) return __builtin_nontemporal_load(q);
+    else return *q;
+}
+
+template <typename T, int K, bool NT>
+__device__ __forceinline__ void stream_chunk32(int ubase, int lane, int nfull,
+                                               const T *__restrict__ vbody,
+                                               const uint32_t *__restrict__ cbody,
+                                               const T *__restrict__ x, uint32_t x_last,
+                                               T *__restrict__ sp_body) {
+    constexpr int U = Cfg<T>::U;
+    using V = typename Native<T>::V;
+    using CV = unsigned int __attribute__((ext_vector_type(U)));
+    V vv[K];
+    CV cc[K];
+    int uu[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int u = ubase + k * lsk::kWave + lane;
+        uu[k] = u;
+        const int uc = u < nfull ? u : nfull - 1;
+        vv[k] = vload<NT>(reinterpret_cast<const V *>(vbody) + uc);
+        cc[k] = load_col32_unit<NT>(cbody + uc * U, CV{});
+    }
+    T xv[K][U];
+    bool in[K][U];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+#pragma unroll
+        for (int p = 0; p < U; ++p) {
+            const uint32_t c = cc[k][p];
+            in[k][p] = c <= x_last;
+            xv[k][p] = x[in[k][p] ? c : 0u];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        if (uu[k] < nfull) {
+#pragma unroll
+            for (int p = 0; p < U; ++p)
+                sp_body[uu[k] * U + p] = in[k][p] ? vv[k][p] * xv[k][p] : T(0);
+        }
+    }
+}
+
 // The streaming phase of one batch of consecutive rows: n entries starting at valb / colb go as
 // products into sp[0, n).  Units are U consecutive entries whose val word is 16-byte aligned;
 // the entries before the first and after the last whole unit are handled one per lane.
-template <typename T, bool NT, int KMAX>
+template <typename T, typename CT, bool NT, int KMAX>
 __device__ __forceinline__ void stream_batch(int lane, int n, const T *__restrict__ valb,
-                                             const int64_t *__restrict__ colb,
+                                             const CT *__restrict__ colb,
                                              const T *__restrict__ x, int64_t x_lo, int64_t x_hi,
                                              T *__restrict__ sp) {
+    constexpr bool C32 = sizeof(CT) == 4;
     constexpr int U = Cfg<T>::U;
     const int shift = static_cast<int>((reinterpret_cast<uintptr_t>(valb) / sizeof(T)) % U);
     const int head0 = (U - shift) % U;
@@ -320,7 +412,7 @@ __device__ __forceinline__ void stream_batch(int lane, int n, const T *__restric
     const int nfull = (n - head) / U;
     const int tail0 = head + nfull * U; // first entry after the whole units
     const T *vbody = valb + head;
-    const int64_t *cbody = colb + head;
+    const CT *cbody = colb + head;
     // Up to KMAX units per lane in one go.  KMAX = 8 holds a whole tile of 32 rows x 27 entries
     // (7 units): all its col/val loads are in flight together, then all its gathers; two rounds
     // of 4 units cost 13 % at that size.  The instance with KMAX = 4 needs 68 instead of 103
@@ -328,7 +420,16 @@ __device__ __forceinline__ void stream_batch(int lane, int n, const T *__restric
     for (int ubase = 0; ubase < nfull; ubase += lsk::kWave * KMAX) {
         const int left = nfull - ubase; // wave-uniform
 #define LSK_CHUNK(K)                                                                              \
-    stream_chunk<T, K, NT>(ubase, lane, nfull, vbody, cbody, x, x_lo, x_hi, sp + head)
+    do {                                                                                          \
+        if constexpr (C32)                                                                        \
+            stream_chunk32<T, K, NT>(ubase, lane, nfull, vbody,                                   \
+                                     reinterpret_cast<const uint32_t *>(cbody), x,                \
+                                     static_cast<uint32_t>(x_hi), sp + head);                     \
+        else                                                                                      \
+            stream_chunk<T, K, NT>(ubase, lane, nfull, vbody,                                     \
+                                   reinterpret_cast<const int64_t *>(cbody), x, x_lo, x_hi,       \
+                                   sp + head);                                                    \
+    } while (0)
         if constexpr (KMAX == 8) {
             if (left > 7 * lsk::kWave) { LSK_CHUNK(8); continue; }
             if (left > 6 * lsk::kWave) { LSK_CHUNK(7); continue; }
@@ -344,9 +445,9 @@ __device__ __forceinline__ void stream_batch(int lane, int n, const T *__restric
     const int n_edge = head + (n - tail0);
     if (lane < n_edge) {
         const int e = lane < head ? lane : tail0 + (lane - head);
-        const long long c = colb[e];
-        const bool in = c >= x_lo && c <= x_hi;
-        sp[e] = in ? valb[e] * x[c - x_lo] : T(0);
+        const CT c = colb[e];
+        const bool in = ColOps<CT>::in(c, x_lo, x_hi);
+        sp[e] = in ? valb[e] * x[in ? ColOps<CT>::off(c, x_lo) : 0] : T(0);
     }
 }
 
@@ -384,13 +485,13 @@ __device__ __forceinline__ T fold_range(const T *__restrict__ sp, int e0, int e1
 // DOT: the kernel also leaves, per wave, the sum over its rows of y_new[r] * w[r] in
 // partials[tile * 4 + wave] (0 for waves past the last row): the dot product a Krylov step
 // takes right after the product (CG's p.Ap) without a second pass over y and w.
-template <typename T, int LOG_ROWS, bool NT, int KMAX, bool DOT>
+template <typename T, typename CT, int LOG_ROWS, bool NT, int KMAX, bool DOT>
 #ifndef LSK_MIN_WAVES
 #define LSK_MIN_WAVES 4
 #endif
 __global__ __launch_bounds__(kBlock, LSK_MIN_WAVES) void csr_spmv_wave_kernel( // at least 4 waves per SIMD: <= 128 VGPRs
     int64_t rows, const Rect *__restrict__ rects, int64_t k_base, int64_t nnz,
-    const int64_t *__restrict__ col, const T *__restrict__ val, const T *__restrict__ x,
+    const CT *__restrict__ col, const T *__restrict__ val, const T *__restrict__ x,
     int64_t x_lo, int64_t x_hi, T *__restrict__ y, int beta, int remap,
     const T *__restrict__ w, T *__restrict__ partials) {
     constexpr int ROWS = 1 << LOG_ROWS;
@@ -459,11 +560,11 @@ __global__ __launch_bounds__(kBlock, LSK_MIN_WAVES) void csr_spmv_wave_kernel( /
         if (row < nr - 1) ok = ok && (next_lo == rel_end[j]);
     }
     if (!__all(ok)) {
-        wave_rows_direct<T>(nr, rects + r0, k_base, nnz, col, val, x, x_lo, x_hi, y + r0, beta, wt, &dot_acc);
+        wave_rows_direct<T, CT>(nr, rects + r0, k_base, nnz, col, val, x, x_lo, x_hi, y + r0, beta, wt, &dot_acc);
         if (DOT && lane == 0) *my_partial = dot_acc;
         return;
     }
-    const int64_t *colb = col + (k0 - k_base);
+    const CT *colb = col + (k0 - k_base);
     const T *valb = val + (k0 - k_base);
 
     // value of a per-row quantity at tile row q (q wave-uniform), as a wave-uniform value
@@ -488,13 +589,13 @@ __global__ __launch_bounds__(kBlock, LSK_MIN_WAVES) void csr_spmv_wave_kernel( /
             m += __popcll(__ballot(fits));
         }
         if (m == 0) { // this row alone is longer than the buffer
-            wave_rows_direct<T>(1, rects + r0 + ra, k_base, nnz, col, val, x, x_lo, x_hi, y + r0 + ra, beta,
+            wave_rows_direct<T, CT>(1, rects + r0 + ra, k_base, nnz, col, val, x, x_lo, x_hi, y + r0 + ra, beta,
                                 DOT ? wt + ra : nullptr, &dot_acc);
             ra += 1;
             continue;
         }
         const int n = at_row(rel_end, ra + m - 1) - base;
-        stream_batch<T, NT, KMAX>(lane, n, valb + base, colb + base, x, x_lo, x_hi, sp);
+        stream_batch<T, CT, NT, KMAX>(lane, n, valb + base, colb + base, x, x_lo, x_hi, sp);
         wave_lds_fence();
         if constexpr (RPL == 1) {
             const int row = lane / GW, g = lane % GW;
@@ -560,9 +661,9 @@ __global__ void store_zero_kernel(T *out) { *out = T(0); }
 
 // w != nullptr selects the fused form: besides y, partials[0 .. *count) receive per-wave sums
 // of y_new[r] * w[r] (w[0] pairs with the piece's first row).
-template <typename T>
+template <typename T, typename CT = int64_t>
 int launch_csr_spmv(const char *name, int64_t rows, int64_t nnz, const int64_t *rects,
-                    int64_t k_base, const int64_t *col, const T *val, const T *x, int64_t x_lo,
+                    int64_t k_base, const CT *col, const T *val, const T *x, int64_t x_lo,
                     int64_t x_hi, T *y, int beta, lsk_stream_t stream, const T *w = nullptr,
                     T *partials = nullptr, int64_t capacity = 0, int64_t *count = nullptr) {
     const bool fused = (w != nullptr);
@@ -580,7 +681,8 @@ int launch_csr_spmv(const char *name, int64_t rows, int64_t nnz, const int64_t *
     if (x_hi >= x_lo && !x) return lsk::fail(LSK_ERR_ARG, "%s: null input vector", name);
     if (!lsk::aligned16(rects))
         return lsk::fail(LSK_ERR_ALIGN, "%s: rects must be 16-byte aligned", name);
-    if ((reinterpret_cast<uintptr_t>(col) & 7u) || (reinterpret_cast<uintptr_t>(val) & (sizeof(T) - 1)))
+    constexpr bool C32 = sizeof(CT) == 4;
+    if ((reinterpret_cast<uintptr_t>(col) & (sizeof(CT) - 1)) || (reinterpret_cast<uintptr_t>(val) & (sizeof(T) - 1)))
         return lsk::fail(LSK_ERR_ALIGN, "%s: col/val must be naturally aligned", name);
 
     if (x_hi < x_lo) { // an empty input domain admits no entry: y <- beta * y
@@ -604,7 +706,7 @@ int launch_csr_spmv(const char *name, int64_t rows, int64_t nnz, const int64_t *
     const Rect *rc = reinterpret_cast<const Rect *>(rects);
     hipStream_t s = lsk::as_stream(stream);
     const lsk::Options &tune = lsk::options();
-    if (tune.csr_variant == 1 || fused) {
+    if (tune.csr_variant == 1 || fused || C32) {
         const int log_rw = pick_log_rows_per_wave<T>(rows, nnz);
         const int64_t blocks_w = lsk::ceil_div(rows, int64_t(4) << log_rw);
         if (blocks_w > 0x7fffffffLL) return lsk::fail(LSK_ERR_UNSUPPORTED, "%s: too many rows", name);
@@ -612,19 +714,24 @@ int launch_csr_spmv(const char *name, int64_t rows, int64_t nnz, const int64_t *
             return lsk::fail(LSK_ERR_ARG, "%s: room for %lld partial sums, %lld needed", name,
                              (long long)capacity, (long long)(blocks_w * 4));
         // Units per lane a mean tile needs: more than 4 -> the 8-unit instance.
-        const double units = 1.05 * mean * double(1 << log_rw) / double(lsk::kWave * Cfg<T>::U);
+        constexpr int UNIT = Cfg<T>::U;
+        constexpr int KWIDE = 8;
+        const double units = 1.05 * mean * double(1 << log_rw) / double(lsk::kWave * UNIT);
         const bool wide = tune.csr_max_units == 0 ? units > 4.0 : tune.csr_max_units == 8;
 #define LSK_CSRW_LAUNCH(L, NT, KMAX)                                                              \
-    csr_spmv_wave_kernel<T, L, NT, KMAX, false><<<unsigned(blocks_w), kBlock, 0, s>>>(            \
+    csr_spmv_wave_kernel<T, CT, L, NT, KMAX, false><<<unsigned(blocks_w), kBlock, 0, s>>>(        \
         rows, rc, k_base, nnz, col, val, x, x_lo, x_hi, y, beta, tune.xcd_remap, nullptr, nullptr)
 #define LSK_CSRW_LAUNCH_DOT(L, KMAX)                                                              \
-    csr_spmv_wave_kernel<T, L, false, KMAX, true><<<unsigned(blocks_w), kBlock, 0, s>>>(          \
+    csr_spmv_wave_kernel<T, CT, L, false, KMAX, true><<<unsigned(blocks_w), kBlock, 0, s>>>(      \
         rows, rc, k_base, nnz, col, val, x, x_lo, x_hi, y, beta, tune.xcd_remap, w, partials)
 #define LSK_CSRW_CASE(L)                                                                          \
     case L:                                                                                       \
         if (fused) {                                                                              \
-            if (wide) LSK_CSRW_LAUNCH_DOT(L, 8);                                                  \
+            if (wide) LSK_CSRW_LAUNCH_DOT(L, KWIDE);                                              \
             else LSK_CSRW_LAUNCH_DOT(L, 4);                                                       \
+        } else if constexpr (C32) {                                                               \
+            if (wide) LSK_CSRW_LAUNCH(L, false, KWIDE);                                           \
+            else LSK_CSRW_LAUNCH(L, false, 4);                                                    \
         } else if (tune.csr_nontemporal) {                                                        \
             if (wide) LSK_CSRW_LAUNCH(L, true, 8);                                                \
             else LSK_CSRW_LAUNCH(L, true, 4);                                                     \
@@ -652,6 +759,7 @@ int launch_csr_spmv(const char *name, int64_t rows, int64_t nnz, const int64_t *
         return LSK_OK;
     }
 
+    if constexpr (!C32) {
     // Rows per workgroup: as many as keep the tile's products inside the LDS buffer at the
     // piece's mean row length, a power of two in 4..256.
     const double want = mean > 0.0 ? 0.9 * Cfg<T>::CAP / mean : 256.0;
@@ -677,7 +785,19 @@ int launch_csr_spmv(const char *name, int64_t rows, int64_t nnz, const int64_t *
     }
 #undef LSK_CSR_CASE
     LSK_LAUNCH_CHECK();
+    }
     return LSK_OK;
+}
+
+// col32[k] <- col[k] - x_lo if x_lo <= col[k] <= x_hi, else 0xffffffff.
+__global__ __launch_bounds__(kBlock) void compress_cols_kernel(int64_t nnz, const int64_t *__restrict__ col,
+                                                               int64_t x_lo, int64_t x_hi,
+                                                               uint32_t *__restrict__ col32) {
+    const int64_t stride = int64_t(gridDim.x) * kBlock;
+    for (int64_t k = int64_t(blockIdx.x) * kBlock + threadIdx.x; k < nnz; k += stride) {
+        const int64_t c = col[k];
+        col32[k] = (c >= x_lo && c <= x_hi) ? static_cast<uint32_t>(c - x_lo) : 0xffffffffu;
+    }
 }
 
 // indptr conversion, bit-exact with convertGlobalRowptrToLocalIndPtr
@@ -694,9 +814,9 @@ __global__ __launch_bounds__(kBlock) void rects_to_indptr_kernel(int64_t rows,
 }
 
 // Times the candidates of the tile -> XCD placement on this piece and reports the fastest.
-template <typename T>
+template <typename T, typename CT = int64_t>
 int tune_csr_spmv(const char *name, int64_t rows, int64_t nnz, const int64_t *rects, int64_t k_base,
-                  const int64_t *col, const T *val, const T *x, int64_t x_lo, int64_t x_hi, T *y,
+                  const CT *col, const T *val, const T *x, int64_t x_lo, int64_t x_hi, T *y,
                   lsk_stream_t stream, int *remap_out, float *ms_out) {
     static const int candidates[] = {0, 16, 64, 256, 1024, 4096};
     constexpr int kWarm = 2, kTimed = 5;
@@ -711,11 +831,11 @@ int tune_csr_spmv(const char *name, int64_t rows, int64_t nnz, const int64_t *re
     for (int c : candidates) {
         tune.xcd_remap = c;
         for (int i = 0; i < kWarm && status == LSK_OK; ++i)
-            status = launch_csr_spmv<T>(name, rows, nnz, rects, k_base, col, val, x, x_lo, x_hi, y, 0, stream);
+            status = launch_csr_spmv<T, CT>(name, rows, nnz, rects, k_base, col, val, x, x_lo, x_hi, y, 0, stream);
         if (status != LSK_OK) break;
         if (hipEventRecord(t0, s) != hipSuccess) { status = lsk::fail(LSK_ERR_HIP, "%s: event record", name); break; }
         for (int i = 0; i < kTimed && status == LSK_OK; ++i)
-            status = launch_csr_spmv<T>(name, rows, nnz, rects, k_base, col, val, x, x_lo, x_hi, y, 0, stream);
+            status = launch_csr_spmv<T, CT>(name, rows, nnz, rects, k_base, col, val, x, x_lo, x_hi, y, 0, stream);
         if (status != LSK_OK) break;
         float ms = 0.0f;
         if (hipEventRecord(t1, s) != hipSuccess || hipEventSynchronize(t1) != hipSuccess ||
@@ -797,6 +917,57 @@ int lsk_csr_spmv_f64(int64_t rows, int64_t nnz, const int64_t *rects, int64_t k_
     return launch_csr_spmv<double>("lsk_csr_spmv_f64", rows, nnz, rects, k_base, col, val, x, x_lo,
                                    x_hi, y, beta, stream);
 }
+
+int lsk_csr_compress_cols_u32(int64_t nnz, const int64_t *col, int64_t x_lo, int64_t x_hi,
+                               uint32_t *col32, lsk_stream_t stream) {
+    if (nnz < 0) return lsk::fail(LSK_ERR_ARG, "lsk_csr_compress_cols_u32: negative nnz");
+    if (nnz == 0) return LSK_OK;
+    if (!col || !col32) return lsk::fail(LSK_ERR_ARG, "lsk_csr_compress_cols_u32: null pointer");
+    if (x_hi >= x_lo && x_hi - x_lo >= 0xffffffffLL)
+        return lsk::fail(LSK_ERR_UNSUPPORTED,
+                         "lsk_csr_compress_cols_u32: a window of %lld columns does not fit 32-bit offsets",
+                         (long long)(x_hi - x_lo + 1));
+    int64_t blocks = lsk::ceil_div(nnz, kBlock * 4);
+    if (blocks > lsk::kMaxGridBlocks) blocks = lsk::kMaxGridBlocks;
+    compress_cols_kernel<<<static_cast<unsigned>(blocks), kBlock, 0, lsk::as_stream(stream)>>>(nnz, col, x_lo,
+                                                                                               x_hi, col32);
+    LSK_LAUNCH_CHECK();
+    return LSK_OK;
+}
+
+#define LSK_C32(SUF, T)                                                                               \
+    int lsk_csr_spmv_c32_##SUF(int64_t rows, int64_t nnz, const int64_t *rects, int64_t k_base,       \
+                               const uint32_t *col32, const T *val, const T *x, int64_t x_extent, T *y, \
+                               int beta, lsk_stream_t stream) {                                       \
+        if (x_extent < 0 || x_extent > 0xffffffffLL)                                                  \
+            return lsk::fail(LSK_ERR_ARG, "lsk_csr_spmv_c32_" #SUF ": window of %lld columns",        \
+                             (long long)x_extent);                                                    \
+        return launch_csr_spmv<T, uint32_t>("lsk_csr_spmv_c32_" #SUF, rows, nnz, rects, k_base, col32, val, x, \
+                                            0, x_extent - 1, y, beta, stream);                        \
+    }                                                                                                 \
+    int lsk_csr_spmv_c32_dot_##SUF(int64_t rows, int64_t nnz, const int64_t *rects, int64_t k_base,   \
+                                   const uint32_t *col32, const T *val, const T *x, int64_t x_extent, \
+                                   T *y, int beta, const T *w, T *partials, int64_t capacity,         \
+                                   int64_t *count, lsk_stream_t stream) {                             \
+        if (!w) return lsk::fail(LSK_ERR_ARG, "lsk_csr_spmv_c32_dot_" #SUF ": null w");               \
+        if (x_extent < 0 || x_extent > 0xffffffffLL)                                                  \
+            return lsk::fail(LSK_ERR_ARG, "lsk_csr_spmv_c32_dot_" #SUF ": window of %lld columns",    \
+                             (long long)x_extent);                                                    \
+        return launch_csr_spmv<T, uint32_t>("lsk_csr_spmv_c32_dot_" #SUF, rows, nnz, rects, k_base, col32, val, \
+                                            x, 0, x_extent - 1, y, beta, stream, w, partials, capacity, count); \
+    }                                                                                                 \
+    int lsk_csr_spmv_c32_tune_##SUF(int64_t rows, int64_t nnz, const int64_t *rects, int64_t k_base,  \
+                                    const uint32_t *col32, const T *val, const T *x, int64_t x_extent, \
+                                    T *y, lsk_stream_t stream, int *remap_out, float *ms_out) {       \
+        if (x_extent < 0 || x_extent > 0xffffffffLL)                                                  \
+            return lsk::fail(LSK_ERR_ARG, "lsk_csr_spmv_c32_tune_" #SUF ": window of %lld columns",   \
+                             (long long)x_extent);                                                    \
+        return tune_csr_spmv<T, uint32_t>("lsk_csr_spmv_c32_tune_" #SUF, rows, nnz, rects, k_base, col32, val, \
+                                          x, 0, x_extent - 1, y, stream, remap_out, ms_out);          \
+    }
+LSK_C32(f32, float)
+LSK_C32(f64, double)
+#undef LSK_C32
 
 int lsk_rects_to_indptr_i64(int64_t rows, const int64_t *rects, int64_t *indptr,
                             lsk_stream_t stream) {

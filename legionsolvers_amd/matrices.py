@@ -13,6 +13,7 @@ on the device.  `matvec` is one leaf launch per local piece.
 from __future__ import annotations
 
 import os
+import sys
 from dataclasses import dataclass
 from typing import List, Tuple
 
@@ -72,6 +73,8 @@ class CSRMatrix(AbstractMatrix):
         self.rows = rects.shape[0]
         self.nnz = col.numel()
         self.placement = {}  # piece colour -> tile placement found by tune()
+        self.col32 = None         # compress(): the column field as 32-bit offsets into ...
+        self.col32_window = None  # ... this window (x_lo, x_hi)
 
     TUNE_MIN_ROWS = 1 << 21  # pieces below this are not worth the ~30 trial launches
     FUSE_DOT_MAX_ROW_LENGTH = 16.0
@@ -84,6 +87,28 @@ class CSRMatrix(AbstractMatrix):
         if override is not None:
             return override != "0"
         return self.rows > 0 and self.nnz / self.rows <= self.FUSE_DOT_MAX_ROW_LENGTH
+
+    def compress(self, x_lo: int, x_hi: int) -> bool:
+        """Set-up-time copy of the column field as 32-bit offsets into the window x_lo..x_hi of
+        the input vector (the ghost interval the planner found for this rank): products against
+        exactly that window then read 4 instead of 8 bytes of index per entry and give
+        bit-identical results.  What the reference redoes on every call for cuSPARSE
+        (src/CuSPARSEHelpers.hpp:71-80), done once.  LSK_COMPRESS=0 turns it off.  Returns
+        whether the copy was made (not for windows of 2^32 - 1 columns or more)."""
+        be = self.ctx.backend
+        maker = getattr(be, "csr_compress_cols", None)
+        if (maker is None or os.environ.get("LSK_COMPRESS", "1") == "0" or x_hi < x_lo or self.nnz == 0
+                or x_hi - x_lo + 1 > be.COMPRESS_MAX_EXTENT):
+            return False
+        self.col32 = maker(self.col, x_lo, x_hi)
+        self.col32_window = (int(x_lo), int(x_hi))
+        return True
+
+    def _cols(self, x_lo: int, x_hi: int) -> torch.Tensor:
+        """The column array a product against the window x_lo..x_hi reads."""
+        if self.col32 is not None and self.col32_window == (x_lo, x_hi):
+            return self.col32
+        return self.col
 
     def tune(self, x_lo, x_hi, kernel_partition, range_partition) -> None:
         """Set-up-time choice of the tile -> XCD placement per piece (the backend times a few
@@ -102,6 +127,7 @@ class CSRMatrix(AbstractMatrix):
         y = torch.empty(max(range_partition.pieces[kernel_partition.colors[i]].volume for i in big),
                         dtype=self.dtype, device=self.val.device)
         self._redraw_arrays(x, x_lo, x_hi, y, kernel_partition, range_partition, big)
+        col = self._cols(x_lo, x_hi)
         for i, c in enumerate(kernel_partition.colors):
             p = range_partition.pieces[c]
             k_lo, k_hi = kernel_partition.intervals[i]
@@ -111,7 +137,7 @@ class CSRMatrix(AbstractMatrix):
             r0 = p.lo[0] - self.row_lo
             off = k_lo - self.k_base
             self.placement[c], _ = tuner(p.volume, nnz, self.rects[r0:r0 + p.volume], k_lo,
-                                         self.col[off:off + nnz], self.val[off:off + nnz], x, x_lo, x_hi, y)
+                                         col[off:off + nnz], self.val[off:off + nnz], x, x_lo, x_hi, y)
 
     def halo_split(self, own_lo: int, own_hi: int, kernel_partition, range_partition):
         """For every local piece, its rows in three runs: [0, a) read ghost cells below own_lo,
@@ -163,9 +189,13 @@ class CSRMatrix(AbstractMatrix):
         redraws = int(os.environ.get("LSK_TUNE_REDRAWS", str(self.REDRAWS)))
         if redraws <= 0 or not self.val.is_cuda or getattr(self.ctx.backend, "csr_spmv_tune", None) is None:
             return
-        need = sum(t.numel() * t.element_size() for t in (self.rects, self.col, self.val))
+        compressed = self._cols(x_lo, x_hi) is not self.col  # then the 64-bit field is not on the path
+        need = sum(t.numel() * t.element_size()
+                   for t in (self.rects, self.col32 if compressed else self.col, self.val))
 
         def time_current() -> float:
+            col = self._cols(x_lo, x_hi)
+
             def sweep():
                 for i in pieces:
                     c = kernel_partition.colors[i]
@@ -173,7 +203,7 @@ class CSRMatrix(AbstractMatrix):
                     k_lo, k_hi = kernel_partition.intervals[i]
                     r0, off, nnz = p.lo[0] - self.row_lo, k_lo - self.k_base, k_hi - k_lo + 1
                     self.ctx.backend.csr_spmv(p.volume, nnz, self.rects[r0:r0 + p.volume], k_lo,
-                                              self.col[off:off + nnz], self.val[off:off + nnz], x, x_lo, x_hi,
+                                              col[off:off + nnz], self.val[off:off + nnz], x, x_lo, x_hi,
                                               y, 0, self.placement.get(c, 0))
             for _ in range(2):
                 sweep()
@@ -190,13 +220,19 @@ class CSRMatrix(AbstractMatrix):
             free, _total = torch.cuda.mem_get_info(self.val.device)
             if free < need + (2 << 30):
                 break
-            old = (self.rects, self.col, self.val)
-            self.rects, self.col, self.val = (t.clone() for t in old)
+            if compressed:
+                old = (self.rects, self.col32, self.val)
+                self.rects, self.col32, self.val = (t.clone() for t in old)
+            else:
+                old = (self.rects, self.col, self.val)
+                self.rects, self.col, self.val = (t.clone() for t in old)
             t = time_current()
             if os.environ.get("LSK_TUNE_VERBOSE"):
-                print(f"[lsk] array placement: {best:.3f} ms held, {t:.3f} ms redrawn", flush=True)
+                print(f"[lsk] array placement: {best:.3f} ms held, {t:.3f} ms redrawn", file=sys.stderr, flush=True)
             if t < best:
                 best = t
+            elif compressed:
+                self.rects, self.col32, self.val = old
             else:
                 self.rects, self.col, self.val = old
             del old
@@ -239,6 +275,7 @@ class CSRMatrix(AbstractMatrix):
         if touch is not None:
             touch()
         pieces = []
+        col = self._cols(x_lo, x_hi)
         for i, c in enumerate(kernel_partition.colors):
             p = range_partition.pieces[c]
             rows = p.volume
@@ -255,14 +292,14 @@ class CSRMatrix(AbstractMatrix):
                     n_run = max(kb - ka + 1, 0)
                     off = (ka - self.k_base) if n_run else 0
                     be.csr_spmv(rb - ra, n_run, self.rects[r0 + ra:r0 + rb], ka if n_run else self.k_base,
-                                self.col[off:off + n_run], self.val[off:off + n_run], x, x_lo, x_hi,
+                                col[off:off + n_run], self.val[off:off + n_run], x, x_lo, x_hi,
                                 dst.piece(i)[ra:rb], beta, self.placement.get(c, 0))
                 continue
             if split is not None and phase == 0:
                 continue  # a piece without a split entry (no entries) goes with the late phase
             off = (k_lo - self.k_base) if nnz else 0
             args = (rows, nnz, self.rects[r0:r0 + rows], k_lo if nnz else self.k_base,
-                    self.col[off:off + nnz], self.val[off:off + nnz], x, x_lo, x_hi, dst.piece(i), beta)
+                    col[off:off + nnz], self.val[off:off + nnz], x, x_lo, x_hi, dst.piece(i), beta)
             if fused:
                 buf = dst._partials("mv", i, be.csr_spmv_dot_slots(rows, nnz, self.dtype))
                 pieces.append((buf, be.csr_spmv_dot(*args, dot_with.piece(i), buf, self.placement.get(c, 0))))

@@ -109,9 +109,14 @@ class SquarePlanner:
         mine = (domain_partition.rank_interval(rank, world), _hull(ghost_partition.intervals))
         everyone = self.ctx.comm.all_gather_object(mine)
         plan = build_halo_plan(rank, [e[0] for e in everyone], [e[1] for e in everyone])
+        # The window of x every product of this matrix will be given (see _gather_ghost).
+        own = domain_partition.rank_interval(rank, world)
+        window = (own[0] - plan.pad_lo, own[1] + plan.pad_hi) if (plan.recvs or plan.sends) else own
+        compress = getattr(matrix, "compress", None)
+        if compress is not None and getattr(matrix, "col32", None) is None:
+            compress(window[0], window[1])
         tune = getattr(matrix, "tune", None)
         if tune is not None and not getattr(matrix, "_tuned", False):
-            window = _hull(ghost_partition.intervals)
             tune(window[0], window[1], kernel_partition, range_partition)
             matrix._tuned = True
         split = None

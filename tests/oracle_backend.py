@@ -93,8 +93,19 @@ class OracleBackend:
         bv = b.item() if b is not None else 0.0
         out[0] = float(oracle.scalar_op(_OPS[op], a.item(), bv, _np(a).dtype))
 
+    COMPRESS_MAX_EXTENT = 0xFFFFFFFF - 1
+
+    def csr_compress_cols(self, col, x_lo, x_hi):
+        c = _np(col)
+        inside = (c >= x_lo) & (c <= x_hi)
+        return torch.from_numpy(np.where(inside, c - x_lo, 0xFFFFFFFF).astype(np.uint32).view(np.int32))
+
     def csr_spmv(self, rows, nnz, rects, k_base, col, val, x, x_lo, x_hi, y, beta, placement=0):
-        oracle.csr_matvec(_np(rects), k_base, _np(col), _np(val), _np(x), x_lo, x_hi, _np(y), beta=beta)
+        c = _np(col)
+        if c.dtype == np.int32:  # compressed: offsets into the window, 0xffffffff = outside it
+            u = c.view(np.uint32).astype(np.int64)
+            c = np.where(u == 0xFFFFFFFF, x_lo - 1, u + x_lo)
+        oracle.csr_matvec(_np(rects), k_base, c, _np(val), _np(x), x_lo, x_hi, _np(y), beta=beta)
 
     def coo_spmv(self, nnz, row, col, val, x, x_lo, x_hi, y, y_lo, y_hi):
         oracle.coo_matvec(_np(row), _np(col), _np(val), _np(x), x_lo, x_hi, _np(y), y_lo, y_hi)

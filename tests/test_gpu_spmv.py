@@ -64,6 +64,24 @@ def csr_case(suf, rects, k_base, col, val, x, x_lo, x_hi, beta=0, y0=None, tag="
     err = np.abs(got.astype(np.float64) - want.astype(np.float64))
     lim = tol * (bound.astype(np.float64) + np.abs(y0) + 1e-300)
     assert np.all(err <= lim), f"{tag}: max err {err.max()} at row {int(np.argmax(err - lim))}"
+    # the same piece with compressed (32-bit, window-relative) columns: the compression is bit-exact,
+    # and the product is bit-identical to the 64-bit wave-tile form
+    c32 = torch.empty(val.size, dtype=torch.int32, device="cuda")
+    _lib.call("lsk_csr_compress_cols_u32", val.size, P(cd), x_lo, x_hi, P(c32), stream())
+    inside = (col >= x_lo) & (col <= x_hi)
+    assert np.array_equal(c32.cpu().numpy().view(np.uint32),
+                          np.where(inside, col - x_lo, 0xFFFFFFFF).astype(np.uint32)), f"{tag}: compression"
+    yc = dev(y0)
+    _lib.call(f"lsk_csr_spmv_c32_{suf}", rows, val.size, P(rd), k_base, P(c32), P(vd), P(xd), x_hi - x_lo + 1,
+              P(yc), beta, stream())
+    got32 = yc.cpu().numpy()
+    variant = ctypes.c_int(0)
+    _lib.call("lsk_get_option", b"csr.variant", ctypes.byref(variant))
+    if variant.value == 1:
+        assert np.array_equal(got32, got), f"{tag}: compressed columns change the result"
+    else:
+        err = np.abs(got32.astype(np.float64) - want.astype(np.float64))
+        assert np.all(err <= lim), f"{tag} (compressed columns): max err {err.max()}"
     return got
 
 
@@ -209,6 +227,82 @@ def test_csr_spmv_misaligned_arrays(suf, csr_variant):
             _lib.call(f"lsk_csr_spmv_{suf}", n, val.size, P(rd), 0, P(cd[coff:]), P(vd[voff:]), P(xd),
                       0, n - 1, P(yd), 0, stream())
             np.testing.assert_allclose(yd.cpu().numpy(), want, rtol=0, atol=tol * 20)
+
+
+@pytest.mark.parametrize("suf", ["f32", "f64"])
+def test_csr_spmv_c32_phases(suf):
+    """Compressed columns with col32 / val handed over at every combination of 16-byte phases,
+    pieces starting at every entry offset mod 4, fused dot and tuner on the compressed form."""
+    npdt, tdt, tol = DT[suf]
+    offs, cfs = oracle.benchmark_stencil_offsets(4)
+    rects, _, col, val = oracle.linearized_stencil((9, 10, 11), offs, cfs, dtype=npdt)
+    n = rects.shape[0]
+    x = np.random.default_rng(61).standard_normal(n).astype(npdt)
+    xd, rd = dev(x), dev(rects)
+    ref = torch.zeros(n, dtype=tdt, device="cuda")
+    col64, val0 = dev(col), dev(val)
+    _lib.call(f"lsk_csr_spmv_{suf}", n, val.size, P(rd), 0, P(col64), P(val0), P(xd), 0, n - 1, P(ref), 0,
+              stream())
+    torch.cuda.synchronize()
+    c32 = (col.astype(np.uint32)).view(np.int32)
+    for coff in range(4):
+        for voff in range(0, 4 if suf == "f32" else 2):
+            print(f"case csr c32 phases {suf} coff={coff} voff={voff}", flush=True)
+            cd = dev(np.concatenate([np.zeros(coff, np.int32), c32]))
+            vd = dev(np.concatenate([np.zeros(voff, npdt), val]))
+            yd = torch.zeros(n, dtype=tdt, device="cuda")
+            _lib.call(f"lsk_csr_spmv_c32_{suf}", n, val.size, P(rd), 0, P(cd[coff:]), P(vd[voff:]), P(xd), n,
+                      P(yd), 0, stream())
+            assert torch.equal(yd, ref)
+    # pieces that start at rows 1..5 (first entry at any offset), window = the piece's image
+    cd, vd = dev(c32), dev(val)
+    for r0 in range(1, 6):
+        k_lo = int(rects[r0, 0])
+        rows = n - r0 - 3
+        nnz = int(rects[r0 + rows - 1, 1]) - k_lo + 1
+        print(f"case csr c32 piece {suf} r0={r0} k_lo={k_lo}", flush=True)
+        yd = torch.zeros(rows, dtype=tdt, device="cuda")
+        _lib.call(f"lsk_csr_spmv_c32_{suf}", rows, nnz, P(rd[r0:]), k_lo, P(cd[k_lo:]), P(vd[k_lo:]), P(xd), n,
+                  P(yd), 0, stream())
+        assert torch.equal(yd, ref[r0:r0 + rows])
+    # fused product + dot on the compressed form: same y, same partial sums as the 64-bit form
+    w = dev(np.random.default_rng(62).standard_normal(n).astype(npdt))
+    slots = int(_lib.lib().lsk_csr_spmv_dot_partials(n, val.size, 4 if suf == "f32" else 8))
+    out = []
+    for name, cols, window in (("lsk_csr_spmv_dot", col64, (0, n - 1)), ("lsk_csr_spmv_c32_dot", cd, (n,))):
+        print(f"case {name}_{suf}", flush=True)
+        yd = torch.zeros(n, dtype=tdt, device="cuda")
+        part = torch.full((slots,), 7.0, dtype=tdt, device="cuda")
+        count = ctypes.c_int64(0)
+        _lib.call(f"{name}_{suf}", n, val.size, P(rd), 0, P(cols), P(vd), P(xd), *window, P(yd), 0, P(w), P(part),
+                  slots, ctypes.byref(count), stream())
+        assert torch.equal(yd, ref) and count.value == slots
+        out.append(part.clone())
+    assert torch.equal(out[0], out[1])
+    # tuner on the compressed form returns one of its candidates and a time
+    remap, ms = ctypes.c_int(-1), ctypes.c_float(0.0)
+    yd = torch.zeros(n, dtype=tdt, device="cuda")
+    _lib.call(f"lsk_csr_spmv_c32_tune_{suf}", n, val.size, P(rd), 0, P(cd), P(vd), P(xd), n, P(yd), stream(),
+              ctypes.byref(remap), ctypes.byref(ms))
+    assert remap.value in (0, 16, 64, 256, 1024, 4096) and ms.value > 0 and torch.equal(yd, ref)
+
+
+def test_csr_compress_cols_limits():
+    """A window too wide for 32-bit offsets is refused; an empty window marks every column."""
+    col = dev(np.array([0, 5, 2**33, -3], dtype=np.int64))
+    out = torch.zeros(4, dtype=torch.int32, device="cuda")
+    with pytest.raises(_lib.LskError):
+        _lib.call("lsk_csr_compress_cols_u32", 4, P(col), 0, 2**32, P(out), stream())
+    _lib.call("lsk_csr_compress_cols_u32", 4, P(col), 0, 2**32 - 3, P(out), stream())
+    assert out.cpu().numpy().view(np.uint32).tolist() == [0, 5, 0xFFFFFFFF, 0xFFFFFFFF]
+    _lib.call("lsk_csr_compress_cols_u32", 4, P(col), 10, 9, P(out), stream())
+    assert out.cpu().numpy().view(np.uint32).tolist() == [0xFFFFFFFF] * 4
+    # a product against an empty window: y <- 0
+    rects = dev(np.array([[0, 1], [2, 3]], dtype=np.int64))
+    y = torch.ones(2, dtype=torch.float64, device="cuda")
+    val = torch.ones(4, dtype=torch.float64, device="cuda")
+    _lib.call("lsk_csr_spmv_c32_f64", 2, 4, P(rects), 0, P(out), P(val), None, 0, P(y), 0, stream())
+    assert y.tolist() == [0.0, 0.0]
 
 
 @pytest.fixture(params=[1, 0], ids=["wave-scan", "workgroup-chunks"])
