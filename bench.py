@@ -12,8 +12,8 @@ on the device and resident in HBM before the timed region.  Rank 0 prints ONE JS
 
 Besides the contract's fields the line carries:
   roofline      the CSR SpMV kernel of the timed steps against the HBM roof: algorithmic bytes of
-                one launch in the layout it reads (nnz*12 + rows*32 on this rank with the set-up-time
-                32-bit columns, nnz*16 + rows*32 without) / its mean duration from HIP events
+                one launch in the layout it reads (nnz*12 + rows*20 on this rank with the set-up-time
+                32-bit structure, nnz*16 + rows*32 without) / its mean duration from HIP events
   roofline_int64_columns   the same for the kernel that reads the reference's 64-bit column field
   cpu_baseline  the CPU oracle's CG step (OpenMP over row blocks) on a bounded 27-point sample,
                 rank 0 at N = 1 only
@@ -42,7 +42,7 @@ HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak
 def spmv_kernel_time(ctx, matrix, planner, reps: int, compressed: bool = True) -> float:
     """Mean seconds of one CSR SpMV launch on this rank (the kernel alone, no halo traffic),
     from HIP events recorded on the launch stream.  compressed=False times the form that reads
-    the reference's 64-bit column field instead of the set-up-time 32-bit copy."""
+    the reference's 64-bit columns and rects instead of the set-up-time 32-bit copies."""
     entry = planner.row_partitioned_matrices[0]
     src = planner.get_vector(2, 0)  # P
     dst = planner.get_vector(3, 0)  # Q
@@ -138,11 +138,13 @@ def main():
     # the dominant kernel against its roofline (this rank's launch)
     # (bytes of the layout the kernel reads: 4-byte columns when the set-up copy exists, else 8)
     compressed = matrix.col32 is not None
-    col_bytes = 4 if compressed else 8
+    col_bytes = 4 if compressed else 8       # per entry, beside the 8-byte value
+    row_bytes = 4 + 16 if compressed else 32  # per row: offset or rect, x once, y once
     t_spmv = spmv_kernel_time(ctx, matrix, planner, reps=20, compressed=compressed)
-    algo_bytes = matrix.nnz * (8 + col_bytes) + matrix.rows * 32
+    algo_bytes = matrix.nnz * (8 + col_bytes) + matrix.rows * row_bytes
     achieved = algo_bytes / t_spmv / 1e9
-    spmv_gbps_job = (nnz_total * (8 + col_bytes) + rows * 32) / ctx.comm.max_over_ranks(t_spmv, ctx.device) / 1e9
+    spmv_gbps_job = ((nnz_total * (8 + col_bytes) + rows * row_bytes)
+                     / ctx.comm.max_over_ranks(t_spmv, ctx.device) / 1e9)
     # the same product on the reference's own 64-bit column field, for comparison
     t_spmv64 = spmv_kernel_time(ctx, matrix, planner, reps=20, compressed=False) if compressed else t_spmv
     algo_bytes64 = matrix.nnz * 16 + matrix.rows * 32
@@ -178,8 +180,9 @@ def main():
                         "3-D 27-pt stencil, fp64 CSR with int64 indices and 16-byte row rects, "
                         "rhs=1, x0=0, one row block per GPU",
             "rows": rows, "nnz": nnz_total, "pieces": world,
-            "column_layout": ("32-bit window-relative copy of the int64 column field, made once at set-up "
-                              "(bit-identical products)") if compressed else "int64 global columns as handed over",
+            "structure_layout": ("32-bit copies of the structure made once at set-up (window-relative columns, "
+                                 "row offsets); bit-identical products") if compressed
+                                else "int64 global columns and 16-byte rects as handed over",
         },
         "spmv_gbps": spmv_gbps_job,
         "two_system_iters_per_s": two_system,

@@ -291,37 +291,49 @@ int lsk_csr_spmv_tune_f64(int64_t rows, int64_t nnz, const int64_t *rects, int64
                           const int64_t *col, const double *val, const double *x, int64_t x_lo,
                           int64_t x_hi, double *y, lsk_stream_t stream, int *remap_out, float *ms_out);
 
-/* Compressed columns: the set-up-time replacement for the per-call rebasing of
- * src/CuSPARSEHelpers.hpp:71-80 (the reference converts its 64-bit global indices for cuSPARSE
- * on EVERY call; here the conversion is done once and kept by the caller beside the matrix).
- * lsk_csr_compress_cols_u32 writes col32[k] = col[k] - x_lo for columns inside x_lo..x_hi and
- * 0xffffffff for the others (which every product skips, as the 64-bit form skips them); the
- * window must span fewer than 2^32 - 1 columns (else LSK_ERR_UNSUPPORTED and the caller stays
- * with the 64-bit form).  lsk_csr_spmv_c32_* is lsk_csr_spmv_* on that array: `x` points at the
- * window's first element, `x_extent` = x_hi - x_lo + 1 of the compression.  It reads 4 bytes of
- * index per entry instead of 8; tiles and the order of additions are the same, so y is
- * bit-identical to lsk_csr_spmv_*.  _dot_ and _tune_ as the 64-bit entry points of those names. */
+/* Compressed structure: the set-up-time replacement for the per-call rebasing of
+ * src/CuSPARSEHelpers.hpp:9-31,71-80 (the reference converts its rects to 0-based offsets and
+ * hands cuSPARSE 64-bit indices on EVERY call; here the conversion is done once and kept by the
+ * caller beside the matrix piece).
+ *   lsk_csr_compress_cols_u32: col32[k] = col[k] - x_lo for columns inside x_lo..x_hi, 0xffffffff
+ *     for the others (which every product skips, as the 64-bit form skips them).  The window must
+ *     span fewer than 2^32 - 1 columns, else LSK_ERR_UNSUPPORTED.
+ *   lsk_csr_compress_rows_u32: rowoff32[r] = rects[r].lo - k_base for r < rows, rowoff32[rows] =
+ *     rects[rows-1].hi + 1 - k_base (rows + 1 values: offsets into the piece's col/val arrays, the
+ *     classic CSR row pointer).  Needs rects that are back to back, ascending and inside the piece,
+ *     and nnz < 2^32; else LSK_ERR_UNSUPPORTED (blocks until the check has run; uses the library's
+ *     per-device scratch).
+ * In both cases a caller that gets LSK_ERR_UNSUPPORTED stays with lsk_csr_spmv_* (that answer never
+ * aborts, whatever lsk_set_abort_on_error says).
+ * lsk_csr_spmv_c32_* is lsk_csr_spmv_* on those arrays: `x` points at the window's first
+ * element, `x_extent` = x_hi - x_lo + 1 of the compression; a run of rows [a, b) of the piece is
+ * multiplied by passing rowoff32 + a, rows = b - a and the same col32 / val.  It reads 4 bytes of
+ * column and 4 of row structure instead of 8 and 16; tiles and the order of additions are the
+ * same, so y is bit-identical to lsk_csr_spmv_*.  _dot_ and _tune_ as the 64-bit entry points
+ * of those names. */
 int lsk_csr_compress_cols_u32(int64_t nnz, const int64_t *col, int64_t x_lo, int64_t x_hi,
                               uint32_t *col32, lsk_stream_t stream);
-int lsk_csr_spmv_c32_f32(int64_t rows, int64_t nnz, const int64_t *rects, int64_t k_base,
-                         const uint32_t *col32, const float *val, const float *x, int64_t x_extent,
-                         float *y, int beta, lsk_stream_t stream);
-int lsk_csr_spmv_c32_f64(int64_t rows, int64_t nnz, const int64_t *rects, int64_t k_base,
-                         const uint32_t *col32, const double *val, const double *x, int64_t x_extent,
-                         double *y, int beta, lsk_stream_t stream);
-int lsk_csr_spmv_c32_dot_f32(int64_t rows, int64_t nnz, const int64_t *rects, int64_t k_base,
+int lsk_csr_compress_rows_u32(int64_t rows, int64_t nnz, const int64_t *rects, int64_t k_base,
+                              uint32_t *rowoff32, lsk_stream_t stream);
+int lsk_csr_spmv_c32_f32(int64_t rows, int64_t nnz, const uint32_t *rowoff32, const uint32_t *col32,
+                         const float *val, const float *x, int64_t x_extent, float *y, int beta,
+                         lsk_stream_t stream);
+int lsk_csr_spmv_c32_f64(int64_t rows, int64_t nnz, const uint32_t *rowoff32, const uint32_t *col32,
+                         const double *val, const double *x, int64_t x_extent, double *y, int beta,
+                         lsk_stream_t stream);
+int lsk_csr_spmv_c32_dot_f32(int64_t rows, int64_t nnz, const uint32_t *rowoff32,
                              const uint32_t *col32, const float *val, const float *x,
                              int64_t x_extent, float *y, int beta, const float *w, float *partials,
                              int64_t capacity, int64_t *count, lsk_stream_t stream);
-int lsk_csr_spmv_c32_dot_f64(int64_t rows, int64_t nnz, const int64_t *rects, int64_t k_base,
+int lsk_csr_spmv_c32_dot_f64(int64_t rows, int64_t nnz, const uint32_t *rowoff32,
                              const uint32_t *col32, const double *val, const double *x,
                              int64_t x_extent, double *y, int beta, const double *w, double *partials,
                              int64_t capacity, int64_t *count, lsk_stream_t stream);
-int lsk_csr_spmv_c32_tune_f32(int64_t rows, int64_t nnz, const int64_t *rects, int64_t k_base,
+int lsk_csr_spmv_c32_tune_f32(int64_t rows, int64_t nnz, const uint32_t *rowoff32,
                               const uint32_t *col32, const float *val, const float *x,
                               int64_t x_extent, float *y, lsk_stream_t stream, int *remap_out,
                               float *ms_out);
-int lsk_csr_spmv_c32_tune_f64(int64_t rows, int64_t nnz, const int64_t *rects, int64_t k_base,
+int lsk_csr_spmv_c32_tune_f64(int64_t rows, int64_t nnz, const uint32_t *rowoff32,
                               const uint32_t *col32, const double *val, const double *x,
                               int64_t x_extent, double *y, lsk_stream_t stream, int *remap_out,
                               float *ms_out);

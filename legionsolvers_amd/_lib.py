@@ -18,6 +18,7 @@ LIB_PATH = os.environ.get("LSK_LIBRARY") or os.path.join(PKG_DIR, "liblsk.so")  
 HEADER_PATH = os.path.join(os.path.dirname(PKG_DIR), "include", "lsk.h")
 
 LSK_OK = 0
+LSK_ERR_UNSUPPORTED = -4
 UNIQUE_ID_BYTES = 128
 
 SOP_NEG, SOP_ADD, SOP_SUB, SOP_MUL, SOP_DIV, SOP_SQRT, SOP_RSQRT, SOP_COPY = range(8)
@@ -72,6 +73,7 @@ PROTOTYPES = {
     "lsk_index_bounds_i64": (_i, [_i64, _p, _p, _p]),
     "lsk_csr_halo_rows_i64": (_i, [_i64, _i64, _p, _i64, _p, _i64, _i64, _p, _p]),
     "lsk_csr_compress_cols_u32": (_i, [_i64, _p, _i64, _i64, _p, _p]),
+    "lsk_csr_compress_rows_u32": (_i, [_i64, _i64, _p, _i64, _p, _p]),
     "lsk_stencil_count": (_i, [_i, _p, _i, _p, _i64, _i64, _p, _p]),
     "lsk_rects_from_counts_i64": (_i, [_i64, _p, _p, _i64, _p, _p]),
     "lsk_task_id_t": (_i64, [_i, _i]),
@@ -107,10 +109,10 @@ PROTOTYPES.update(_typed(_FT, lambda s, t: {
     f"lsk_sum_partials_{s}": (_i, [_i64, _p, _p, _p, _sz, _p]),
     f"lsk_csr_spmv_tune_{s}": (_i, [_i64, _i64, _p, _i64, _p, _p, _p, _i64, _i64, _p, _p,
                                     ctypes.POINTER(_i), ctypes.POINTER(ctypes.c_float)]),
-    f"lsk_csr_spmv_c32_{s}": (_i, [_i64, _i64, _p, _i64, _p, _p, _p, _i64, _p, _i, _p]),
-    f"lsk_csr_spmv_c32_dot_{s}": (_i, [_i64, _i64, _p, _i64, _p, _p, _p, _i64, _p, _i, _p, _p, _i64,
+    f"lsk_csr_spmv_c32_{s}": (_i, [_i64, _i64, _p, _p, _p, _p, _i64, _p, _i, _p]),
+    f"lsk_csr_spmv_c32_dot_{s}": (_i, [_i64, _i64, _p, _p, _p, _p, _i64, _p, _i, _p, _p, _i64,
                                        ctypes.POINTER(_i64), _p]),
-    f"lsk_csr_spmv_c32_tune_{s}": (_i, [_i64, _i64, _p, _i64, _p, _p, _p, _i64, _p, _p,
+    f"lsk_csr_spmv_c32_tune_{s}": (_i, [_i64, _i64, _p, _p, _p, _p, _i64, _p, _p,
                                         ctypes.POINTER(_i), ctypes.POINTER(ctypes.c_float)]),
     f"lsk_coo_spmv_{s}": (_i, [_i64, _p, _p, _p, _p, _i64, _i64, _p, _i64, _i64, _p]),
     f"lsk_stencil_fill_csr_{s}": (_i, [_i, _p, _i, _p, _p, _i64, _i64, _p, _i64, _p, _p, _p]),

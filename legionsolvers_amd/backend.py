@@ -102,7 +102,7 @@ class HipBackend:
             self._placement = placement
         count = ctypes.c_int64(0)
         if col.dtype == torch.int32:
-            _lib.call(f"lsk_csr_spmv_c32_dot_{_lib.suffix(val.dtype)}", rows, nnz, _ptr(rects), k_base, _ptr(col),
+            _lib.call(f"lsk_csr_spmv_c32_dot_{_lib.suffix(val.dtype)}", rows, nnz, _ptr(rects), _ptr(col),
                       _ptr(val), _ptr(x), x_hi - x_lo + 1, _ptr(y), beta, _ptr(w), _ptr(partials),
                       partials.numel(), ctypes.byref(count), self.stream())
             return count.value
@@ -131,13 +131,14 @@ class HipBackend:
                  val: torch.Tensor, x: torch.Tensor, x_lo: int, x_hi: int, y: torch.Tensor,
                  beta: int, placement: int = 0) -> None:
         """`placement`: the piece's tile -> XCD placement found by csr_spmv_tune (a speed hint).
-        `col`: int64 global column ids, or the int32-typed array csr_compress_cols made for the
-        window x_lo..x_hi (x[0] is the window's first element either way)."""
+        `rects`, `col`: the (rows, 2) int64 rects and int64 global column ids, or the int32-typed
+        arrays of csr_compress_rows (rows + 1 offsets) and csr_compress_cols (made for the window
+        x_lo..x_hi; x[0] is the window's first element either way; k_base is then unused)."""
         if placement != self._placement:
             _lib.call("lsk_set_option", b"xcd_remap", placement)
             self._placement = placement
         if col.dtype == torch.int32:
-            _lib.call(f"lsk_csr_spmv_c32_{_lib.suffix(val.dtype)}", rows, nnz, _ptr(rects), k_base, _ptr(col),
+            _lib.call(f"lsk_csr_spmv_c32_{_lib.suffix(val.dtype)}", rows, nnz, _ptr(rects), _ptr(col),
                       _ptr(val), _ptr(x), x_hi - x_lo + 1, _ptr(y), beta, self.stream())
             return
         _lib.call(f"lsk_csr_spmv_{_lib.suffix(val.dtype)}", rows, nnz, _ptr(rects), k_base, _ptr(col),
@@ -150,7 +151,7 @@ class HipBackend:
         piece; y is overwritten.  Synchronises."""
         remap, ms = ctypes.c_int(0), ctypes.c_float(0.0)
         if col.dtype == torch.int32:
-            _lib.call(f"lsk_csr_spmv_c32_tune_{_lib.suffix(val.dtype)}", rows, nnz, _ptr(rects), k_base, _ptr(col),
+            _lib.call(f"lsk_csr_spmv_c32_tune_{_lib.suffix(val.dtype)}", rows, nnz, _ptr(rects), _ptr(col),
                       _ptr(val), _ptr(x), x_hi - x_lo + 1, _ptr(y), self.stream(), ctypes.byref(remap),
                       ctypes.byref(ms))
             return remap.value, ms.value
@@ -171,6 +172,19 @@ class HipBackend:
         uint32 in an int32 tensor; 0xffffffff marks a column outside the window)."""
         out = torch.empty(col.numel(), dtype=torch.int32, device=self.device)
         _lib.call("lsk_csr_compress_cols_u32", col.numel(), _ptr(col), x_lo, x_hi, _ptr(out), self.stream())
+        return out
+
+    def csr_compress_rows(self, rects: torch.Tensor, k_base: int, nnz: int):
+        """rows + 1 32-bit offsets into the piece's col/val arrays (the classic row pointer; bit
+        pattern of uint32 in an int32 tensor), or None when the rects are not back to back inside
+        the piece or nnz does not fit.  Synchronises."""
+        rows = rects.shape[0]
+        out = torch.empty(rows + 1, dtype=torch.int32, device=self.device)
+        code = getattr(self.lib, "lsk_csr_compress_rows_u32")(rows, nnz, _ptr(rects), k_base, _ptr(out),
+                                                             self.stream())
+        if code == _lib.LSK_ERR_UNSUPPORTED:
+            return None
+        _lib.check(code)
         return out
 
     def csr_halo_rows(self, rows: int, nnz: int, rects: torch.Tensor, k_base: int, col: torch.Tensor,

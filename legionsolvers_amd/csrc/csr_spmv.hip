@@ -70,6 +70,28 @@ template <> struct ColOps<uint32_t> {
     static __device__ __forceinline__ uint32_t off(uint32_t c, int64_t) { return c; }
 };
 
+// Row field: with 64-bit columns the reference's {lo, hi} rects of global entry indices; with the
+// compressed form rows + 1 32-bit offsets of each row's first entry from the start of the piece's
+// col / val arrays (validated when they were made: ascending, inside the piece).
+template <typename CT> struct RowField;
+template <> struct RowField<int64_t> {
+    using type = Rect;
+    static __device__ __forceinline__ void bounds(const Rect *p, int64_t r, int64_t k_base, int64_t nnz,
+                                                  int64_t &lo, int64_t &hi) {
+        const Rect rc = p[r]; // clipped to the piece so that a malformed rect cannot fault
+        lo = rc.lo > k_base ? rc.lo : k_base;
+        hi = rc.hi < k_base + nnz - 1 ? rc.hi : k_base + nnz - 1;
+    }
+};
+template <> struct RowField<uint32_t> {
+    using type = uint32_t;
+    static __device__ __forceinline__ void bounds(const uint32_t *p, int64_t r, int64_t, int64_t,
+                                                  int64_t &lo, int64_t &hi) {
+        lo = p[r];
+        hi = static_cast<int64_t>(p[r + 1]) - 1;
+    }
+};
+
 template <typename T> struct Native;
 template <> struct Native<double> { using V = d2_t; };
 template <> struct Native<float> { using V = f4_t; };
@@ -257,17 +279,16 @@ __global__ __launch_bounds__(kBlock) void csr_spmv_kernel(
 // One row of the tile per wave, entries straight from HBM (wave-level form of rows_by_wave).
 // With w != nullptr lane 0 also adds y_new[r] * w[r] into *dot_acc.
 template <typename T, typename CT>
-__device__ void wave_rows_direct(int nr, const Rect *__restrict__ rects, int64_t k_base,
+__device__ void wave_rows_direct(int nr, const typename RowField<CT>::type *__restrict__ rects, int64_t k_base,
                                  int64_t nnz, const CT *__restrict__ col,
                                  const T *__restrict__ val, const T *__restrict__ x, int64_t x_lo,
                                  int64_t x_hi, T *__restrict__ y, int beta,
                                  const T *__restrict__ w = nullptr, T *dot_acc = nullptr) {
     const int lane = threadIdx.x % lsk::kWave;
     for (int r = 0; r < nr; ++r) {
-        const Rect rc = rects[r];
         T acc = T(0);
-        const int64_t lo = rc.lo > k_base ? rc.lo : k_base;
-        const int64_t hi = rc.hi < k_base + nnz - 1 ? rc.hi : k_base + nnz - 1;
+        int64_t lo, hi;
+        RowField<CT>::bounds(rects, r, k_base, nnz, lo, hi);
         for (int64_t k = lo + lane; k <= hi; k += lsk::kWave) {
             const CT c = col[k - k_base];
             if (ColOps<CT>::in(c, x_lo, x_hi)) acc = fma_t(val[k - k_base], x[ColOps<CT>::off(c, x_lo)], acc);
@@ -490,7 +511,7 @@ template <typename T, typename CT, int LOG_ROWS, bool NT, int KMAX, bool DOT>
 #define LSK_MIN_WAVES 4
 #endif
 __global__ __launch_bounds__(kBlock, LSK_MIN_WAVES) void csr_spmv_wave_kernel( // at least 4 waves per SIMD: <= 128 VGPRs
-    int64_t rows, const Rect *__restrict__ rects, int64_t k_base, int64_t nnz,
+    int64_t rows, const typename RowField<CT>::type *__restrict__ rects, int64_t k_base, int64_t nnz,
     const CT *__restrict__ col, const T *__restrict__ val, const T *__restrict__ x,
     int64_t x_lo, int64_t x_hi, T *__restrict__ y, int beta, int remap,
     const T *__restrict__ w, T *__restrict__ partials) {
@@ -528,7 +549,30 @@ __global__ __launch_bounds__(kBlock, LSK_MIN_WAVES) void csr_spmv_wave_kernel( /
         }
     }
 
-    // ---- 1. rects ------------------------------------------------------------------------
+    // ---- 1. rects (or row offsets) --------------------------------------------------------
+    long long k0;
+    int rel_lo[RPL], rel_end[RPL]; // this lane's rows relative to k0 (32-bit once validated)
+    bool ok = true;
+    if constexpr (sizeof(CT) == 4) {
+        // offsets were validated when they were made; only a tile too long for 32-bit
+        // arithmetic below (rows of 2^30 entries) is sent the slow way
+        const uint32_t *off = rects + r0;
+        uint32_t lo32[RPL], end32[RPL];
+#pragma unroll
+        for (int j = 0; j < RPL; ++j) {
+            const int row = j * lsk::kWave + lane;
+            lo32[j] = off[row < nr ? row : nr];
+            end32[j] = off[row < nr ? row + 1 : nr];
+        }
+        const uint32_t first = __builtin_amdgcn_readfirstlane(lo32[0]);
+        k0 = first;
+#pragma unroll
+        for (int j = 0; j < RPL; ++j) {
+            ok = ok && (end32[j] - first <= 0x3fffffffu);
+            rel_lo[j] = static_cast<int>(lo32[j] - first);
+            rel_end[j] = static_cast<int>(end32[j] - first);
+        }
+    } else {
     Rect rc[RPL];
 #pragma unroll
     for (int j = 0; j < RPL; ++j) {
@@ -536,9 +580,7 @@ __global__ __launch_bounds__(kBlock, LSK_MIN_WAVES) void csr_spmv_wave_kernel( /
         rc[j] = Rect{0, -1};
         if (row < nr) rc[j] = rects[r0 + row];
     }
-    const long long k0 = lsk::wave_first(rc[0].lo);
-    int rel_lo[RPL], rel_end[RPL]; // this lane's rows relative to k0 (32-bit once validated)
-    bool ok = true;
+    k0 = lsk::wave_first(rc[0].lo);
 #pragma unroll
     for (int j = 0; j < RPL; ++j) {
         const long long lo64 = rc[j].lo - k0, end64 = rc[j].hi + 1 - k0;
@@ -558,6 +600,7 @@ __global__ __launch_bounds__(kBlock, LSK_MIN_WAVES) void csr_spmv_wave_kernel( /
             if (lane == lsk::kWave - 1) next_lo = wrap;
         }
         if (row < nr - 1) ok = ok && (next_lo == rel_end[j]);
+    }
     }
     if (!__all(ok)) {
         wave_rows_direct<T, CT>(nr, rects + r0, k_base, nnz, col, val, x, x_lo, x_hi, y + r0, beta, wt, &dot_acc);
@@ -662,7 +705,7 @@ __global__ void store_zero_kernel(T *out) { *out = T(0); }
 // w != nullptr selects the fused form: besides y, partials[0 .. *count) receive per-wave sums
 // of y_new[r] * w[r] (w[0] pairs with the piece's first row).
 template <typename T, typename CT = int64_t>
-int launch_csr_spmv(const char *name, int64_t rows, int64_t nnz, const int64_t *rects,
+int launch_csr_spmv(const char *name, int64_t rows, int64_t nnz, const void *rects,
                     int64_t k_base, const CT *col, const T *val, const T *x, int64_t x_lo,
                     int64_t x_hi, T *y, int beta, lsk_stream_t stream, const T *w = nullptr,
                     T *partials = nullptr, int64_t capacity = 0, int64_t *count = nullptr) {
@@ -679,9 +722,10 @@ int launch_csr_spmv(const char *name, int64_t rows, int64_t nnz, const int64_t *
     if (!rects || !y) return lsk::fail(LSK_ERR_ARG, "%s: null rects or output", name);
     if (nnz > 0 && (!col || !val)) return lsk::fail(LSK_ERR_ARG, "%s: null kernel arrays", name);
     if (x_hi >= x_lo && !x) return lsk::fail(LSK_ERR_ARG, "%s: null input vector", name);
-    if (!lsk::aligned16(rects))
-        return lsk::fail(LSK_ERR_ALIGN, "%s: rects must be 16-byte aligned", name);
     constexpr bool C32 = sizeof(CT) == 4;
+    if (C32 ? (reinterpret_cast<uintptr_t>(rects) & 3u) != 0 : !lsk::aligned16(rects))
+        return lsk::fail(LSK_ERR_ALIGN, "%s: %s", name,
+                         C32 ? "row offsets must be 4-byte aligned" : "rects must be 16-byte aligned");
     if ((reinterpret_cast<uintptr_t>(col) & (sizeof(CT) - 1)) || (reinterpret_cast<uintptr_t>(val) & (sizeof(T) - 1)))
         return lsk::fail(LSK_ERR_ALIGN, "%s: col/val must be naturally aligned", name);
 
@@ -703,7 +747,7 @@ int launch_csr_spmv(const char *name, int64_t rows, int64_t nnz, const int64_t *
         return LSK_OK;
     }
     const double mean = rows > 0 ? double(nnz) / double(rows) : 0.0;
-    const Rect *rc = reinterpret_cast<const Rect *>(rects);
+    const typename RowField<CT>::type *rc = static_cast<const typename RowField<CT>::type *>(rects);
     hipStream_t s = lsk::as_stream(stream);
     const lsk::Options &tune = lsk::options();
     if (tune.csr_variant == 1 || fused || C32) {
@@ -813,9 +857,29 @@ __global__ __launch_bounds__(kBlock) void rects_to_indptr_kernel(int64_t rows,
     }
 }
 
+// rowoff[r] <- rects[r].lo - k_base, rowoff[rows] <- rects[rows-1].hi + 1 - k_base; *bad is set if
+// the rects are not back to back, ascending and inside the piece [k_base, k_base + nnz).
+__global__ __launch_bounds__(kBlock) void compress_rows_kernel(int64_t rows, int64_t nnz,
+                                                               const Rect *__restrict__ rects, int64_t k_base,
+                                                               uint32_t *__restrict__ rowoff, int *__restrict__ bad) {
+    const int64_t stride = int64_t(gridDim.x) * kBlock;
+    bool wrong = false;
+    for (int64_t r = int64_t(blockIdx.x) * kBlock + threadIdx.x; r < rows; r += stride) {
+        const Rect rc = rects[r];
+        const long long lo = rc.lo - k_base, end = rc.hi + 1 - k_base;
+        wrong = wrong || lo < 0 || end < lo || end > nnz;
+        if (r + 1 < rows) wrong = wrong || rects[r + 1].lo != rc.hi + 1;
+        rowoff[r] = static_cast<uint32_t>(lo);
+        if (r + 1 == rows) rowoff[rows] = static_cast<uint32_t>(end);
+    }
+    if (wrong) *bad = 1; // every writer stores the same value
+}
+
+__global__ void clear_flag_kernel(int *flag) { *flag = 0; }
+
 // Times the candidates of the tile -> XCD placement on this piece and reports the fastest.
 template <typename T, typename CT = int64_t>
-int tune_csr_spmv(const char *name, int64_t rows, int64_t nnz, const int64_t *rects, int64_t k_base,
+int tune_csr_spmv(const char *name, int64_t rows, int64_t nnz, const void *rects, int64_t k_base,
                   const CT *col, const T *val, const T *x, int64_t x_lo, int64_t x_hi, T *y,
                   lsk_stream_t stream, int *remap_out, float *ms_out) {
     static const int candidates[] = {0, 16, 64, 256, 1024, 4096};
@@ -924,9 +988,9 @@ int lsk_csr_compress_cols_u32(int64_t nnz, const int64_t *col, int64_t x_lo, int
     if (nnz == 0) return LSK_OK;
     if (!col || !col32) return lsk::fail(LSK_ERR_ARG, "lsk_csr_compress_cols_u32: null pointer");
     if (x_hi >= x_lo && x_hi - x_lo >= 0xffffffffLL)
-        return lsk::fail(LSK_ERR_UNSUPPORTED,
-                         "lsk_csr_compress_cols_u32: a window of %lld columns does not fit 32-bit offsets",
-                         (long long)(x_hi - x_lo + 1));
+        return lsk::decline(LSK_ERR_UNSUPPORTED,
+                            "lsk_csr_compress_cols_u32: a window of %lld columns does not fit 32-bit offsets",
+                            (long long)(x_hi - x_lo + 1));
     int64_t blocks = lsk::ceil_div(nnz, kBlock * 4);
     if (blocks > lsk::kMaxGridBlocks) blocks = lsk::kMaxGridBlocks;
     compress_cols_kernel<<<static_cast<unsigned>(blocks), kBlock, 0, lsk::as_stream(stream)>>>(nnz, col, x_lo,
@@ -935,38 +999,72 @@ int lsk_csr_compress_cols_u32(int64_t nnz, const int64_t *col, int64_t x_lo, int
     return LSK_OK;
 }
 
+int lsk_csr_compress_rows_u32(int64_t rows, int64_t nnz, const int64_t *rects, int64_t k_base,
+                              uint32_t *rowoff32, lsk_stream_t stream) {
+    if (rows < 0 || nnz < 0) return lsk::fail(LSK_ERR_ARG, "lsk_csr_compress_rows_u32: negative size");
+    if (!rowoff32) return lsk::fail(LSK_ERR_ARG, "lsk_csr_compress_rows_u32: null output");
+    if (nnz > 0xffffffffLL)
+        return lsk::decline(LSK_ERR_UNSUPPORTED, "lsk_csr_compress_rows_u32: %lld entries do not fit 32-bit offsets",
+                         (long long)nnz);
+    hipStream_t s = lsk::as_stream(stream);
+    if (rows == 0) {
+        const uint32_t zero = 0;
+        LSK_HIP(hipMemcpyAsync(rowoff32, &zero, sizeof(zero), hipMemcpyHostToDevice, s));
+        LSK_HIP(hipStreamSynchronize(s));
+        return LSK_OK;
+    }
+    if (!rects) return lsk::fail(LSK_ERR_ARG, "lsk_csr_compress_rows_u32: null rects");
+    if (!lsk::aligned16(rects))
+        return lsk::fail(LSK_ERR_ALIGN, "lsk_csr_compress_rows_u32: rects must be 16-byte aligned");
+    lsk::DeviceState *st = nullptr;
+    if (int rc = lsk::device_state(&st)) return rc;
+    int *flag = static_cast<int *>(st->scratch);
+    clear_flag_kernel<<<1, 1, 0, s>>>(flag);
+    int64_t blocks = lsk::ceil_div(rows, kBlock);
+    if (blocks > lsk::kMaxGridBlocks) blocks = lsk::kMaxGridBlocks;
+    compress_rows_kernel<<<static_cast<unsigned>(blocks), kBlock, 0, s>>>(
+        rows, nnz, reinterpret_cast<const Rect *>(rects), k_base, rowoff32, flag);
+    LSK_LAUNCH_CHECK();
+    int bad = 0;
+    LSK_HIP(hipMemcpyAsync(&bad, flag, sizeof(bad), hipMemcpyDeviceToHost, s));
+    LSK_HIP(hipStreamSynchronize(s));
+    if (bad)
+        return lsk::decline(LSK_ERR_UNSUPPORTED,
+                            "lsk_csr_compress_rows_u32: rects are not back to back inside the piece");
+    return LSK_OK;
+}
+
+#define LSK_C32_WINDOW(NAME)                                                                          \
+    if (x_extent < 0 || x_extent > 0xffffffffLL)                                                      \
+        return lsk::fail(LSK_ERR_ARG, NAME ": window of %lld columns", (long long)x_extent);          \
+    if (nnz > 0xffffffffLL) return lsk::fail(LSK_ERR_ARG, NAME ": %lld entries", (long long)nnz)
 #define LSK_C32(SUF, T)                                                                               \
-    int lsk_csr_spmv_c32_##SUF(int64_t rows, int64_t nnz, const int64_t *rects, int64_t k_base,       \
+    int lsk_csr_spmv_c32_##SUF(int64_t rows, int64_t nnz, const uint32_t *rowoff32,                   \
                                const uint32_t *col32, const T *val, const T *x, int64_t x_extent, T *y, \
                                int beta, lsk_stream_t stream) {                                       \
-        if (x_extent < 0 || x_extent > 0xffffffffLL)                                                  \
-            return lsk::fail(LSK_ERR_ARG, "lsk_csr_spmv_c32_" #SUF ": window of %lld columns",        \
-                             (long long)x_extent);                                                    \
-        return launch_csr_spmv<T, uint32_t>("lsk_csr_spmv_c32_" #SUF, rows, nnz, rects, k_base, col32, val, x, \
+        LSK_C32_WINDOW("lsk_csr_spmv_c32_" #SUF);                                                     \
+        return launch_csr_spmv<T, uint32_t>("lsk_csr_spmv_c32_" #SUF, rows, nnz, rowoff32, 0, col32, val, x, \
                                             0, x_extent - 1, y, beta, stream);                        \
     }                                                                                                 \
-    int lsk_csr_spmv_c32_dot_##SUF(int64_t rows, int64_t nnz, const int64_t *rects, int64_t k_base,   \
+    int lsk_csr_spmv_c32_dot_##SUF(int64_t rows, int64_t nnz, const uint32_t *rowoff32,               \
                                    const uint32_t *col32, const T *val, const T *x, int64_t x_extent, \
                                    T *y, int beta, const T *w, T *partials, int64_t capacity,         \
                                    int64_t *count, lsk_stream_t stream) {                             \
         if (!w) return lsk::fail(LSK_ERR_ARG, "lsk_csr_spmv_c32_dot_" #SUF ": null w");               \
-        if (x_extent < 0 || x_extent > 0xffffffffLL)                                                  \
-            return lsk::fail(LSK_ERR_ARG, "lsk_csr_spmv_c32_dot_" #SUF ": window of %lld columns",    \
-                             (long long)x_extent);                                                    \
-        return launch_csr_spmv<T, uint32_t>("lsk_csr_spmv_c32_dot_" #SUF, rows, nnz, rects, k_base, col32, val, \
+        LSK_C32_WINDOW("lsk_csr_spmv_c32_dot_" #SUF);                                                 \
+        return launch_csr_spmv<T, uint32_t>("lsk_csr_spmv_c32_dot_" #SUF, rows, nnz, rowoff32, 0, col32, val, \
                                             x, 0, x_extent - 1, y, beta, stream, w, partials, capacity, count); \
     }                                                                                                 \
-    int lsk_csr_spmv_c32_tune_##SUF(int64_t rows, int64_t nnz, const int64_t *rects, int64_t k_base,  \
+    int lsk_csr_spmv_c32_tune_##SUF(int64_t rows, int64_t nnz, const uint32_t *rowoff32,              \
                                     const uint32_t *col32, const T *val, const T *x, int64_t x_extent, \
                                     T *y, lsk_stream_t stream, int *remap_out, float *ms_out) {       \
-        if (x_extent < 0 || x_extent > 0xffffffffLL)                                                  \
-            return lsk::fail(LSK_ERR_ARG, "lsk_csr_spmv_c32_tune_" #SUF ": window of %lld columns",   \
-                             (long long)x_extent);                                                    \
-        return tune_csr_spmv<T, uint32_t>("lsk_csr_spmv_c32_tune_" #SUF, rows, nnz, rects, k_base, col32, val, \
+        LSK_C32_WINDOW("lsk_csr_spmv_c32_tune_" #SUF);                                                \
+        return tune_csr_spmv<T, uint32_t>("lsk_csr_spmv_c32_tune_" #SUF, rows, nnz, rowoff32, 0, col32, val, \
                                           x, 0, x_extent - 1, y, stream, remap_out, ms_out);          \
     }
 LSK_C32(f32, float)
 LSK_C32(f64, double)
+#undef LSK_C32_WINDOW
 #undef LSK_C32
 
 int lsk_rects_to_indptr_i64(int64_t rows, const int64_t *rects, int64_t *indptr,

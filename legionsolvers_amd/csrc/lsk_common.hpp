@@ -14,6 +14,9 @@ namespace lsk {
 // Records `code` and a printf-style message for lsk_last_error(); prints and abort()s when
 // lsk_set_abort_on_error(1) is in force.  Returns `code`.
 int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+// The same for an answer the caller is expected to handle (a set-up probe that says "not for this
+// input"): records the message and returns the code, but never aborts.
+int decline(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
 
 int hip_fail(hipError_t status, const char *expr, const char *file, int line);
 

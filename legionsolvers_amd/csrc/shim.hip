@@ -32,6 +32,14 @@ int fail(int code, const char *fmt, ...) {
     return code;
 }
 
+int decline(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    std::vsnprintf(g_error, sizeof(g_error), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
 int hip_fail(hipError_t status, const char *expr, const char *file, int line) {
     // Same fields the reference prints in check_cuda (src/CUDAUtilities.cpp:13-27).
     return fail(LSK_ERR_HIP, "HIP failure with status code %d (%s: %s) in %s at %s:%d",

@@ -75,6 +75,7 @@ class CSRMatrix(AbstractMatrix):
         self.placement = {}  # piece colour -> tile placement found by tune()
         self.col32 = None         # compress(): the column field as 32-bit offsets into ...
         self.col32_window = None  # ... this window (x_lo, x_hi)
+        self.rowoff = {}          # ... and per piece colour rows + 1 32-bit offsets of the rows' entries
 
     TUNE_MIN_ROWS = 1 << 21  # pieces below this are not worth the ~30 trial launches
     FUSE_DOT_MAX_ROW_LENGTH = 16.0
@@ -88,27 +89,43 @@ class CSRMatrix(AbstractMatrix):
             return override != "0"
         return self.rows > 0 and self.nnz / self.rows <= self.FUSE_DOT_MAX_ROW_LENGTH
 
-    def compress(self, x_lo: int, x_hi: int) -> bool:
-        """Set-up-time copy of the column field as 32-bit offsets into the window x_lo..x_hi of
-        the input vector (the ghost interval the planner found for this rank): products against
-        exactly that window then read 4 instead of 8 bytes of index per entry and give
-        bit-identical results.  What the reference redoes on every call for cuSPARSE
-        (src/CuSPARSEHelpers.hpp:71-80), done once.  LSK_COMPRESS=0 turns it off.  Returns
-        whether the copy was made (not for windows of 2^32 - 1 columns or more)."""
+    def compress(self, x_lo: int, x_hi: int, kernel_partition, range_partition) -> bool:
+        """Set-up-time copy of the matrix structure in 32 bits: the column field as offsets into
+        the window x_lo..x_hi of the input vector (the ghost interval the planner found for this
+        rank) and, per piece, the rects as rows + 1 offsets into the piece's entries.  Products
+        against exactly that window then read 4 instead of 8 bytes of column and 4 instead of 16
+        of row structure and give bit-identical results.  What the reference redoes on every
+        call for cuSPARSE (src/CuSPARSEHelpers.hpp:9-31,71-80), done once.  LSK_COMPRESS=0 turns
+        it off.  Returns whether the copy was made (not for windows of 2^32 - 1 columns or more,
+        pieces of 2^32 entries or more, or rects that are not back to back)."""
         be = self.ctx.backend
-        maker = getattr(be, "csr_compress_cols", None)
-        if (maker is None or os.environ.get("LSK_COMPRESS", "1") == "0" or x_hi < x_lo or self.nnz == 0
-                or x_hi - x_lo + 1 > be.COMPRESS_MAX_EXTENT):
+        cols, rows_of = getattr(be, "csr_compress_cols", None), getattr(be, "csr_compress_rows", None)
+        if (cols is None or rows_of is None or os.environ.get("LSK_COMPRESS", "1") == "0" or x_hi < x_lo
+                or self.nnz == 0 or x_hi - x_lo + 1 > be.COMPRESS_MAX_EXTENT):
             return False
-        self.col32 = maker(self.col, x_lo, x_hi)
+        rowoff = {}
+        for i, c in enumerate(kernel_partition.colors):
+            p = range_partition.pieces[c]
+            k_lo, k_hi = kernel_partition.intervals[i]
+            nnz = max(k_hi - k_lo + 1, 0)
+            if p.volume == 0:
+                continue
+            r0 = p.lo[0] - self.row_lo
+            off = rows_of(self.rects[r0:r0 + p.volume], k_lo if nnz else self.k_base, nnz)
+            if off is None:
+                return False
+            rowoff[c] = off
+        self.rowoff = rowoff
+        self.col32 = cols(self.col, x_lo, x_hi)
         self.col32_window = (int(x_lo), int(x_hi))
         return True
 
-    def _cols(self, x_lo: int, x_hi: int) -> torch.Tensor:
-        """The column array a product against the window x_lo..x_hi reads."""
-        if self.col32 is not None and self.col32_window == (x_lo, x_hi):
-            return self.col32
-        return self.col
+    def _structure(self, x_lo: int, x_hi: int, c: int, r0: int, ra: int, rb: int):
+        """(row field, column array) a product of rows [ra, rb) of piece c (whose first row is
+        this rank's row r0) against the window x_lo..x_hi reads."""
+        if self.col32 is not None and self.col32_window == (x_lo, x_hi) and c in self.rowoff:
+            return self.rowoff[c][ra:rb + 1], self.col32
+        return self.rects[r0 + ra:r0 + rb], self.col
 
     def tune(self, x_lo, x_hi, kernel_partition, range_partition) -> None:
         """Set-up-time choice of the tile -> XCD placement per piece (the backend times a few
@@ -127,7 +144,6 @@ class CSRMatrix(AbstractMatrix):
         y = torch.empty(max(range_partition.pieces[kernel_partition.colors[i]].volume for i in big),
                         dtype=self.dtype, device=self.val.device)
         self._redraw_arrays(x, x_lo, x_hi, y, kernel_partition, range_partition, big)
-        col = self._cols(x_lo, x_hi)
         for i, c in enumerate(kernel_partition.colors):
             p = range_partition.pieces[c]
             k_lo, k_hi = kernel_partition.intervals[i]
@@ -136,7 +152,8 @@ class CSRMatrix(AbstractMatrix):
                 continue
             r0 = p.lo[0] - self.row_lo
             off = k_lo - self.k_base
-            self.placement[c], _ = tuner(p.volume, nnz, self.rects[r0:r0 + p.volume], k_lo,
+            rowf, col = self._structure(x_lo, x_hi, c, r0, 0, p.volume)
+            self.placement[c], _ = tuner(p.volume, nnz, rowf, k_lo,
                                          col[off:off + nnz], self.val[off:off + nnz], x, x_lo, x_hi, y)
 
     def halo_split(self, own_lo: int, own_hi: int, kernel_partition, range_partition):
@@ -189,20 +206,20 @@ class CSRMatrix(AbstractMatrix):
         redraws = int(os.environ.get("LSK_TUNE_REDRAWS", str(self.REDRAWS)))
         if redraws <= 0 or not self.val.is_cuda or getattr(self.ctx.backend, "csr_spmv_tune", None) is None:
             return
-        compressed = self._cols(x_lo, x_hi) is not self.col  # then the 64-bit field is not on the path
+        compressed = self.col32 is not None and self.col32_window == (x_lo, x_hi)  # then rects / col are off the path
         need = sum(t.numel() * t.element_size()
-                   for t in (self.rects, self.col32 if compressed else self.col, self.val))
+                   for t in ((self.col32, self.val, *self.rowoff.values()) if compressed
+                             else (self.rects, self.col, self.val)))
 
         def time_current() -> float:
-            col = self._cols(x_lo, x_hi)
-
             def sweep():
                 for i in pieces:
                     c = kernel_partition.colors[i]
                     p = range_partition.pieces[c]
                     k_lo, k_hi = kernel_partition.intervals[i]
                     r0, off, nnz = p.lo[0] - self.row_lo, k_lo - self.k_base, k_hi - k_lo + 1
-                    self.ctx.backend.csr_spmv(p.volume, nnz, self.rects[r0:r0 + p.volume], k_lo,
+                    rowf, col = self._structure(x_lo, x_hi, c, r0, 0, p.volume)
+                    self.ctx.backend.csr_spmv(p.volume, nnz, rowf, k_lo,
                                               col[off:off + nnz], self.val[off:off + nnz], x, x_lo, x_hi,
                                               y, 0, self.placement.get(c, 0))
             for _ in range(2):
@@ -221,8 +238,9 @@ class CSRMatrix(AbstractMatrix):
             if free < need + (2 << 30):
                 break
             if compressed:
-                old = (self.rects, self.col32, self.val)
-                self.rects, self.col32, self.val = (t.clone() for t in old)
+                old = (self.rowoff, self.col32, self.val)
+                self.rowoff = {c: t.clone() for c, t in self.rowoff.items()}
+                self.col32, self.val = self.col32.clone(), self.val.clone()
             else:
                 old = (self.rects, self.col, self.val)
                 self.rects, self.col, self.val = (t.clone() for t in old)
@@ -232,7 +250,7 @@ class CSRMatrix(AbstractMatrix):
             if t < best:
                 best = t
             elif compressed:
-                self.rects, self.col32, self.val = old
+                self.rowoff, self.col32, self.val = old
             else:
                 self.rects, self.col, self.val = old
             del old
@@ -275,7 +293,6 @@ class CSRMatrix(AbstractMatrix):
         if touch is not None:
             touch()
         pieces = []
-        col = self._cols(x_lo, x_hi)
         for i, c in enumerate(kernel_partition.colors):
             p = range_partition.pieces[c]
             rows = p.volume
@@ -290,15 +307,20 @@ class CSRMatrix(AbstractMatrix):
                     if run_phase != phase:
                         continue
                     n_run = max(kb - ka + 1, 0)
-                    off = (ka - self.k_base) if n_run else 0
-                    be.csr_spmv(rb - ra, n_run, self.rects[r0 + ra:r0 + rb], ka if n_run else self.k_base,
-                                col[off:off + n_run], self.val[off:off + n_run], x, x_lo, x_hi,
+                    rowf, col = self._structure(x_lo, x_hi, c, r0, ra, rb)
+                    if rowf.dtype == torch.int32:   # offsets count from the piece's first entry
+                        off, n_arr = (k_lo - self.k_base) if nnz else 0, nnz
+                    else:
+                        off, n_arr = (ka - self.k_base) if n_run else 0, n_run
+                    be.csr_spmv(rb - ra, n_arr, rowf, ka if n_run else self.k_base,
+                                col[off:off + n_arr], self.val[off:off + n_arr], x, x_lo, x_hi,
                                 dst.piece(i)[ra:rb], beta, self.placement.get(c, 0))
                 continue
             if split is not None and phase == 0:
                 continue  # a piece without a split entry (no entries) goes with the late phase
             off = (k_lo - self.k_base) if nnz else 0
-            args = (rows, nnz, self.rects[r0:r0 + rows], k_lo if nnz else self.k_base,
+            rowf, col = self._structure(x_lo, x_hi, c, r0, 0, rows)
+            args = (rows, nnz, rowf, k_lo if nnz else self.k_base,
                     col[off:off + nnz], self.val[off:off + nnz], x, x_lo, x_hi, dst.piece(i), beta)
             if fused:
                 buf = dst._partials("mv", i, be.csr_spmv_dot_slots(rows, nnz, self.dtype))

@@ -114,7 +114,7 @@ class SquarePlanner:
         window = (own[0] - plan.pad_lo, own[1] + plan.pad_hi) if (plan.recvs or plan.sends) else own
         compress = getattr(matrix, "compress", None)
         if compress is not None and getattr(matrix, "col32", None) is None:
-            compress(window[0], window[1])
+            compress(window[0], window[1], kernel_partition, range_partition)
         tune = getattr(matrix, "tune", None)
         if tune is not None and not getattr(matrix, "_tuned", False):
             tune(window[0], window[1], kernel_partition, range_partition)

@@ -100,7 +100,21 @@ class OracleBackend:
         inside = (c >= x_lo) & (c <= x_hi)
         return torch.from_numpy(np.where(inside, c - x_lo, 0xFFFFFFFF).astype(np.uint32).view(np.int32))
 
+    def csr_compress_rows(self, rects, k_base, nnz):
+        r = _np(rects)
+        if nnz > 0xFFFFFFFF:
+            return None
+        lo, end = r[:, 0] - k_base, r[:, 1] + 1 - k_base
+        if (lo < 0).any() or (end < lo).any() or (end > nnz).any() or (r[1:, 0] != r[:-1, 1] + 1).any():
+            return None
+        off = np.concatenate([lo, end[-1:]]) if len(r) else np.zeros(1, dtype=np.int64)
+        return torch.from_numpy(off.astype(np.uint32).view(np.int32))
+
     def csr_spmv(self, rows, nnz, rects, k_base, col, val, x, x_lo, x_hi, y, beta, placement=0):
+        if rects.dtype == torch.int32:  # rows + 1 offsets from the start of col / val
+            off = _np(rects).view(np.uint32).astype(np.int64)
+            rects = torch.from_numpy(np.stack([off[:-1], off[1:] - 1], axis=1))
+            k_base = 0
         c = _np(col)
         if c.dtype == np.int32:  # compressed: offsets into the window, 0xffffffff = outside it
             u = c.view(np.uint32).astype(np.int64)

@@ -71,17 +71,27 @@ def csr_case(suf, rects, k_base, col, val, x, x_lo, x_hi, beta=0, y0=None, tag="
     inside = (col >= x_lo) & (col <= x_hi)
     assert np.array_equal(c32.cpu().numpy().view(np.uint32),
                           np.where(inside, col - x_lo, 0xFFFFFFFF).astype(np.uint32)), f"{tag}: compression"
+    # ... and the rects as rows + 1 offsets, when they are back to back inside the piece
+    back_to_back = bool(np.all(rects[1:, 0] == rects[:-1, 1] + 1) and np.all(rects[:, 1] + 1 >= rects[:, 0])
+                        and rects[0, 0] >= k_base and rects[-1, 1] + 1 - k_base <= val.size) if rows else True
+    off32 = torch.full((rows + 1,), -7, dtype=torch.int32, device="cuda")
+    code = _lib.lib().lsk_csr_compress_rows_u32(rows, val.size, P(rd), k_base, P(off32), stream())
+    assert code == (_lib.LSK_OK if back_to_back else _lib.LSK_ERR_UNSUPPORTED), f"{tag}: row compression said {code}"
+    if not back_to_back:
+        return got
+    want_off = np.concatenate([rects[:, 0] - k_base, rects[-1:, 1] + 1 - k_base]) if rows else np.zeros(1)
+    assert np.array_equal(off32.cpu().numpy().view(np.uint32), want_off.astype(np.uint32)), f"{tag}: row offsets"
     yc = dev(y0)
-    _lib.call(f"lsk_csr_spmv_c32_{suf}", rows, val.size, P(rd), k_base, P(c32), P(vd), P(xd), x_hi - x_lo + 1,
+    _lib.call(f"lsk_csr_spmv_c32_{suf}", rows, val.size, P(off32), P(c32), P(vd), P(xd), x_hi - x_lo + 1,
               P(yc), beta, stream())
     got32 = yc.cpu().numpy()
     variant = ctypes.c_int(0)
     _lib.call("lsk_get_option", b"csr.variant", ctypes.byref(variant))
     if variant.value == 1:
-        assert np.array_equal(got32, got), f"{tag}: compressed columns change the result"
+        assert np.array_equal(got32, got), f"{tag}: the compressed structure changes the result"
     else:
         err = np.abs(got32.astype(np.float64) - want.astype(np.float64))
-        assert np.all(err <= lim), f"{tag} (compressed columns): max err {err.max()}"
+        assert np.all(err <= lim), f"{tag} (compressed structure): max err {err.max()}"
     return got
 
 
@@ -245,16 +255,17 @@ def test_csr_spmv_c32_phases(suf):
               stream())
     torch.cuda.synchronize()
     c32 = (col.astype(np.uint32)).view(np.int32)
+    off = dev(np.concatenate([rects[:, 0], rects[-1:, 1] + 1]).astype(np.uint32).view(np.int32))
     for coff in range(4):
         for voff in range(0, 4 if suf == "f32" else 2):
             print(f"case csr c32 phases {suf} coff={coff} voff={voff}", flush=True)
             cd = dev(np.concatenate([np.zeros(coff, np.int32), c32]))
             vd = dev(np.concatenate([np.zeros(voff, npdt), val]))
             yd = torch.zeros(n, dtype=tdt, device="cuda")
-            _lib.call(f"lsk_csr_spmv_c32_{suf}", n, val.size, P(rd), 0, P(cd[coff:]), P(vd[voff:]), P(xd), n,
+            _lib.call(f"lsk_csr_spmv_c32_{suf}", n, val.size, P(off), P(cd[coff:]), P(vd[voff:]), P(xd), n,
                       P(yd), 0, stream())
             assert torch.equal(yd, ref)
-    # pieces that start at rows 1..5 (first entry at any offset), window = the piece's image
+    # runs of rows that start at rows 1..5 (first entry at any offset): offsets handed over from that row on
     cd, vd = dev(c32), dev(val)
     for r0 in range(1, 6):
         k_lo = int(rects[r0, 0])
@@ -262,19 +273,20 @@ def test_csr_spmv_c32_phases(suf):
         nnz = int(rects[r0 + rows - 1, 1]) - k_lo + 1
         print(f"case csr c32 piece {suf} r0={r0} k_lo={k_lo}", flush=True)
         yd = torch.zeros(rows, dtype=tdt, device="cuda")
-        _lib.call(f"lsk_csr_spmv_c32_{suf}", rows, nnz, P(rd[r0:]), k_lo, P(cd[k_lo:]), P(vd[k_lo:]), P(xd), n,
+        _lib.call(f"lsk_csr_spmv_c32_{suf}", rows, val.size, P(off[r0:]), P(cd), P(vd), P(xd), n,
                   P(yd), 0, stream())
         assert torch.equal(yd, ref[r0:r0 + rows])
     # fused product + dot on the compressed form: same y, same partial sums as the 64-bit form
     w = dev(np.random.default_rng(62).standard_normal(n).astype(npdt))
     slots = int(_lib.lib().lsk_csr_spmv_dot_partials(n, val.size, 4 if suf == "f32" else 8))
     out = []
-    for name, cols, window in (("lsk_csr_spmv_dot", col64, (0, n - 1)), ("lsk_csr_spmv_c32_dot", cd, (n,))):
+    for name, structure in (("lsk_csr_spmv_dot", (P(rd), 0, P(col64), P(vd), P(xd), 0, n - 1)),
+                            ("lsk_csr_spmv_c32_dot", (P(off), P(cd), P(vd), P(xd), n))):
         print(f"case {name}_{suf}", flush=True)
         yd = torch.zeros(n, dtype=tdt, device="cuda")
         part = torch.full((slots,), 7.0, dtype=tdt, device="cuda")
         count = ctypes.c_int64(0)
-        _lib.call(f"{name}_{suf}", n, val.size, P(rd), 0, P(cols), P(vd), P(xd), *window, P(yd), 0, P(w), P(part),
+        _lib.call(f"{name}_{suf}", n, val.size, *structure, P(yd), 0, P(w), P(part),
                   slots, ctypes.byref(count), stream())
         assert torch.equal(yd, ref) and count.value == slots
         out.append(part.clone())
@@ -282,7 +294,7 @@ def test_csr_spmv_c32_phases(suf):
     # tuner on the compressed form returns one of its candidates and a time
     remap, ms = ctypes.c_int(-1), ctypes.c_float(0.0)
     yd = torch.zeros(n, dtype=tdt, device="cuda")
-    _lib.call(f"lsk_csr_spmv_c32_tune_{suf}", n, val.size, P(rd), 0, P(cd), P(vd), P(xd), n, P(yd), stream(),
+    _lib.call(f"lsk_csr_spmv_c32_tune_{suf}", n, val.size, P(off), P(cd), P(vd), P(xd), n, P(yd), stream(),
               ctypes.byref(remap), ctypes.byref(ms))
     assert remap.value in (0, 16, 64, 256, 1024, 4096) and ms.value > 0 and torch.equal(yd, ref)
 
@@ -298,11 +310,21 @@ def test_csr_compress_cols_limits():
     _lib.call("lsk_csr_compress_cols_u32", 4, P(col), 10, 9, P(out), stream())
     assert out.cpu().numpy().view(np.uint32).tolist() == [0xFFFFFFFF] * 4
     # a product against an empty window: y <- 0
-    rects = dev(np.array([[0, 1], [2, 3]], dtype=np.int64))
+    off = dev(np.array([0, 2, 4], dtype=np.int32))
     y = torch.ones(2, dtype=torch.float64, device="cuda")
     val = torch.ones(4, dtype=torch.float64, device="cuda")
-    _lib.call("lsk_csr_spmv_c32_f64", 2, 4, P(rects), 0, P(out), P(val), None, 0, P(y), 0, stream())
+    _lib.call("lsk_csr_spmv_c32_f64", 2, 4, P(off), P(out), P(val), None, 0, P(y), 0, stream())
     assert y.tolist() == [0.0, 0.0]
+    # rects that cannot become offsets: a gap, a rect outside the piece, too many entries
+    o3 = torch.zeros(3, dtype=torch.int32, device="cuda")
+    lib = _lib.lib()
+    for rects, k_base, nnz in ((np.array([[0, 1], [3, 4]]), 0, 5), (np.array([[0, 1], [2, 9]]), 0, 5),
+                               (np.array([[5, 6], [7, 8]]), 6, 4), (np.array([[0, 1], [2, 3]]), 0, 2**32 + 1)):
+        rd = dev(rects.astype(np.int64))
+        assert lib.lsk_csr_compress_rows_u32(2, nnz, P(rd), k_base, P(o3), stream()) == _lib.LSK_ERR_UNSUPPORTED
+    rd = dev(np.array([[6, 6], [7, 6]], dtype=np.int64))  # the second row is empty
+    _lib.call("lsk_csr_compress_rows_u32", 2, 4, P(rd), 6, P(o3), stream())
+    assert o3.tolist() == [0, 1, 1]
 
 
 @pytest.fixture(params=[1, 0], ids=["wave-scan", "workgroup-chunks"])

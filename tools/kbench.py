@@ -107,6 +107,7 @@ def main():
     ap.add_argument("--logrw", default="-1")
     ap.add_argument("--kmax", default="0", help="csr.max_units values (0 = automatic, 4, 8)")
     ap.add_argument("--blas1", action="store_true")
+    ap.add_argument("--c32", action="store_true", help="time the compressed-column form of the CSR kernel")
     ap.add_argument("--coo", action="store_true", help="time the COO kernel forms instead (stencil at --n)")
     ap.add_argument("--coo-random-rows", type=int, default=0,
                     help="with --coo: also a random row-sorted matrix, 32 entries per row")
@@ -130,6 +131,11 @@ def main():
     x.owned.copy_(torch.randn(rows, device="cuda", dtype=dtype))
     algo = A.nnz * (8 + esz) + rows * (16 + 2 * esz)
     print(f"matrix: rows={rows} nnz={A.nnz} algorithmic bytes/SpMV={algo}", flush=True)
+
+    if args.c32:
+        assert A.compress(0, rows - 1)
+        algo = A.nnz * (4 + esz) + rows * (16 + 2 * esz)
+        print(f"compressed columns: algorithmic bytes/SpMV={algo}", flush=True)
 
     def spmv():
         A.matvec(y, x.owned, 0, rows - 1, kp, 0)
