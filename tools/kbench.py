@@ -133,8 +133,8 @@ def main():
     print(f"matrix: rows={rows} nnz={A.nnz} algorithmic bytes/SpMV={algo}", flush=True)
 
     if args.c32:
-        assert A.compress(0, rows - 1)
-        algo = A.nnz * (4 + esz) + rows * (16 + 2 * esz)
+        assert A.compress(0, rows - 1, kp, ip)
+        algo = A.nnz * (4 + esz) + rows * (4 + 2 * esz)
         print(f"compressed columns: algorithmic bytes/SpMV={algo}", flush=True)
 
     def spmv():

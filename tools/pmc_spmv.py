@@ -23,11 +23,17 @@ rows = n1 ** 3
 ip = IndexPartition.equal(IndexSpace(0, rows - 1), 1)
 A = sg.create_linearized_csr_stencil_matrix(ctx, (n1, n1, n1), offs, cfs, ip)
 kp = A.create_kernel_partition_from_range_partition(ip)
-A.tune(0, rows - 1, kp, ip)  # the placement the planner would pick at set-up
+A.compress(0, rows - 1, kp, ip)  # the planner's set-up: 32-bit structure (unless LSK_COMPRESS=0) ...
+A.tune(0, rows - 1, kp, ip)      # ... and the tile placement
 x = PartitionedVector(ctx, "x", ip)
 y = PartitionedVector(ctx, "y", ip)
 x.owned.copy_(torch.randn(rows, device="cuda", dtype=torch.float64))
 y.zero_fill()
+if A.col32 is not None:  # the form that reads the 64-bit columns and rects, for comparison
+    held, A.col32_window = A.col32_window, None
+    for _ in range(3):
+        A.matvec(y, x.owned, 0, rows - 1, kp, 0)
+    A.col32_window = held
 for _ in range(3):
     A.matvec(y, x.owned, 0, rows - 1, kp, 0)
 a = Scalar(ctx, 0.5, torch.float64)
@@ -37,4 +43,5 @@ for _ in range(3):
 ctx.synchronize()
 print(f"tile placement {A.placement}")
 print(f"rows={rows} nnz={A.nnz} spmv_algorithmic_bytes={A.nnz * 16 + rows * 32} "
+      f"spmv_c32_algorithmic_bytes={A.nnz * 12 + rows * 20} "
       f"dot_bytes={rows * 16} axpy_read_bytes={rows * 16} axpy_write_bytes={rows * 8}")

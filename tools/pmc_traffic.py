@@ -17,7 +17,8 @@ def means(path, counter):
         if r["Counter_Name"] != counter:
             continue
         name = r["Kernel_Name"]
-        key = "spmv" if "csr_spmv" in name else "dot" if "dot_kernel" in name else None
+        key = ("spmv_c32" if "csr_spmv" in name and "unsigned int" in name else
+               "spmv" if "csr_spmv" in name else "dot" if "dot_kernel" in name else None)
         if key:
             acc.setdefault(key, []).append(float(r["Counter_Value"]))
     # the last three launches of each kind are the measured ones (earlier SpMV launches belong
@@ -35,6 +36,12 @@ def main():
     factor = 2 if 1.9 < ratio < 2.1 else 1
     traffic = factor * f["spmv"] * 1024 + w["spmv"] * 1024
     algo = nnz * 16 + rows * 32
+    c32 = {}
+    if "spmv_c32" in f:  # the form on the set-up-time 32-bit structure
+        t32, a32 = factor * f["spmv_c32"] * 1024 + w["spmv_c32"] * 1024, nnz * 12 + rows * 20
+        c32 = {"bytes_per_launch_c32": int(round(t32)), "algorithmic_bytes_per_launch_c32": a32,
+               "ratio_traffic_over_algorithmic_c32": t32 / a32,
+               "FETCH_SIZE_KB_mean_c32": f["spmv_c32"], "WRITE_SIZE_KB_mean_c32": w["spmv_c32"]}
     json.dump({
         "workload": "csr_spmv f64, 27-pt 512^3, 1 GPU",
         "tile_placement": placement,
@@ -43,7 +50,7 @@ def main():
                         "FETCH_SIZE_KB_mean": f["dot"], "ratio_true_over_reported": ratio},
         "correction": f"bytes = {factor}*FETCH_SIZE*1024 + WRITE_SIZE*1024 (factor from the calibration)",
         "bytes_per_launch": int(round(traffic)), "algorithmic_bytes_per_launch": algo,
-        "ratio_traffic_over_algorithmic": traffic / algo,
+        "ratio_traffic_over_algorithmic": traffic / algo, **c32,
     }, open(out, "w"), indent=1)
     print(open(out).read())
 
