@@ -13,6 +13,9 @@
 // reference's `cuda_task_body`, because that is the name TaskTDI::preregister and
 // HasCUDAVariantMixin look for (src/TaskBaseClasses.hpp:211-223, src/MetaprogrammingUtilities.hpp:
 // 123-145).
+#include <map>
+#include <utility>
+
 #include <legion.h>
 #include <realm/hip/hip_module.h>
 
@@ -54,6 +57,7 @@ template <> struct Abi<float> {
     static constexpr auto xpay_nd = lsk_xpay_nd_f32;
     static constexpr auto dot_host = lsk_dot_host_f32;
     static constexpr auto csr_spmv = lsk_csr_spmv_f32;
+    static constexpr auto csr_spmv_c32 = lsk_csr_spmv_c32_f32;
     static constexpr auto coo_spmv = lsk_coo_spmv_f32;
 };
 template <> struct Abi<double> {
@@ -63,8 +67,48 @@ template <> struct Abi<double> {
     static constexpr auto xpay_nd = lsk_xpay_nd_f64;
     static constexpr auto dot_host = lsk_dot_host_f64;
     static constexpr auto csr_spmv = lsk_csr_spmv_f64;
+    static constexpr auto csr_spmv_c32 = lsk_csr_spmv_c32_f64;
     static constexpr auto coo_spmv = lsk_coo_spmv_f64;
 };
+
+// Set-up-time 32-bit copy of a CSR piece's structure, made on the first product of a piece and
+// reused by every later one: the once-only form of what the reference redoes per call
+// (src/CuSPARSEHelpers.hpp:9-31,71-80).  One table per GPU processor, like CUDALibraryContext
+// (src/CUDAUtilities.cpp:125-130); a GPU processor runs one task at a time, so no lock.
+struct Structure32 {
+    const void *rects = nullptr;
+    int64_t rows = 0, nnz = 0, x_lo = 0, x_hi = -1;
+    uint32_t *rowoff = nullptr, *col = nullptr; // null after a refusal: stay with the 64-bit form
+};
+std::map<std::pair<unsigned long long, const void *>, Structure32> structure_table;
+
+const Structure32 &structure32(const int64_t *rects, int64_t rows, int64_t k_base, const int64_t *col,
+                               int64_t nnz, int64_t x_lo, int64_t x_hi, lsk_stream_t stream) {
+    const auto key = std::make_pair(Legion::Processor::get_executing_processor().id,
+                                    static_cast<const void *>(col));
+    Structure32 &s = structure_table[key];
+    if (s.rects == rects && s.rows == rows && s.nnz == nnz && s.x_lo == x_lo && s.x_hi == x_hi) return s;
+    if (s.rowoff) check(lsk_free(s.rowoff));
+    if (s.col) check(lsk_free(s.col));
+    s = Structure32{rects, rows, nnz, x_lo, x_hi, nullptr, nullptr};
+    void *rowoff = nullptr, *col32 = nullptr;
+    check(lsk_malloc(&rowoff, static_cast<size_t>(rows + 1) * sizeof(uint32_t)));
+    check(lsk_malloc(&col32, static_cast<size_t>(nnz) * sizeof(uint32_t)));
+    const int a = lsk_csr_compress_rows_u32(rows, nnz, rects, k_base, static_cast<uint32_t *>(rowoff), stream);
+    const int b = a == LSK_OK
+                      ? lsk_csr_compress_cols_u32(nnz, col, x_lo, x_hi, static_cast<uint32_t *>(col32), stream)
+                      : a;
+    if (a == LSK_OK && b == LSK_OK) {
+        s.rowoff = static_cast<uint32_t *>(rowoff);
+        s.col = static_cast<uint32_t *>(col32);
+    } else {
+        if (a != LSK_ERR_UNSUPPORTED) check(a);
+        if (b != LSK_ERR_UNSUPPORTED) check(b);
+        check(lsk_free(rowoff));
+        check(lsk_free(col32));
+    }
+    return s;
+}
 
 // One vector argument of a BLAS-1 task: base pointer of the dense piece and its volume.
 template <typename T, int DIM, typename COORD_T, typename ACC>
@@ -140,6 +184,19 @@ void CSRMatvecTask<LEGION_SOLVERS_KDR_TEMPLATE_ARGS>::cuda_task_body(LEGION_SOLV
         regions[2], *task->regions[2].privilege_fields.begin());
     const AffineReader<ENTRY_T, 1, DOMAIN_COORD_T> x(regions[3], *task->regions[3].privilege_fields.begin());
     const bool no_x = in_bounds.empty(), no_k = ker_bounds.empty();
+    if (!no_x && !no_k) {
+        const Structure32 &s32 = structure32(
+            reinterpret_cast<const int64_t *>(rowptr.ptr(out_bounds.lo)), static_cast<int64_t>(out_bounds.volume()),
+            ker_bounds.lo[0], reinterpret_cast<const int64_t *>(col.ptr(ker_bounds.lo)),
+            static_cast<int64_t>(ker_bounds.volume()), in_bounds.lo[0], in_bounds.hi[0], task_stream());
+        if (s32.rowoff) {
+            check(Abi<ENTRY_T>::csr_spmv_c32(s32.rows, s32.nnz, s32.rowoff, s32.col, val.ptr(ker_bounds.lo),
+                                             x.ptr(in_bounds.lo), in_bounds.hi[0] - in_bounds.lo[0] + 1,
+                                             const_cast<ENTRY_T *>(y.ptr(out_bounds.lo)), /*beta=*/0,
+                                             task_stream()));
+            return;
+        }
+    }
     // beta = 0: what the reference's cuSPARSE call does (src/CSRMatrixTasks.cu:117-118).
     check(Abi<ENTRY_T>::csr_spmv(
         static_cast<int64_t>(out_bounds.volume()), no_k ? 0 : static_cast<int64_t>(ker_bounds.volume()),
