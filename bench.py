@@ -131,6 +131,7 @@ def main():
     # connections of the halo exchange, so that a run with --warmup 0 does not time their set-up.
     # CG's first step overwrites Q with the same product.
     planner.matvec(CGSolver.Q, CGSolver.P)
+    ctx.comm.all_reduce_sum(torch.zeros(1, dtype=torch.float64, device=ctx.device))  # likewise the dots' all-reduce
     seconds = bs.timed_steps(ctx, solver, args.warmup, args.steps)
     iters_per_s = args.steps / seconds
     rr = solver.residual_norm_squared[-1].get_value()
