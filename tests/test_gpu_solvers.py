@@ -172,3 +172,49 @@ def test_cg_with_tuned_placement(gpu_ctx, monkeypatch):
         sm.step()
     np.testing.assert_allclose([s.get_value() for s in sm.residual_norm_squared],
                                [float(v) for v in so.residual_norm_squared], rtol=1e-10)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("solver_name", ["cg", "gmres"])
+def test_compressed_structure_gives_the_same_history(gpu_ctx, monkeypatch, dtype, solver_name):
+    """The planner's set-up-time 32-bit copy of the CSR structure (on by default) and the products
+    straight on the reference's int64 columns and rects (LSK_COMPRESS=0) give bit-identical
+    residual histories: same tiles, same order of additions."""
+    rects, row, col, val, n = hc.stencil_problem(4, (20, 12, 16), dtype)
+    rhs = np.random.default_rng(33).standard_normal(n).astype(dtype)
+    histories = []
+    for compress in ("1", "0"):
+        monkeypatch.setenv("LSK_COMPRESS", compress)
+        mpl = hc.mirror_planner(gpu_ctx, "csr", rects, row, col, val, n, 3, dtype, rhs)
+        matrix = mpl.row_partitioned_matrices[0].matrix
+        assert (matrix.col32 is not None) == (compress == "1")
+        assert (sorted(matrix.rowoff) == [0, 1, 2]) == (compress == "1")
+        solver = CGSolver(mpl) if solver_name == "cg" else GMRESSolver(mpl, 5)
+        for _ in range(7 if solver_name == "cg" else 2):
+            solver.step()
+        histories.append(mpl.get_vector(0, 0).to_host().clone())
+        if solver_name == "cg":
+            histories[-1] = (histories[-1], [s.get_value() for s in solver.residual_norm_squared])
+    if solver_name == "cg":
+        assert histories[0][1] == histories[1][1] and torch.equal(histories[0][0], histories[1][0])
+    else:
+        assert torch.equal(histories[0], histories[1])
+
+
+def test_structure_that_cannot_be_compressed_falls_back(gpu_ctx):
+    """Rects with a gap (every row ignores its last entry): no 32-bit copy is made, products take
+    the reference arrays, CG still follows the oracle."""
+    rects, row, col, val, n = hc.stencil_problem(3, (9, 8, 7), np.float64)
+    rects = rects.copy()
+    rects[rects[:, 1] > rects[:, 0], 1] -= 1
+    rhs = np.random.default_rng(34).standard_normal(n)
+    opl = hc.oracle_planner("csr", rects, row, col, val, n, 2, np.float64, rhs)
+    mpl = hc.mirror_planner(gpu_ctx, "csr", rects, row, col, val, n, 2, np.float64, rhs)
+    matrix = mpl.row_partitioned_matrices[0].matrix
+    assert matrix.col32 is None and not matrix.rowoff
+    so, sm = S.CGSolver(opl), CGSolver(mpl)
+    for _ in range(5):
+        so.step()
+        sm.step()
+    np.testing.assert_allclose([s.get_value() for s in sm.residual_norm_squared],
+                               [float(v) for v in so.residual_norm_squared], rtol=1e-10)

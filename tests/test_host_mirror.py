@@ -272,3 +272,39 @@ def test_eight_rank_gloo_matches_oracle(tmp_path):
             so.step()
         np.testing.assert_allclose(res[f"cg_{extent[0]}"], [float(v) for v in so.residual_norm_squared], rtol=1e-12)
         np.testing.assert_allclose(res[f"sol_{extent[0]}"], opl.get_vector(0, 0), rtol=1e-10, atol=1e-13)
+
+
+def test_planner_compresses_the_structure_and_falls_back(monkeypatch):
+    """Host logic of the set-up-time 32-bit structure on the oracle backend: made for back-to-back
+    rects (and used: the product then gets int32 arrays), not made for gapped rects or with
+    LSK_COMPRESS=0; the CG history is the same in all three cases that share a matrix."""
+    rects, row, col, val, n = hc.stencil_problem(3, (6, 5, 7), np.float64)
+    seen = []
+
+    class Spy(OracleBackend):
+        def csr_spmv(self, rows, nnz, rects, k_base, col, *rest, **kw):
+            seen.append((rects.dtype, col.dtype))
+            return super().csr_spmv(rows, nnz, rects, k_base, col, *rest, **kw)
+
+    histories = {}
+    for label, env, rc in (("compressed", "1", rects), ("off", "0", rects)):
+        monkeypatch.setenv("LSK_COMPRESS", env)
+        seen.clear()
+        ctx = Context(backend=Spy())
+        mpl = hc.mirror_planner(ctx, "csr", rc, row, col, val, n, 2, np.float64)
+        matrix = mpl.row_partitioned_matrices[0].matrix
+        assert (matrix.col32 is not None) == (label == "compressed")
+        solver = CGSolver(mpl)
+        for _ in range(4):
+            solver.step()
+        histories[label] = [s.get_value() for s in solver.residual_norm_squared]
+        want = (torch.int32, torch.int32) if label == "compressed" else (torch.int64, torch.int64)
+        assert seen and all(pair == want for pair in seen)
+    assert histories["compressed"] == histories["off"]
+    monkeypatch.setenv("LSK_COMPRESS", "1")
+    gapped = rects.copy()
+    gapped[gapped[:, 1] > gapped[:, 0], 1] -= 1
+    ctx = Context(backend=Spy())
+    mpl = hc.mirror_planner(ctx, "csr", gapped, row, col, val, n, 2, np.float64)
+    matrix = mpl.row_partitioned_matrices[0].matrix
+    assert matrix.col32 is None and not matrix.rowoff
