@@ -1,0 +1,138 @@
+// test/BenchmarkStencil.cpp of the reference as a plain C++ program above the lsk C ABI: same flags
+// (-dim -nx -ny -nz -vp -solver -it -pt), same set-up (two identical systems sol/rhs and sol1/rhs1
+// on one matrix, rhs = 1, x0 = 0), same warm-up / timed trace structure (:201-262) and the same
+// three output lines.  Extensions for tests: -systems 1 solves a single system, -coo 1 builds the
+// COO form of the matrix, -f32 1 uses float entries, -restart N sets GMRES's restart length
+// (the reference hard-codes 10), -history 1 prints the solver's scalar history one value per line.
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+
+#include "stencil_generator.hpp"
+
+using namespace LegionSolversHost;
+
+namespace {
+
+struct Args {
+    long dim = 1, solver = 1, nx = 16, ny = 16, nz = 16, vp = 4, it = 20, pt = 1;
+    long systems = 2, coo = 0, f32 = 0, restart = 10, history = 0, compress = 1;
+};
+
+Args parse(int argc, char **argv) {
+    Args a;
+    const struct { const char *flag; long Args::*field; } table[] = {
+        {"-dim", &Args::dim}, {"-solver", &Args::solver}, {"-nx", &Args::nx}, {"-ny", &Args::ny},
+        {"-nz", &Args::nz}, {"-vp", &Args::vp}, {"-it", &Args::it}, {"-pt", &Args::pt},
+        {"-systems", &Args::systems}, {"-coo", &Args::coo}, {"-f32", &Args::f32}, {"-restart", &Args::restart},
+        {"-history", &Args::history}, {"-compress", &Args::compress}};
+    for (int i = 1; i + 1 < argc; i += 2) {
+        bool known = false;
+        for (const auto &t : table)
+            if (!std::strcmp(argv[i], t.flag)) {
+                a.*(t.field) = std::atol(argv[i + 1]);
+                known = true;
+            }
+        if (!known) throw std::invalid_argument(std::string("unknown flag ") + argv[i]);
+    }
+    return a;
+}
+
+template <typename Solver> void print_history(const Solver &) {}
+template <typename T> void print_history(const CGSolver<T> &s) {
+    for (const auto &v : s.residual_norm_squared) std::printf("%.17g\n", static_cast<double>(v.get()));
+}
+template <typename T> void print_history(const BiCGStabSolver<T> &s) {
+    for (const auto &v : s.rho) std::printf("%.17g\n", static_cast<double>(v.get()));
+}
+
+template <typename T, typename Solver>
+void run(const Context &ctx, const Args &a, Solver &solver, SquarePlanner<T> &planner) {
+    const long num_warmup_traces = 5;
+    const long num_traces = (a.it + a.pt - 1) / a.pt;
+    ctx.synchronize();
+    for (long i = 0; i < num_warmup_traces; ++i)
+        for (long j = 0; j < a.pt; ++j) solver.step();
+    ctx.synchronize();
+    const auto begin = std::chrono::steady_clock::now();
+    std::cout << "Performed " << num_warmup_traces << " warmup traces." << std::endl;
+    for (long i = num_warmup_traces; i < num_traces; ++i)
+        for (long j = 0; j < a.pt; ++j) solver.step();
+    ctx.synchronize();
+    const auto end = std::chrono::steady_clock::now();
+    std::cout << "Performed " << (num_traces - num_warmup_traces) << " timed traces." << std::endl;
+    const double ns = std::chrono::duration<double, std::nano>(end - begin).count();
+    const double ns_per_iter = ns / static_cast<double>(a.pt * std::max<long>(num_traces - num_warmup_traces, 1));
+    std::cout << "Achieved " << ns_per_iter / 1.0e6 << "ms per iteration." << std::endl;
+    if (a.history) {
+        print_history(solver);
+        const auto x = planner.get_vector(0, 0).to_host();
+        double sum = 0.0, sum2 = 0.0;
+        for (const T v : x) {
+            sum += static_cast<double>(v);
+            sum2 += static_cast<double>(v) * static_cast<double>(v);
+        }
+        std::printf("solution_sum %.17g\nsolution_sum_of_squares %.17g\n", sum, sum2);
+    }
+}
+
+template <typename T> int main_typed(const Args &a) {
+    Context ctx(0);
+    const Stencil st = benchmark_stencil(static_cast<int>(a.dim));
+    std::vector<int64_t> extent = {a.nx};
+    if (st.dim >= 2) extent.push_back(a.ny);
+    if (st.dim >= 3) extent.push_back(a.nz);
+    int64_t rows = 1;
+    for (int64_t e : extent) rows *= e;
+    const EqualPartition partition(rows, static_cast<int>(a.vp));
+
+    std::unique_ptr<AbstractMatrix<T>> matrix;
+    if (a.coo)
+        matrix = std::make_unique<COOMatrix<T>>(create_linearized_coo_stencil_matrix<T>(ctx, extent, st, partition));
+    else
+        matrix = std::make_unique<CSRMatrix<T>>(
+            create_linearized_csr_stencil_matrix<T>(ctx, extent, st, partition, a.compress != 0));
+
+    std::vector<std::unique_ptr<PartitionedVector<T>>> sols, rhss;
+    SquarePlanner<T> planner(ctx);
+    for (long s = 0; s < a.systems; ++s) {
+        sols.push_back(std::make_unique<PartitionedVector<T>>(ctx, s ? "sol1" : "sol", partition));
+        sols.back()->zero_fill();
+        planner.add_sol_vector(*sols.back());
+    }
+    for (long s = 0; s < a.systems; ++s) {
+        rhss.push_back(std::make_unique<PartitionedVector<T>>(ctx, s ? "rhs1" : "rhs", partition));
+        rhss.back()->constant_fill(T(1));
+        planner.add_rhs_vector(*rhss.back());
+    }
+    for (long s = 0; s < a.systems; ++s) planner.add_row_partitioned_matrix(*matrix, static_cast<int>(s), static_cast<int>(s));
+
+    if (a.solver == 1) {
+        CGSolver<T> solver(planner);
+        run<T>(ctx, a, solver, planner);
+    } else if (a.solver == 2) {
+        BiCGStabSolver<T> solver(planner);
+        run<T>(ctx, a, solver, planner);
+    } else if (a.solver == 3) {
+        GMRESSolver<T> solver(planner, static_cast<int>(a.restart));
+        run<T>(ctx, a, solver, planner);
+    } else {
+        std::cout << "INVALID SOLVER" << std::endl;
+        return 1;
+    }
+    return 0;
+}
+
+} // namespace
+
+int main(int argc, char **argv) {
+    try {
+        const Args a = parse(argc, argv);
+        return a.f32 ? main_typed<float>(a) : main_typed<double>(a);
+    } catch (const std::exception &e) {
+        std::cerr << e.what() << std::endl;
+        return 1;
+    }
+}

@@ -1,0 +1,571 @@
+// C++ host layer above the lsk C ABI: the reference's caller classes with their own names and call
+// shapes -- Scalar (src/Scalar.hpp), PartitionedVector (src/PartitionedVector.hpp), CSRMatrix /
+// COOMatrix (src/CSRMatrix.hpp, src/COOMatrix.hpp), SquarePlanner (src/SquarePlanner.hpp),
+// CGSolver / BiCGStabSolver / GMRESSolver (src/CGSolver.hpp, src/BiCGStabSolver.hpp,
+// src/GMRESSolver.hpp) -- for ONE process driving ONE GPU, without Legion.  A vector of n elements is
+// split into `pieces` equal row blocks (the colours of Legion's create_equal_partition); every
+// operation launches one leaf per piece through include/lsk.h, as the reference's index launches
+// do.  Scalars are device-resident futures, so a solver step enqueues without a host round trip.
+//
+// Header-only; needs only lsk.h and liblsk.so.  No arithmetic happens here.
+#pragma once
+
+#include <algorithm>
+#include <cstdint>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "lsk.h"
+
+namespace LegionSolversHost {
+
+inline void check(int status) {
+    if (status != LSK_OK) throw std::runtime_error(std::string("lsk: ") + lsk_last_error());
+}
+
+// The typed entry points of the ABI, selected by the entry type.
+template <typename T> struct Abi;
+#define LSK_HOST_ABI(T, SUF)                                                                       \
+    template <> struct Abi<T> {                                                                    \
+        static constexpr auto fill = lsk_fill_##SUF;                                               \
+        static constexpr auto copy = lsk_copy_##SUF;                                               \
+        static constexpr auto scal_dev = lsk_scal_dev_##SUF;                                       \
+        static constexpr auto axpy_dev = lsk_axpy_dev_##SUF;                                       \
+        static constexpr auto xpay_dev = lsk_xpay_dev_##SUF;                                       \
+        static constexpr auto dot = lsk_dot_##SUF;                                                 \
+        static constexpr auto scalar_op = lsk_scalar_op_##SUF;                                     \
+        static constexpr auto sum_scalars = lsk_sum_scalars_##SUF;                                 \
+        static constexpr auto csr_spmv = lsk_csr_spmv_##SUF;                                       \
+        static constexpr auto csr_spmv_c32 = lsk_csr_spmv_c32_##SUF;                               \
+        static constexpr auto coo_spmv = lsk_coo_spmv_##SUF;                                       \
+        static constexpr auto stencil_fill_csr = lsk_stencil_fill_csr_##SUF;                       \
+        static constexpr auto stencil_fill_coo = lsk_stencil_fill_coo_##SUF;                       \
+    }
+LSK_HOST_ABI(float, f32);
+LSK_HOST_ABI(double, f64);
+#undef LSK_HOST_ABI
+
+// What the reference threads through every class as (Legion::Context, Legion::Runtime *): here the
+// GPU, the stream every leaf is enqueued on, and the workspace of the dot products.
+class Context {
+public:
+    explicit Context(int device = 0) {
+        check(lsk_init(device));
+        check(lsk_stream_create(&stream_));
+        workspace_bytes_ = lsk_dot_workspace_bytes(0);
+        check(lsk_malloc(&workspace_, workspace_bytes_));
+    }
+    Context(const Context &) = delete;
+    Context &operator=(const Context &) = delete;
+    ~Context() {
+        lsk_stream_synchronize(stream_);
+        for (void *chunk : chunks_) lsk_free(chunk);
+        lsk_free(workspace_);
+        lsk_stream_destroy(stream_);
+    }
+    // 8-byte device slots for scalars, recycled without freeing device memory (a hipFree waits for
+    // the device, once per scalar per solver step otherwise).  A recycled slot is rewritten by a
+    // kernel enqueued after every reader of its old value: everything runs on the one stream.
+    void *acquire_slot() const {
+        if (free_slots_.empty()) {
+            constexpr size_t kChunk = 4096;
+            void *chunk = nullptr;
+            check(lsk_malloc(&chunk, kChunk * 8));
+            chunks_.push_back(chunk);
+            for (size_t i = kChunk; i-- > 0;) free_slots_.push_back(static_cast<char *>(chunk) + 8 * i);
+        }
+        void *slot = free_slots_.back();
+        free_slots_.pop_back();
+        return slot;
+    }
+    void release_slot(void *slot) const { free_slots_.push_back(slot); }
+    lsk_stream_t stream() const { return stream_; }
+    void *workspace() const { return workspace_; }
+    size_t workspace_bytes() const { return workspace_bytes_; }
+    void synchronize() const { check(lsk_stream_synchronize(stream_)); }
+
+private:
+    lsk_stream_t stream_ = nullptr;
+    void *workspace_ = nullptr;
+    size_t workspace_bytes_ = 0;
+    mutable std::vector<void *> chunks_, free_slots_;
+};
+
+// Device memory that frees itself.
+template <typename E> class DeviceArray {
+public:
+    DeviceArray() = default;
+    explicit DeviceArray(int64_t n) : n_(n) {
+        void *p = nullptr;
+        check(lsk_malloc(&p, static_cast<size_t>(std::max<int64_t>(n, 1)) * sizeof(E)));
+        p_ = static_cast<E *>(p);
+    }
+    DeviceArray(DeviceArray &&o) noexcept : p_(o.p_), n_(o.n_) { o.p_ = nullptr; o.n_ = 0; }
+    DeviceArray &operator=(DeviceArray &&o) noexcept {
+        if (this != &o) {
+            lsk_free(p_);
+            p_ = o.p_;
+            n_ = o.n_;
+            o.p_ = nullptr;
+            o.n_ = 0;
+        }
+        return *this;
+    }
+    DeviceArray(const DeviceArray &) = delete;
+    DeviceArray &operator=(const DeviceArray &) = delete;
+    ~DeviceArray() { lsk_free(p_); }
+    E *get() const { return p_; }
+    int64_t size() const { return n_; }
+    std::vector<E> to_host(const Context &ctx, int64_t first = 0, int64_t count = -1) const {
+        if (count < 0) count = n_ - first;
+        std::vector<E> out(static_cast<size_t>(count));
+        check(lsk_memcpy_d2h(out.data(), p_ + first, static_cast<size_t>(count) * sizeof(E), ctx.stream()));
+        ctx.synchronize();
+        return out;
+    }
+    void from_host(const Context &ctx, const std::vector<E> &src) {
+        check(lsk_memcpy_h2d(p_, src.data(), src.size() * sizeof(E), ctx.stream()));
+        ctx.synchronize();
+    }
+
+private:
+    E *p_ = nullptr;
+    int64_t n_ = 0;
+};
+
+// Scalar<T> (src/Scalar.hpp): a future of one T, here one T in device memory written by a
+// stream-ordered kernel; the operators are the scalar tasks of src/UtilityTasks.cpp:34-99.
+template <typename T> class Scalar {
+public:
+    Scalar() = default;
+    Scalar(const Context &ctx, T value) : Scalar(uninitialised(ctx)) {
+        check(Abi<T>::fill(1, value, writable(), ctx.stream()));
+    }
+    // A future nobody has written yet.  The Context must outlive every Scalar made from it.
+    static Scalar uninitialised(const Context &ctx) {
+        static_assert(sizeof(T) <= 8, "scalar slots are 8 bytes");
+        Scalar s;
+        s.ctx_ = &ctx;
+        const Context *owner = &ctx;
+        s.v_ = std::shared_ptr<T>(static_cast<T *>(ctx.acquire_slot()), [owner](T *p) { owner->release_slot(p); });
+        return s;
+    }
+    const T *get_future() const { return v_.get(); }
+    T *writable() const { return v_.get(); }
+    T get() const { // blocks, like Future::get_result
+        T out;
+        check(lsk_memcpy_d2h(&out, v_.get(), sizeof(T), ctx_->stream()));
+        ctx_->synchronize();
+        return out;
+    }
+    Scalar operator-() const { return op(LSK_SOP_NEG, nullptr); }
+    Scalar operator+(const Scalar &r) const { return op(LSK_SOP_ADD, &r); }
+    Scalar operator-(const Scalar &r) const { return op(LSK_SOP_SUB, &r); }
+    Scalar operator*(const Scalar &r) const { return op(LSK_SOP_MUL, &r); }
+    Scalar operator/(const Scalar &r) const { return op(LSK_SOP_DIV, &r); }
+    Scalar sqrt() const { return op(LSK_SOP_SQRT, nullptr); }
+    Scalar rsqrt() const { return op(LSK_SOP_RSQRT, nullptr); }
+
+private:
+    Scalar op(int code, const Scalar *r) const {
+        Scalar out = uninitialised(*ctx_);
+        check(Abi<T>::scalar_op(code, get_future(), r ? r->get_future() : nullptr, out.writable(), ctx_->stream()));
+        return out;
+    }
+    const Context *ctx_ = nullptr;
+    std::shared_ptr<T> v_;
+};
+
+// Bounds of `pieces` consecutive blocks of 0..n-1 as Legion's create_equal_partition colours
+// them: sizes differ by at most one, the larger blocks come last.
+struct EqualPartition {
+    int64_t n = 0;
+    std::vector<std::pair<int64_t, int64_t>> piece; // inclusive; hi < lo when empty
+    EqualPartition() = default;
+    EqualPartition(int64_t size, int pieces) : n(size) {
+        if (pieces < 1) throw std::invalid_argument("a partition needs at least one colour");
+        int64_t px = 0;
+        for (int i = 0; i < pieces; ++i) {
+            const int64_t nx = (n - px) / (pieces - i);
+            piece.emplace_back(px, px + nx - 1);
+            px += nx;
+        }
+    }
+    int colors() const { return static_cast<int>(piece.size()); }
+    int64_t volume(int c) const { return piece[c].second - piece[c].first + 1; }
+    bool operator==(const EqualPartition &o) const { return n == o.n && piece == o.piece; }
+};
+
+// PartitionedVector<T> (src/PartitionedVector.hpp): one dense buffer, coloured by the partition.
+template <typename T> class PartitionedVector {
+public:
+    PartitionedVector(const Context &ctx, std::string name, const EqualPartition &partition)
+        : ctx_(&ctx), name_(std::move(name)), part_(partition), data_(partition.n), slots_(partition.colors()) {}
+    const Context &context() const { return *ctx_; }
+    const EqualPartition &partition() const { return part_; }
+    const std::string &name() const { return name_; }
+    T *data() const { return data_.get(); }
+    T *piece(int c) const { return data_.get() + part_.piece[c].first; }
+    std::vector<T> to_host() const { return data_.to_host(*ctx_); }
+
+    void constant_fill(T value) { each([&](int c) { check(Abi<T>::fill(part_.volume(c), value, piece(c), ctx_->stream())); }); }
+    void zero_fill() { constant_fill(T(0)); }
+    PartitionedVector &operator=(const PartitionedVector &src) { // CopyTask per piece
+        same_partition(src);
+        each([&](int c) { check(Abi<T>::copy(part_.volume(c), src.piece(c), piece(c), ctx_->stream())); });
+        return *this;
+    }
+    PartitionedVector(const PartitionedVector &) = delete;
+
+    // alpha = get_alpha(futures) (src/LegionUtilities.cpp:72-97): f0, f0/f1, f0*f1/f2, f0*f1/(f2*f3)
+    void scal(const std::vector<Scalar<T>> &alpha) {
+        const T *f[4];
+        const int nf = futures(alpha, f);
+        each([&](int c) { check(Abi<T>::scal_dev(part_.volume(c), nf, f[0], f[1], f[2], f[3], piece(c), ctx_->stream())); });
+    }
+    void axpy(const std::vector<Scalar<T>> &alpha, const PartitionedVector &x) {
+        same_partition(x);
+        const T *f[4];
+        const int nf = futures(alpha, f);
+        each([&](int c) {
+            check(Abi<T>::axpy_dev(part_.volume(c), nf, f[0], f[1], f[2], f[3], x.piece(c), piece(c), ctx_->stream()));
+        });
+    }
+    void xpay(const std::vector<Scalar<T>> &alpha, const PartitionedVector &x) {
+        same_partition(x);
+        const T *f[4];
+        const int nf = futures(alpha, f);
+        each([&](int c) {
+            check(Abi<T>::xpay_dev(part_.volume(c), nf, f[0], f[1], f[2], f[3], x.piece(c), piece(c), ctx_->stream()));
+        });
+    }
+    // One dot leaf per piece, then the pieces' results added in colour order: Legion's REDOP_SUM
+    // over the future map (src/PartitionedVector.cpp:353-357).
+    Scalar<T> dot(const PartitionedVector &w) const {
+        same_partition(w);
+        // the pieces' results live in a buffer of this vector; everything is ordered on one stream,
+        // so the next dot may reuse it
+        for (int c = 0; c < part_.colors(); ++c)
+            check(Abi<T>::dot(part_.volume(c), piece(c), w.piece(c), slots_.get() + c, ctx_->workspace(),
+                              ctx_->workspace_bytes(), ctx_->stream()));
+        Scalar<T> out = Scalar<T>::uninitialised(*ctx_);
+        check(Abi<T>::sum_scalars(part_.colors(), slots_.get(), out.writable(), ctx_->stream()));
+        return out;
+    }
+
+private:
+    template <typename F> void each(F &&f) {
+        for (int c = 0; c < part_.colors(); ++c)
+            if (part_.volume(c) > 0) f(c);
+    }
+    void same_partition(const PartitionedVector &o) const {
+        if (!(part_ == o.part_)) throw std::invalid_argument("vectors are partitioned differently");
+    }
+    static int futures(const std::vector<Scalar<T>> &alpha, const T *(&f)[4]) {
+        if (alpha.size() > 4) throw std::invalid_argument("alpha takes at most 4 futures");
+        for (int i = 0; i < 4; ++i) f[i] = i < static_cast<int>(alpha.size()) ? alpha[i].get_future() : nullptr;
+        return static_cast<int>(alpha.size());
+    }
+    const Context *ctx_;
+    std::string name_;
+    EqualPartition part_;
+    DeviceArray<T> data_;
+    DeviceArray<T> slots_; // one dot result per piece
+};
+
+// AbstractMatrix (src/AbstractMatrix.hpp) as the planner uses it.
+template <typename T> class AbstractMatrix {
+public:
+    virtual ~AbstractMatrix() = default;
+    // dst <- beta * dst + A src, one leaf per colour of dst's partition
+    virtual void matvec(PartitionedVector<T> &dst, const PartitionedVector<T> &src, int beta) const = 0;
+    virtual bool accumulates_only() const = 0;
+};
+
+// CSRMatrix<T> (src/CSRMatrix.hpp) in the reference's layout: per row a {lo, hi} rect of global
+// entry indices, int64 global columns, T entries.  The kernel piece of a row block is the image of
+// its rects (src/CSRMatrix.cpp:89-109).  At construction a 32-bit copy of the structure is made
+// per piece when the library accepts it (bit-identical products, fewer bytes).
+template <typename T> class CSRMatrix : public AbstractMatrix<T> {
+public:
+    CSRMatrix(const Context &ctx, const EqualPartition &range, int64_t domain_size, DeviceArray<int64_t> rects,
+              DeviceArray<int64_t> col, DeviceArray<T> val, bool compress = true)
+        : ctx_(&ctx), range_(range), domain_(domain_size), rects_(std::move(rects)), col_(std::move(col)),
+          val_(std::move(val)) {
+        for (int c = 0; c < range_.colors(); ++c) {
+            Piece p;
+            if (range_.volume(c) > 0) {
+                const auto first = rects_.to_host(ctx, 2 * range_.piece[c].first, 2);
+                const auto last = rects_.to_host(ctx, 2 * range_.piece[c].second, 2);
+                p.k_lo = first[0];
+                p.nnz = std::max<int64_t>(last[1] - first[0] + 1, 0);
+            }
+            pieces_.push_back(std::move(p));
+        }
+        if (compress && col_.size() > 0 && domain_ > 0) try_compress();
+    }
+    bool compressed() const { return col32_.size() > 0; }
+    bool accumulates_only() const override { return false; }
+    void matvec(PartitionedVector<T> &dst, const PartitionedVector<T> &src, int beta) const override {
+        if (!(dst.partition() == range_) || src.partition().n != domain_)
+            throw std::invalid_argument("matrix and vectors do not fit");
+        for (int c = 0; c < range_.colors(); ++c) {
+            const int64_t rows = range_.volume(c);
+            if (rows <= 0) continue;
+            const Piece &p = pieces_[c];
+            if (compressed())
+                check(Abi<T>::csr_spmv_c32(rows, p.nnz, p.rowoff.get(), col32_.get() + p.k_lo, val_.get() + p.k_lo,
+                                           src.data(), domain_, dst.piece(c), beta, ctx_->stream()));
+            else
+                check(Abi<T>::csr_spmv(rows, p.nnz, rects_.get() + 2 * range_.piece[c].first, p.k_lo,
+                                       col_.get() + p.k_lo, val_.get() + p.k_lo, src.data(), 0, domain_ - 1,
+                                       dst.piece(c), beta, ctx_->stream()));
+        }
+    }
+
+private:
+    struct Piece {
+        int64_t k_lo = 0, nnz = 0;
+        DeviceArray<uint32_t> rowoff;
+    };
+    void try_compress() {
+        DeviceArray<uint32_t> col32(col_.size());
+        if (lsk_csr_compress_cols_u32(col_.size(), col_.get(), 0, domain_ - 1, col32.get(), ctx_->stream()) != LSK_OK)
+            return;
+        for (int c = 0; c < range_.colors(); ++c) {
+            const int64_t rows = range_.volume(c);
+            if (rows <= 0) continue;
+            DeviceArray<uint32_t> off(rows + 1);
+            const int rc = lsk_csr_compress_rows_u32(rows, pieces_[c].nnz, rects_.get() + 2 * range_.piece[c].first,
+                                                     pieces_[c].k_lo, off.get(), ctx_->stream());
+            if (rc == LSK_ERR_UNSUPPORTED) {
+                for (auto &p : pieces_) p.rowoff = DeviceArray<uint32_t>();
+                return;
+            }
+            check(rc);
+            pieces_[c].rowoff = std::move(off);
+        }
+        col32_ = std::move(col32);
+    }
+    const Context *ctx_;
+    EqualPartition range_;
+    int64_t domain_;
+    DeviceArray<int64_t> rects_, col_;
+    DeviceArray<T> val_;
+    DeviceArray<uint32_t> col32_;
+    std::vector<Piece> pieces_;
+};
+
+// COOMatrix<T> (src/COOMatrix.hpp): int64 global row and column ids, T entries, row-sorted, so the
+// kernel piece of a row block (the preimage of its rows, src/COOMatrix.cpp:77-95) is one run of
+// entries, handed over as `piece_entries` (first entry, count) per colour.
+template <typename T> class COOMatrix : public AbstractMatrix<T> {
+public:
+    COOMatrix(const Context &ctx, const EqualPartition &range, int64_t domain_size, DeviceArray<int64_t> row,
+              DeviceArray<int64_t> col, DeviceArray<T> val, std::vector<std::pair<int64_t, int64_t>> piece_entries)
+        : ctx_(&ctx), range_(range), domain_(domain_size), row_(std::move(row)), col_(std::move(col)),
+          val_(std::move(val)), entries_(std::move(piece_entries)) {}
+    bool accumulates_only() const override { return true; }
+    void matvec(PartitionedVector<T> &dst, const PartitionedVector<T> &src, int beta) const override {
+        if (beta != 1) throw std::invalid_argument("COO matvec accumulates (beta = 1)");
+        for (int c = 0; c < range_.colors(); ++c) {
+            if (range_.volume(c) <= 0 || entries_[c].second <= 0) continue;
+            const int64_t k = entries_[c].first;
+            check(Abi<T>::coo_spmv(entries_[c].second, row_.get() + k, col_.get() + k, val_.get() + k, src.data(), 0,
+                                   domain_ - 1, dst.piece(c), range_.piece[c].first, range_.piece[c].second,
+                                   ctx_->stream()));
+        }
+    }
+
+private:
+    const Context *ctx_;
+    EqualPartition range_;
+    int64_t domain_;
+    DeviceArray<int64_t> row_, col_;
+    DeviceArray<T> val_;
+    std::vector<std::pair<int64_t, int64_t>> entries_;
+};
+
+// SquarePlanner<T> (src/SquarePlanner.hpp): the solution / right-hand-side / workspace vectors of
+// one or more spaces, addressed by index (0 = solution, 1 = right-hand side, 2.. = workspace),
+// and the matrices between the spaces.  Every operation runs over all spaces; dot adds the spaces'
+// results (:300-329); matvec is zero fill + one accumulating product per matrix (:340-357), the
+// first CSR product into a space overwriting instead of the zero fill (same result).
+template <typename T> class SquarePlanner {
+public:
+    static constexpr int SOL = 0, RHS = 1;
+    explicit SquarePlanner(const Context &ctx) : ctx_(&ctx), vectors_(2) {}
+    const Context &get_context() const { return *ctx_; }
+    int add_sol_vector(PartitionedVector<T> &v) { return add(v, SOL); }
+    int add_rhs_vector(PartitionedVector<T> &v) { return add(v, RHS); }
+    int get_num_spaces() const {
+        if (vectors_[SOL].size() != vectors_[RHS].size())
+            throw std::logic_error("every space needs one solution and one right-hand-side vector");
+        return static_cast<int>(vectors_[SOL].size());
+    }
+    void add_row_partitioned_matrix(const AbstractMatrix<T> &m, int domain_index, int range_index) {
+        const int n = get_num_spaces();
+        if (domain_index < 0 || domain_index >= n || range_index < 0 || range_index >= n)
+            throw std::out_of_range("matrix refers to a space the planner does not have");
+        matrices_.push_back({&m, domain_index, range_index});
+    }
+    void allocate_workspace(int count) {
+        const int n = get_num_spaces();
+        for (int i = 0; i < count; ++i) {
+            std::vector<PartitionedVector<T> *> row;
+            for (int s = 0; s < n; ++s) {
+                owned_.push_back(std::make_unique<PartitionedVector<T>>(
+                    *ctx_, "workspace_" + std::to_string(vectors_.size() - 2) + "_" + std::to_string(s),
+                    vectors_[SOL][s]->partition()));
+                row.push_back(owned_.back().get());
+            }
+            vectors_.push_back(std::move(row));
+        }
+    }
+    PartitionedVector<T> &get_vector(int index, int space) const { return *vectors_.at(index).at(space); }
+    void zero_fill(int dst) { for (auto *v : vectors_.at(dst)) v->zero_fill(); }
+    void copy(int dst, int src) { for (size_t s = 0; s < vectors_.at(dst).size(); ++s) *vectors_[dst][s] = *vectors_.at(src)[s]; }
+    void scal(int dst, const std::vector<Scalar<T>> &alpha) { for (auto *v : vectors_.at(dst)) v->scal(alpha); }
+    void axpy(int dst, const std::vector<Scalar<T>> &alpha, int src) {
+        for (size_t s = 0; s < vectors_.at(dst).size(); ++s) vectors_[dst][s]->axpy(alpha, *vectors_.at(src)[s]);
+    }
+    void xpay(int dst, const std::vector<Scalar<T>> &alpha, int src) {
+        for (size_t s = 0; s < vectors_.at(dst).size(); ++s) vectors_[dst][s]->xpay(alpha, *vectors_.at(src)[s]);
+    }
+    Scalar<T> dot(int v, int w) const {
+        Scalar<T> acc = vectors_.at(v)[0]->dot(*vectors_.at(w)[0]);
+        for (size_t s = 1; s < vectors_[v].size(); ++s) acc = acc + vectors_[v][s]->dot(*vectors_[w][s]);
+        return acc;
+    }
+    void matvec(int dst, int src) {
+        std::vector<bool> touched(vectors_.at(dst).size(), false);
+        for (const auto &e : matrices_) {
+            PartitionedVector<T> &y = *vectors_[dst][e.range];
+            if (!touched[e.range] && e.matrix->accumulates_only()) y.zero_fill();
+            e.matrix->matvec(y, *vectors_.at(src)[e.domain], touched[e.range] || e.matrix->accumulates_only() ? 1 : 0);
+            touched[e.range] = true;
+        }
+        for (size_t s = 0; s < touched.size(); ++s)
+            if (!touched[s]) vectors_[dst][s]->zero_fill();
+    }
+
+private:
+    struct Entry {
+        const AbstractMatrix<T> *matrix;
+        int domain, range;
+    };
+    int add(PartitionedVector<T> &v, int index) {
+        vectors_[index].push_back(&v);
+        return static_cast<int>(vectors_[index].size()) - 1;
+    }
+    const Context *ctx_;
+    std::vector<std::vector<PartitionedVector<T> *>> vectors_;
+    std::vector<std::unique_ptr<PartitionedVector<T>>> owned_;
+    std::vector<Entry> matrices_;
+};
+
+// CGSolver<T> (src/CGSolver.hpp:13-57).
+template <typename T> class CGSolver {
+public:
+    static constexpr int SOL = 0, RHS = 1, P = 2, Q = 3, R = 4;
+    std::vector<Scalar<T>> residual_norm_squared;
+    explicit CGSolver(SquarePlanner<T> &planner) : pl(planner), negative_one(planner.get_context(), T(-1)) {
+        pl.allocate_workspace(3);
+        pl.copy(P, RHS);
+        pl.copy(R, RHS);
+        residual_norm_squared.push_back(pl.dot(R, R));
+    }
+    void step() {
+        pl.matvec(Q, P);
+        const Scalar<T> p_norm = pl.dot(P, Q);
+        const Scalar<T> r_norm2_old = residual_norm_squared.back();
+        pl.axpy(SOL, {r_norm2_old, p_norm}, P);
+        pl.axpy(R, {negative_one, r_norm2_old, p_norm}, Q);
+        const Scalar<T> r_norm2_new = pl.dot(R, R);
+        residual_norm_squared.push_back(r_norm2_new);
+        pl.xpay(P, {r_norm2_new, r_norm2_old}, R);
+    }
+
+private:
+    SquarePlanner<T> &pl;
+    Scalar<T> negative_one;
+};
+
+// BiCGStabSolver<T> (src/BiCGStabSolver.hpp:13-84).
+template <typename T> class BiCGStabSolver {
+public:
+    static constexpr int SOL = 0, RHS = 1, P = 2, R = 3, R_TILDE = 4, U = 5, V = 6;
+    std::vector<Scalar<T>> rho, alpha, omega;
+    explicit BiCGStabSolver(SquarePlanner<T> &planner)
+        : pl(planner), negative_one(planner.get_context(), T(-1)), zero(planner.get_context(), T(0)),
+          one(planner.get_context(), T(1)) {
+        pl.allocate_workspace(5);
+        pl.copy(R, RHS);
+        pl.copy(R_TILDE, RHS);
+        rho.push_back(one);
+        alpha.push_back(zero);
+        omega.push_back(one);
+        pl.zero_fill(P);
+        pl.zero_fill(V);
+    }
+    void step() {
+        const Scalar<T> rho_new = pl.dot(R, R_TILDE);
+        const Scalar<T> beta = (rho_new / rho.back()) * (alpha.back() / omega.back());
+        rho.push_back(rho_new);
+        pl.axpy(P, {-omega.back()}, V);
+        pl.xpay(P, {beta}, R);
+        pl.matvec(V, P);
+        const Scalar<T> temp = pl.dot(R_TILDE, V);
+        pl.axpy(R, {negative_one, rho.back(), temp}, V);
+        alpha.push_back(rho.back() / temp);
+        pl.matvec(U, R);
+        const Scalar<T> r_anorm2 = pl.dot(R, U);
+        const Scalar<T> u_norm2 = pl.dot(U, U);
+        omega.push_back(r_anorm2 / u_norm2);
+        pl.axpy(SOL, {alpha.back()}, P);
+        pl.axpy(SOL, {omega.back()}, R);
+        pl.axpy(R, {-omega.back()}, U);
+    }
+
+private:
+    SquarePlanner<T> &pl;
+    Scalar<T> negative_one, zero, one;
+};
+
+// GMRESSolver<T> (src/GMRESSolver.hpp:15-129).  As in the reference the least-squares solve is not
+// there yet: the solution update takes DummyTask's coefficient 1 for every basis vector (:109-126).
+template <typename T> class GMRESSolver {
+public:
+    static constexpr int SOL = 0, RHS = 1;
+    GMRESSolver(SquarePlanner<T> &planner, int restart_length)
+        : pl(planner), restart(restart_length), negative_one(planner.get_context(), T(-1)),
+          dummy_coefficient(planner.get_context(), T(1)) {
+        pl.allocate_workspace(restart + 1);
+    }
+    static int krylov_basis(int i) { return i + 2; }
+    void step() {
+        pl.matvec(krylov_basis(0), SOL);
+        pl.xpay(krylov_basis(0), {negative_one}, RHS);
+        pl.scal(krylov_basis(0), {pl.dot(krylov_basis(0), krylov_basis(0)).rsqrt()});
+        for (int j = 0; j < restart; ++j) {
+            pl.matvec(krylov_basis(j + 1), krylov_basis(j));
+            for (int k = 0; k <= j; ++k) {
+                const Scalar<T> h = pl.dot(krylov_basis(k), krylov_basis(j + 1));
+                pl.axpy(krylov_basis(j + 1), {-h}, krylov_basis(k));
+            }
+            const Scalar<T> d = pl.dot(krylov_basis(j + 1), krylov_basis(j + 1));
+            if (j + 1 < restart) pl.scal(krylov_basis(j + 1), {d.rsqrt()});
+        }
+        for (int j = 0; j < restart; ++j) pl.axpy(SOL, {dummy_coefficient}, krylov_basis(j));
+    }
+
+private:
+    SquarePlanner<T> &pl;
+    int restart;
+    Scalar<T> negative_one, dummy_coefficient;
+};
+
+} // namespace LegionSolversHost

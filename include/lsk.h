@@ -409,6 +409,11 @@ int lsk_stencil_fill_coo_f64(int dim, const int64_t *extent, int noffsets,
                              int64_t row_hi, const int64_t *rects, int64_t k_base,
                              int64_t *row, int64_t *col, double *val, lsk_stream_t stream);
 
+/* out[i] = in[0] + ... + in[i] (in-place allowed), n < 2^31: the running entry count the serial
+ * fill tasks carry from row to row (src/StencilGenerator.cpp:494-511), as one device scan.  Set-up
+ * time: allocates and frees its scratch and returns when the scan has finished. */
+int lsk_inclusive_sum_i64(int64_t n, const int64_t *in, int64_t *out, lsk_stream_t stream);
+
 /* rects[i] = {base + prefix[i], base + prefix[i] + counts[i] - 1} where prefix is the
  * exclusive prefix sum of counts given as `prefix_incl[i] = counts[0]+...+counts[i]`
  * (the row_begin/row_end rule of src/StencilGenerator.cpp:494-511). */

@@ -6,6 +6,8 @@
 // time at 512^3 -- here every row is generated independently.
 #include <climits>
 
+#include <hipcub/hipcub.hpp>
+
 #include "lsk_common.hpp"
 
 namespace {
@@ -304,6 +306,24 @@ int lsk_stencil_fill_coo_f64(int dim, const int64_t *extent, int noffsets, const
                              double *val, lsk_stream_t stream) {
     return launch_fill<double, true>("lsk_stencil_fill_coo_f64", dim, extent, noffsets, offsets,
                                      coeffs, row_lo, row_hi, rects, k_base, row, col, val, stream);
+}
+
+int lsk_inclusive_sum_i64(int64_t n, const int64_t *in, int64_t *out, lsk_stream_t stream) {
+    if (n < 0) return lsk::fail(LSK_ERR_ARG, "lsk_inclusive_sum_i64: negative length");
+    if (n == 0) return LSK_OK;
+    if (!in || !out) return lsk::fail(LSK_ERR_ARG, "lsk_inclusive_sum_i64: null pointer");
+    if (n > 0x7fffffffLL) return lsk::fail(LSK_ERR_UNSUPPORTED, "lsk_inclusive_sum_i64: more than 2^31 - 1 values");
+    hipStream_t s = lsk::as_stream(stream);
+    void *temp = nullptr;
+    size_t temp_bytes = 0;
+    LSK_HIP(hipcub::DeviceScan::InclusiveSum(nullptr, temp_bytes, in, out, static_cast<int>(n), s));
+    LSK_HIP(hipMalloc(&temp, temp_bytes ? temp_bytes : 1));
+    const hipError_t st = hipcub::DeviceScan::InclusiveSum(temp, temp_bytes, in, out, static_cast<int>(n), s);
+    const hipError_t sy = hipStreamSynchronize(s); // set-up time: the scratch is freed before returning
+    (void)hipFree(temp);
+    LSK_HIP(st);
+    LSK_HIP(sy);
+    return LSK_OK;
 }
 
 int lsk_rects_from_counts_i64(int64_t rows, const int64_t *counts, const int64_t *prefix_incl,

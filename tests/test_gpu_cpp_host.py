@@ -1,0 +1,72 @@
+"""The C++ host layer (host_cpp/: the reference's caller classes and its BenchmarkStencil program above
+the C ABI, no Python or torch underneath; built by __graft_entry__.build()).  The program is run as
+a child process and what it prints is compared with the reference's golden CG output
+(test_all.py:130-133) and with the CPU oracle's solvers on the same systems."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import solvers as S
+
+import host_cases as hc
+
+pytestmark = pytest.mark.gpu
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BINARY = os.path.join(REPO, "host_cpp", "BenchmarkStencil")
+
+
+def run(*flags):
+    if not os.path.exists(BINARY):
+        pytest.fail("host_cpp/BenchmarkStencil is not built: run __graft_entry__.build()")
+    args = [str(f) for f in flags]
+    print("case BenchmarkStencil " + " ".join(args), flush=True)
+    res = subprocess.run([BINARY, *args], capture_output=True, text=True, timeout=200)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = res.stdout.splitlines()
+    assert lines[0] == "Performed 5 warmup traces." and lines[1].startswith("Performed ")
+    assert lines[2].startswith("Achieved ") and lines[2].endswith("ms per iteration.")
+    values = [l for l in lines[3:] if not l.startswith("solution_")]
+    sums = {l.split()[0]: float(l.split()[1]) for l in lines[3:] if l.startswith("solution_")}
+    return [float(v) for v in values], sums, lines[3:]
+
+
+@pytest.mark.parametrize("coo", [0, 1])
+def test_reference_golden_cg_output(goldens, krylov_golden, coo):
+    """Test05COOSolveCG / Test06CSRSolveCG: 1-D Laplacian N = 100, 4 pieces, 10 steps."""
+    hist, _, raw = run("-dim", 1, "-nx", 100, "-vp", 4, "-it", 10, "-systems", 1, "-history", 1, "-coo", coo)
+    assert sorted(raw[:11]) == sorted(goldens["expected_cg_output_sorted_set"])
+    np.testing.assert_allclose(hist, krylov_golden["cases"][0]["residual_norm_squared"], rtol=1e-10)
+
+
+@pytest.mark.parametrize("f32", [0, 1])
+@pytest.mark.parametrize("solver", [1, 2, 3])
+@pytest.mark.parametrize("coo", [0, 1])
+def test_solvers_follow_the_oracle(solver, coo, f32):
+    """27-point stencil 10 x 9 x 8 in 3 pieces, two systems as in the reference's program."""
+    dtype = np.float32 if f32 else np.float64
+    steps = {1: 8, 2: 6, 3: 6}[solver]
+    rects, row, col, val, n = hc.stencil_problem(4, (10, 9, 8), dtype)
+    opl = hc.oracle_planner("coo" if coo else "csr", rects, row, col, val, n, 3, dtype, spaces=2)
+    so = {1: S.CGSolver, 2: S.BiCGStabSolver}[solver](opl) if solver < 3 else S.GMRESSolver(opl, 4)
+    for _ in range(steps):
+        so.step()
+    hist, sums, _ = run("-dim", 4, "-nx", 10, "-ny", 9, "-nz", 8, "-vp", 3, "-solver", solver, "-it", steps,
+                        "-restart", 4, "-history", 1, "-coo", coo, "-f32", f32)
+    rtol = 2e-3 if f32 else 1e-9
+    if solver == 1:
+        np.testing.assert_allclose(hist, [float(v) for v in so.residual_norm_squared], rtol=rtol)
+    elif solver == 2:
+        np.testing.assert_allclose(hist, [float(v) for v in so.rho], rtol=rtol)
+    x = opl.get_vector(0, 0).astype(np.float64)
+    np.testing.assert_allclose(sums["solution_sum_of_squares"], float(np.sum(x * x)), rtol=rtol * 10)
+    assert abs(sums["solution_sum"] - float(np.sum(x))) <= rtol * 10 * float(np.sum(np.abs(x)))
+
+
+def test_compressed_structure_prints_the_same():
+    """-compress 0 (products on the int64 columns and rects) and the default 32-bit copy of the
+    structure print the same history to the last digit."""
+    flags = ("-dim", 3, "-nx", 20, "-ny", 17, "-nz", 33, "-vp", 2, "-it", 9, "-systems", 1, "-history", 1)
+    assert run(*flags)[2] == run(*flags, "-compress", 0)[2]
