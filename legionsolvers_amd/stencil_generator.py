@@ -70,7 +70,9 @@ def _build(ctx, extent, offsets, coeffs, index_partition: IndexPartition, dtype,
     counts = torch.empty(rows, dtype=torch.int64, device=dev)
     _lib.call("lsk_stencil_count", dim, ext_c, len(offs), off_c, row_lo, row_hi,
               ctypes.c_void_p(counts.data_ptr()), be.stream())
-    prefix = torch.cumsum(counts, 0)
+    prefix = torch.empty_like(counts)
+    _lib.call("lsk_inclusive_sum_i64", rows, ctypes.c_void_p(counts.data_ptr()),
+              ctypes.c_void_p(prefix.data_ptr()), be.stream())
     nnz = int(prefix[-1].item()) if rows else 0
     k_base = sum(ctx.comm.all_gather_object(nnz)[:ctx.rank])
 

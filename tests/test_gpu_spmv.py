@@ -544,6 +544,19 @@ def test_rects_to_indptr_bit_exact():
         assert np.array_equal(out.cpu().numpy(), oracle.rects_to_indptr(piece))
 
 
+def test_inclusive_sum_bit_exact():
+    rng = np.random.default_rng(71)
+    for n in (1, 2, 255, 256, 257, 100_003, 3_000_000):
+        print(f"case inclusive_sum n={n}", flush=True)
+        a = rng.integers(0, 40, size=n).astype(np.int64)
+        src, out = dev(a), torch.zeros(n, dtype=torch.int64, device="cuda")
+        _lib.call("lsk_inclusive_sum_i64", n, P(src), P(out), stream())
+        assert np.array_equal(out.cpu().numpy(), np.cumsum(a))
+        _lib.call("lsk_inclusive_sum_i64", n, P(src), P(src), stream())  # in place
+        assert np.array_equal(src.cpu().numpy(), np.cumsum(a))
+    _lib.call("lsk_inclusive_sum_i64", 0, None, None, stream())
+
+
 def test_index_bounds():
     rng = np.random.default_rng(27)
     for n in (1, 100, 100000, (1 << 21) + 7):
