@@ -97,6 +97,12 @@ def cpu_baseline(full_rows: int):
     for _ in range(steps):
         rr = oracle.cg_step_mt(rects, col, val, sol, p, q, r, rr, cores)
     dt = (time.perf_counter() - t0) / steps
+    # the same step on one thread, one row block (the scalar port)
+    oracle.set_threads(1)
+    t0 = time.perf_counter()
+    rr = oracle.cg_step_mt(rects, col, val, sol, p, q, r, rr, 1)
+    dt1 = time.perf_counter() - t0
+    oracle.set_threads(cores)
     return {
         "value": (1.0 / dt) * rows / full_rows,
         "unit": "iters/s",
@@ -105,6 +111,7 @@ def cpu_baseline(full_rows: int):
         "sample": f"{steps} CG steps of the CPU oracle (OpenMP, {cores} row blocks) on the 27-pt "
                   f"stencil at {n1}^3 ({rows} rows, {val.size} entries); {dt * 1e3:.1f} ms/step there, "
                   f"scaled by rows to 512^3",
+        "value_one_thread": (1.0 / dt1) * rows / full_rows,
     }
 
 
