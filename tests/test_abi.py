@@ -101,3 +101,22 @@ def test_abort_on_error_matches_the_reference_behaviour():
     assert res.returncode == -6, (res.returncode, res.stderr[-500:])  # SIGABRT
     assert "[lsk]" in res.stderr and "negative" in res.stderr
     assert "survived" not in res.stdout
+
+
+def test_header_is_plain_c_and_the_native_callers_compile():
+    """include/lsk.h compiles as strict C99 (what a cgo / FFI binding would parse), and the C and
+    C++ callers above it (examples/cg_c_abi.c, host_cpp/) compile against it; no GPU, no linking."""
+    import shutil
+    import subprocess
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    inc = os.path.join(repo, "include")
+    if not (shutil.which("gcc") and shutil.which("g++")):
+        pytest.skip("no host compiler")
+    for cmd in (["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-fsyntax-only", "-x", "c",
+                 os.path.join(inc, "lsk.h")],
+                ["gcc", "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-I", inc,
+                 os.path.join(repo, "examples", "cg_c_abi.c")],
+                ["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-I", inc,
+                 "-I", os.path.join(repo, "host_cpp"), os.path.join(repo, "host_cpp", "benchmark_stencil.cpp")]):
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        assert res.returncode == 0, " ".join(cmd) + "\n" + res.stderr[-3000:]
