@@ -362,6 +362,18 @@ int lsk_coo_spmv_f64(int64_t nnz, const int64_t *row, const int64_t *col, const 
                      const double *x, int64_t x_lo, int64_t x_hi, double *y, int64_t y_lo,
                      int64_t y_hi, lsk_stream_t stream);
 
+/* The same on a set-up-time 32-bit copy of the index fields (lsk_csr_compress_cols_u32 serves for
+ * both: row32 = row - row_origin over the caller's row window, col32 = col - x_lo over the x window,
+ * 0xffffffff = outside).  `x` points at the x window's first element, `y` at the row
+ * row_origin + y_first; entries with row32 outside y_first..y_last or col32 >= x_extent are
+ * dropped.  16 instead of 24 (fp64) bytes per entry; same kernel, same run sums. */
+int lsk_coo_spmv_c32_f32(int64_t nnz, const uint32_t *row32, const uint32_t *col32, const float *val,
+                         const float *x, int64_t x_extent, float *y, int64_t y_first, int64_t y_last,
+                         lsk_stream_t stream);
+int lsk_coo_spmv_c32_f64(int64_t nnz, const uint32_t *row32, const uint32_t *col32, const double *val,
+                         const double *x, int64_t x_extent, double *y, int64_t y_first, int64_t y_last,
+                         lsk_stream_t stream);
+
 /* ------------------------------------------------ set-up helpers (device side) ------ */
 /* out[0] = min idx[i], out[1] = max idx[i] (out = {INT64_MAX, INT64_MIN} when n == 0):
  * the bounding interval of create_partition_by_image over a column field

@@ -161,6 +161,10 @@ class HipBackend:
 
     def coo_spmv(self, nnz: int, row: torch.Tensor, col: torch.Tensor, val: torch.Tensor,
                  x: torch.Tensor, x_lo: int, x_hi: int, y: torch.Tensor, y_lo: int, y_hi: int) -> None:
+        if row.dtype == torch.int32:  # 32-bit copies: y_lo / y_hi count from the origin of row32
+            _lib.call(f"lsk_coo_spmv_c32_{_lib.suffix(val.dtype)}", nnz, _ptr(row), _ptr(col), _ptr(val),
+                      _ptr(x), x_hi - x_lo + 1, _ptr(y), y_lo, y_hi, self.stream())
+            return
         _lib.call(f"lsk_coo_spmv_{_lib.suffix(val.dtype)}", nnz, _ptr(row), _ptr(col), _ptr(val),
                   _ptr(x), x_lo, x_hi, _ptr(y), y_lo, y_hi, self.stream())
 

@@ -101,6 +101,9 @@ __device__ __forceinline__ long long wave_read_lane(long long v, int src) {
     const int hi = __builtin_amdgcn_readlane(static_cast<int>(v >> 32), src);
     return (static_cast<long long>(hi) << 32) | static_cast<unsigned>(lo);
 }
+__device__ __forceinline__ uint32_t wave_read_lane(uint32_t v, int src) {
+    return static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(v), src));
+}
 __device__ __forceinline__ double wave_read_lane(double v, int src) {
     return __longlong_as_double(wave_read_lane(__double_as_longlong(v), src));
 }
@@ -123,18 +126,35 @@ template <typename T> __device__ __forceinline__ T run_scan(T s, int lane, int s
     return s;
 }
 
-template <typename T, int K>
+// Index field of the scan kernel: the reference's 64-bit global ids, or 32-bit offsets into the x
+// and y windows made once at set-up (0xffffffff = outside the window, dropped like an id outside
+// x_lo..x_hi / y_lo..y_hi is dropped).
+template <typename IT> struct CooIndex;
+template <> struct CooIndex<int64_t> {
+    using type = long long;
+    static constexpr long long kNone = LLONG_MIN; // a row id no live entry has
+};
+template <> struct CooIndex<uint32_t> {
+    using type = uint32_t;
+    static constexpr uint32_t kNone = 0xffffffffu;
+};
+
+template <typename T, typename IT, int K>
 __global__ __launch_bounds__(kBlock) void coo_spmv_scan_kernel(
-    int64_t nnz, const int64_t *__restrict__ row, const int64_t *__restrict__ col,
+    int64_t nnz, const IT *__restrict__ row, const IT *__restrict__ col,
     const T *__restrict__ val, const T *__restrict__ x, int64_t x_lo, int64_t x_hi,
     T *__restrict__ y, int64_t y_lo, int64_t y_hi) {
+    using I = typename CooIndex<IT>::type;
+    constexpr I kNone = CooIndex<IT>::kNone;
     const int lane = threadIdx.x & (lsk::kWave - 1);
     const int64_t wave = int64_t(blockIdx.x) * (kBlock / lsk::kWave) + (threadIdx.x / lsk::kWave);
     const int64_t base = wave * (lsk::kWave * K);
     if (base >= nnz) return; // the whole wave leaves together
     const int64_t last = nnz - 1;
+    // window bounds in the index type (32-bit form: x_lo = 0 and the bounds fit by construction)
+    const I xl = static_cast<I>(x_lo), xh = static_cast<I>(x_hi), yl = static_cast<I>(y_lo), yh = static_cast<I>(y_hi);
 
-    long long rr[K], cc[K];
+    I rr[K], cc[K];
     T vv[K];
 #pragma unroll
     for (int j = 0; j < K; ++j) { // entries past the end re-read the last one and are dropped below
@@ -148,41 +168,41 @@ __global__ __launch_bounds__(kBlock) void coo_spmv_scan_kernel(
 #pragma unroll
     for (int j = 0; j < K; ++j) {
         const int64_t e = base + j * lsk::kWave + lane;
-        const bool live = e <= last && cc[j] >= x_lo && cc[j] <= x_hi && rr[j] >= y_lo && rr[j] <= y_hi;
-        const T xv = x[live ? cc[j] - x_lo : 0];
+        const bool live = e <= last && cc[j] >= xl && cc[j] <= xh && rr[j] >= yl && rr[j] <= yh;
+        const T xv = x[live ? cc[j] - xl : 0];
         pp[j] = live ? vv[j] * xv : T(0);
         // Dropped entries get a row id no live entry has: they form runs of their own, whose
         // sums are never written.
-        rr[j] = live ? rr[j] : LLONG_MIN;
+        rr[j] = live ? rr[j] : kNone;
     }
 
-    long long carry_row = LLONG_MIN; // run still open at the end of the previous step
+    I carry_row = kNone; // run still open at the end of the previous step
     T carry = T(0);
 #pragma unroll
     for (int j = 0; j < K; ++j) {
         if (base + j * lsk::kWave > last) break; // wave-uniform: nothing but dropped entries left
-        const long long r = rr[j];
+        const I r = rr[j];
         T s = pp[j];
-        const long long r0 = wave_read_lane(r, 0);
+        const I r0 = wave_read_lane(r, 0);
         if (lane == 0) {
             if (r0 == carry_row) s += carry;
-            else if (carry_row != LLONG_MIN) unsafeAtomicAdd(&y[carry_row - y_lo], carry);
+            else if (carry_row != kNone) unsafeAtomicAdd(&y[carry_row - yl], carry);
         }
-        const long long rp = __shfl_up(r, 1);
+        const I rp = __shfl_up(r, 1);
         const bool head = lane == 0 || rp != r;
         const unsigned long long heads = __ballot(head);
         const int start = 63 - __clzll(heads & (~0ull >> (63 - lane))); // bit 0 is always set
         s = run_scan(s, lane, start);
         const bool tail = lane < 63 && ((heads >> (lane + 1)) & 1ull);
-        if (tail && r != LLONG_MIN) unsafeAtomicAdd(&y[r - y_lo], s);
+        if (tail && r != kNone) unsafeAtomicAdd(&y[r - yl], s);
         carry_row = wave_read_lane(r, 63);
         carry = wave_read_lane(s, 63);
     }
-    if (lane == 0 && carry_row != LLONG_MIN) unsafeAtomicAdd(&y[carry_row - y_lo], carry);
+    if (lane == 0 && carry_row != kNone) unsafeAtomicAdd(&y[carry_row - yl], carry);
 }
 
-template <typename T>
-int launch_coo_spmv(const char *name, int64_t nnz, const int64_t *row, const int64_t *col,
+template <typename T, typename IT = int64_t>
+int launch_coo_spmv(const char *name, int64_t nnz, const IT *row, const IT *col,
                     const T *val, const T *x, int64_t x_lo, int64_t x_hi, T *y, int64_t y_lo,
                     int64_t y_hi, lsk_stream_t stream) {
     if (nnz < 0) return lsk::fail(LSK_ERR_ARG, "%s: negative nnz %lld", name, (long long)nnz);
@@ -192,9 +212,13 @@ int launch_coo_spmv(const char *name, int64_t nnz, const int64_t *row, const int
     if (!x || !y) return lsk::fail(LSK_ERR_ARG, "%s: null vector", name);
     const int64_t blocks = lsk::ceil_div(nnz, kChunk); // both forms: 2048 entries per workgroup
     if (blocks > 0x7fffffffLL) return lsk::fail(LSK_ERR_UNSUPPORTED, "%s: too many entries", name);
-    if (lsk::options().coo_variant == 1) {
+    if constexpr (sizeof(IT) == 4) {
         constexpr int K = kChunk / kBlock;
-        coo_spmv_scan_kernel<T, K><<<static_cast<unsigned>(blocks), kBlock, 0, lsk::as_stream(stream)>>>(
+        coo_spmv_scan_kernel<T, IT, K><<<static_cast<unsigned>(blocks), kBlock, 0, lsk::as_stream(stream)>>>(
+            nnz, row, col, val, x, x_lo, x_hi, y, y_lo, y_hi);
+    } else if (lsk::options().coo_variant == 1) {
+        constexpr int K = kChunk / kBlock;
+        coo_spmv_scan_kernel<T, IT, K><<<static_cast<unsigned>(blocks), kBlock, 0, lsk::as_stream(stream)>>>(
             nnz, row, col, val, x, x_lo, x_hi, y, y_lo, y_hi);
     } else {
         coo_spmv_kernel<T><<<static_cast<unsigned>(blocks), kBlock, 0, lsk::as_stream(stream)>>>(
@@ -221,5 +245,18 @@ int lsk_coo_spmv_f64(int64_t nnz, const int64_t *row, const int64_t *col, const 
     return launch_coo_spmv<double>("lsk_coo_spmv_f64", nnz, row, col, val, x, x_lo, x_hi, y, y_lo,
                                    y_hi, stream);
 }
+
+#define LSK_COO_C32(SUF, T)                                                                        \
+    int lsk_coo_spmv_c32_##SUF(int64_t nnz, const uint32_t *row32, const uint32_t *col32, const T *val, \
+                               const T *x, int64_t x_extent, T *y, int64_t y_first, int64_t y_last,   \
+                               lsk_stream_t stream) {                                                 \
+        if (x_extent < 0 || x_extent > 0xffffffffLL || y_first < 0 || y_last >= 0xffffffffLL)         \
+            return lsk::fail(LSK_ERR_ARG, "lsk_coo_spmv_c32_" #SUF ": window does not fit 32-bit offsets"); \
+        return launch_coo_spmv<T, uint32_t>("lsk_coo_spmv_c32_" #SUF, nnz, row32, col32, val, x, 0,   \
+                                            x_extent - 1, y, y_first, y_last, stream);                \
+    }
+LSK_COO_C32(f32, float)
+LSK_COO_C32(f64, double)
+#undef LSK_COO_C32
 
 } // extern "C"

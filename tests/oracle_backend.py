@@ -122,7 +122,12 @@ class OracleBackend:
         oracle.csr_matvec(_np(rects), k_base, c, _np(val), _np(x), x_lo, x_hi, _np(y), beta=beta)
 
     def coo_spmv(self, nnz, row, col, val, x, x_lo, x_hi, y, y_lo, y_hi):
-        oracle.coo_matvec(_np(row), _np(col), _np(val), _np(x), x_lo, x_hi, _np(y), y_lo, y_hi)
+        r, c = _np(row), _np(col)
+        if r.dtype == np.int32:  # 32-bit copies: offsets into the row / x windows, 0xffffffff = outside
+            ru, cu = r.view(np.uint32).astype(np.int64), c.view(np.uint32).astype(np.int64)
+            r = np.where(ru == 0xFFFFFFFF, -1, ru)  # y_lo / y_hi count from the same origin
+            c = np.where(cu == 0xFFFFFFFF, x_lo - 1, cu + x_lo)
+        oracle.coo_matvec(r, c, _np(val), _np(x), x_lo, x_hi, _np(y), y_lo, y_hi)
 
     def csr_halo_rows(self, rows, nnz, rects, k_base, col, lo, hi):
         r, c = _np(rects), _np(col)

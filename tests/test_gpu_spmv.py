@@ -327,6 +327,21 @@ def test_csr_compress_cols_limits():
     assert o3.tolist() == [0, 1, 1]
 
 
+def coo_c32_case(suf, r, c, v, xs_dev, x_lo, x_hi, y0_piece, y_lo, y_hi, want, lim, row_origin):
+    """The same product on 32-bit copies of the index fields (rows counted from row_origin)."""
+    n = v.size
+    rd, cd, vd = dev(r), dev(c), dev(v)
+    r32 = torch.empty(n, dtype=torch.int32, device="cuda")
+    c32 = torch.empty(n, dtype=torch.int32, device="cuda")
+    _lib.call("lsk_csr_compress_cols_u32", n, P(rd), row_origin, row_origin + 2**20, P(r32), stream())
+    _lib.call("lsk_csr_compress_cols_u32", n, P(cd), x_lo, x_hi, P(c32), stream())
+    yd = dev(y0_piece)
+    _lib.call(f"lsk_coo_spmv_c32_{suf}", n, P(r32), P(c32), P(vd), P(xs_dev), x_hi - x_lo + 1, P(yd),
+              y_lo - row_origin, y_hi - row_origin, stream())
+    err = np.abs(yd.cpu().numpy().astype(np.float64) - want)
+    assert np.all(err <= lim), ("32-bit index fields", float(err.max()), int(np.argmax(err - lim)))
+
+
 @pytest.fixture(params=[1, 0], ids=["wave-scan", "workgroup-chunks"])
 def coo_variant(request):
     """Both forms of the COO kernel (option coo.variant); the default is restored afterwards."""
@@ -367,6 +382,8 @@ def test_coo_spmv_run_shapes(suf, coo_variant):
             err = np.abs(yd.cpu().numpy().astype(np.float64) - want)
             lim = tol * (bound.astype(np.float64) + np.abs(want) + 1e-300)
             assert np.all(err <= lim), (nnz, shape, float(err.max()), int(np.argmax(err - lim)))
+            if coo_variant == 1:
+                coo_c32_case(suf, r, c, v, xd, 0, n_cols - 1, y0, 0, n_rows - 1, want, lim, 0)
 
 
 @pytest.mark.parametrize("suf", ["f32", "f64"])
@@ -393,6 +410,10 @@ def test_coo_spmv(suf, coo_variant):
                       P(yd), y_lo, y_hi, stream())
             err = np.abs(yd.cpu().numpy().astype(np.float64) - want)
             assert np.all(err <= tol * (bound + np.abs(want) + 1e-300)), (name, err.max())
+            if coo_variant == 1:  # rows counted from 0 and from a row inside the matrix
+                for origin in (0, min(y_lo, 5)):
+                    coo_c32_case(suf, r, c, v, xd, x_lo, x_hi, y0[y_lo:y_hi + 1], y_lo, y_hi, want,
+                                 tol * (bound + np.abs(want) + 1e-300), origin)
     # one row with many entries (runs longer than the on-chip cut) and duplicates
     r = np.full(5000, 3, dtype=np.int64)
     c = rng.integers(0, 10, 5000).astype(np.int64)

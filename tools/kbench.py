@@ -89,6 +89,22 @@ def coo_bench(args, ctx, lib, dtype, esz):
             med = statistics.median(times[v])
             print(f"  coo.variant={v}: median {med:.3f} ms  min {min(times[v]):.3f} ms  "
                   f"{algo / med / 1e6:.1f} GB/s  ({algo / med / 1e6 / 8000:.3f} of 8 TB/s)", flush=True)
+        # the wave-scan form on 32-bit copies of the index fields
+        lib.lsk_set_option(b"coo.variant", 1)
+        assert A.compress(0, n - 1, kp, part)
+        y.zero_fill()
+        spmv()
+        err = float((y.owned - ref).abs().max())
+        assert err <= (1e-12 if esz == 8 else 1e-4) * float(ref.abs().max()), err
+        t32 = []
+        for _ in range(args.rounds):
+            spmv()
+            t32.append(timed(spmv, args.reps))
+        algo32 = A.nnz * (8 + esz) + n * 3 * esz
+        med = statistics.median(t32)
+        print(f"  coo.variant=1 on 32-bit index fields: median {med:.3f} ms  min {min(t32):.3f} ms  "
+              f"{algo32 / med / 1e6:.1f} GB/s of its own {algo32} B  ({algo32 / med / 1e6 / 8000:.3f} of 8 TB/s)",
+              flush=True)
         del A, x, y
         torch.cuda.empty_cache()
     lib.lsk_set_option(b"coo.variant", 1)
