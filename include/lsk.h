@@ -220,6 +220,18 @@ int lsk_axpy_sqnorm_dev_f64(int64_t n, int nf, const double *f0, const double *f
                             const double *f3, const double *x, double *y, double *partials,
                             int64_t capacity, int *count, lsk_stream_t stream);
 
+/* Fused axpy and xpay over one read of p: z <- fma(alpha, p, z) and p <- fma(beta, p, r), both from
+ * the old p, alpha = get_alpha(a0..) and beta = get_alpha(b0..) evaluated on the device.  CG's
+ * x <- x + alpha p (src/CGSolver.hpp:48) deferred to its p <- r + beta p (:54), between which x and p
+ * are not touched; element for element the same operations as lsk_axpy_dev_* and lsk_xpay_dev_*.
+ * The three vectors must be distinct.  No counterpart in the reference. */
+int lsk_axpy_xpay_dev_f32(int64_t n, int nfa, const float *a0, const float *a1, const float *a2,
+                          const float *a3, int nfb, const float *b0, const float *b1, const float *b2,
+                          const float *b3, const float *r, float *p, float *z, lsk_stream_t stream);
+int lsk_axpy_xpay_dev_f64(int64_t n, int nfa, const double *a0, const double *a1, const double *a2,
+                          const double *a3, int nfb, const double *b0, const double *b1, const double *b2,
+                          const double *b3, const double *r, double *p, double *z, lsk_stream_t stream);
+
 /* *result_dev <- partials[0] + ... + partials[count-1], in an order fixed by `count` alone (so
  * bit-reproducible): the second stage of the fused forms (lsk_axpy_sqnorm_*, lsk_csr_spmv_dot_*).
  * Counts above 8192 take two kernel stages through `workspace` (lsk_dot_workspace_bytes(0)

@@ -90,6 +90,13 @@ class HipBackend:
                   _ptr(partials), partials.numel(), ctypes.byref(count), self.stream())
         return count.value
 
+    def axpy_xpay(self, z: torch.Tensor, futs_a, p: torch.Tensor, futs_b, r: torch.Tensor) -> None:
+        """z <- fma(alpha, p, z) and p <- fma(beta, p, r) from the old p, one pass."""
+        nfa, pa = self._futs(futs_a)
+        nfb, pb = self._futs(futs_b)
+        _lib.call(f"lsk_axpy_xpay_dev_{_lib.suffix(p.dtype)}", p.numel(), nfa, *pa, nfb, *pb, _ptr(r), _ptr(p),
+                  _ptr(z), self.stream())
+
     def csr_spmv_dot_slots(self, rows: int, nnz: int, dtype: torch.dtype) -> int:
         return int(self.lib.lsk_csr_spmv_dot_partials(rows, nnz, 4 if dtype == torch.float32 else 8))
 

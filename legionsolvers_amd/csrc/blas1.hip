@@ -381,6 +381,92 @@ int launch_axpy_sqnorm(const char *name, int64_t n, Alpha<T> a, const T *x, T *y
     return LSK_OK;
 }
 
+// Two updates that read the same vector in one pass: z <- fma(a, p, z) and p <- fma(b, p, r), both
+// from the OLD p (CG's x <- x + alpha p followed by p <- r + beta p, src/CGSolver.hpp:48,54, where the
+// first does not depend on anything computed in between).  5 instead of 6 vector passes.
+template <typename T, typename E, int EN>
+__global__ __launch_bounds__(kBlock) void axpy_xpay_kernel(int64_t n, Alpha<T> a, Alpha<T> b, const T *r, T *p,
+                                                           T *z, int form) {
+    const T alpha = resolve_alpha(a), beta = resolve_alpha(b);
+    const int64_t ne = n / EN;
+    const E *re = reinterpret_cast<const E *>(r);
+    E *pe = reinterpret_cast<E *>(p);
+    E *ze = reinterpret_cast<E *>(z);
+    const int64_t gstride = int64_t(gridDim.x) * kBlock;
+    const int64_t inner = form ? kBlock : gstride;
+    const int64_t outer = 4 * gstride;
+    int64_t i = form ? int64_t(blockIdx.x) * (4 * kBlock) + threadIdx.x
+                     : int64_t(blockIdx.x) * kBlock + threadIdx.x;
+    const bool first = (blockIdx.x == 0 && threadIdx.x == 0);
+    auto both = [&](const E &rv, const E &pv, const E &zv, E &p_out, E &z_out) {
+        if constexpr (EN == 1) {
+            z_out = apply<T, OP_AXPY>(alpha, pv, zv);
+            p_out = apply<T, OP_XPAY>(beta, rv, pv);
+        } else {
+            z_out = apply_v<T, OP_AXPY>(alpha, pv, zv);
+            p_out = apply_v<T, OP_XPAY>(beta, rv, pv);
+        }
+    };
+    for (; i + 3 * inner < ne; i += outer) {
+        E rv[4], pv[4], zv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            rv[u] = re[i + u * inner];
+            pv[u] = pe[i + u * inner];
+            zv[u] = ze[i + u * inner];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            E po, zo;
+            both(rv[u], pv[u], zv[u], po, zo);
+            ze[i + u * inner] = zo;
+            pe[i + u * inner] = po;
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int64_t j = i + u * inner;
+        if (j < ne) {
+            E po, zo;
+            both(re[j], pe[j], ze[j], po, zo);
+            ze[j] = zo;
+            pe[j] = po;
+        }
+    }
+    if (EN > 1 && first) {
+        for (int64_t j = ne * EN; j < n; ++j) {
+            const T pv = p[j];
+            z[j] = apply<T, OP_AXPY>(alpha, pv, z[j]);
+            p[j] = apply<T, OP_XPAY>(beta, r[j], pv);
+        }
+    }
+}
+
+template <typename T>
+int launch_axpy_xpay(const char *name, int64_t n, Alpha<T> a, Alpha<T> b, const T *r, T *p, T *z,
+                     lsk_stream_t stream) {
+    if (n < 0) return lsk::fail(LSK_ERR_ARG, "%s: negative length %lld", name, (long long)n);
+    if (n == 0) return LSK_OK;
+    if (!r || !p || !z) return lsk::fail(LSK_ERR_ARG, "%s: null vector", name);
+    if (r == p || p == z || r == z) return lsk::fail(LSK_ERR_ARG, "%s: the three vectors must differ", name);
+    for (const Alpha<T> *c : {&a, &b}) {
+        if (c->nf > 4) return lsk::fail(LSK_ERR_ARG, "%s: %d futures (0..4 allowed)", name, c->nf);
+        const T *fs[4] = {c->f0, c->f1, c->f2, c->f3};
+        for (int i = 0; i < c->nf; ++i)
+            if (!fs[i]) return lsk::fail(LSK_ERR_ARG, "%s: future %d is null", name, i);
+    }
+    using V = typename Vec<T>::type;
+    constexpr int VN = Vec<T>::N;
+    const bool vec = lsk::aligned16(r) && lsk::aligned16(p) && lsk::aligned16(z);
+    const int blocks = vec ? stream_grid(n / VN + 1) : stream_grid(n);
+    hipStream_t s = lsk::as_stream(stream);
+    const int form = lsk::options().blas1_form;
+    if (vec) axpy_xpay_kernel<T, V, VN><<<blocks, kBlock, 0, s>>>(n, a, b, r, p, z, form);
+    else axpy_xpay_kernel<T, T, 1><<<blocks, kBlock, 0, s>>>(n, a, b, r, p, z, form);
+    LSK_LAUNCH_CHECK();
+    return LSK_OK;
+}
+
 // First stage of a long sum: block b adds the partials b*per .. (b+1)*per-1 left to right per
 // thread, then across the block in block_sum's fixed order.
 template <typename T>
@@ -625,6 +711,12 @@ size_t lsk_dot_workspace_bytes(int64_t n) {
         return launch_axpy_sqnorm<T>("lsk_axpy_sqnorm_dev_" #SUFFIX, n,                           \
                                      dev_alpha<T>(nf, f0, f1, f2, f3), x, y, partials, capacity,  \
                                      count, s);                                                   \
+    }                                                                                             \
+    int lsk_axpy_xpay_dev_##SUFFIX(int64_t n, int nfa, const T *a0, const T *a1, const T *a2, const T *a3, \
+                                   int nfb, const T *b0, const T *b1, const T *b2, const T *b3,   \
+                                   const T *r, T *p, T *z, lsk_stream_t s) {                      \
+        return launch_axpy_xpay<T>("lsk_axpy_xpay_dev_" #SUFFIX, n, dev_alpha<T>(nfa, a0, a1, a2, a3), \
+                                   dev_alpha<T>(nfb, b0, b1, b2, b3), r, p, z, s);                \
     }                                                                                             \
     int lsk_sum_partials_##SUFFIX(int64_t count, const T *partials, T *result, void *ws,          \
                                   size_t wsb, lsk_stream_t s) {                                   \

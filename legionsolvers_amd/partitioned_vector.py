@@ -18,7 +18,29 @@ from .index_space import IndexPartition
 from .scalar import Scalar
 
 
+class _DeferredAxpy:
+    """z <- fma(alpha, p, z) that has been asked for but not launched yet (see
+    PartitionedVector.axpy(defer=True)); referenced from both vectors until it runs."""
+
+    def __init__(self, z: "PartitionedVector", p: "PartitionedVector", scalars, on_outcome=None):
+        self.z, self.p, self.scalars, self.on_outcome = z, p, scalars, on_outcome
+
+    def detach(self, fused: bool) -> None:
+        self.z._deferred = self.p._deferred = None
+        if self.on_outcome is not None:
+            self.on_outcome(fused)
+
+    def run(self) -> None:
+        """Launch it on its own, as if it had never been held back."""
+        self.detach(False)
+        self.z.axpy(*self.scalars, self.p)
+
+
 class PartitionedVector:
+    """Views of the storage (`data`, `owned`, `piece(i)`) are to be fetched again after an operation
+    on the vector rather than kept across it, as a Legion accessor is valid for one mapping only:
+    reading them is what makes an update that is being held back (axpy(defer=True)) happen."""
+
     def __init__(self, ctx, name: str, index_partition: IndexPartition,
                  dtype: torch.dtype = torch.float64, pad: Tuple[int, int] = (0, 0)):
         if dtype not in (torch.float32, torch.float64):
@@ -45,14 +67,34 @@ class PartitionedVector:
             if self.pad_lo or self.pad_hi:
                 raise ValueError("halo padding exists for 1-D vectors only")
             self.own_lo, self.own_hi = 0, -1
-        self.data = ctx.backend.empty(self.pad_lo + self.local_size + self.pad_hi, dtype)
-        self.owned = self.data[self.pad_lo:self.pad_lo + self.local_size]
+        self._data = ctx.backend.empty(self.pad_lo + self.local_size + self.pad_hi, dtype)
+        self._owned = self._data[self.pad_lo:self.pad_lo + self.local_size]
+        self._deferred = None  # a _DeferredAxpy this vector takes part in
         # Bookkeeping of the fused leaf forms: `version` counts the writes made through this
         # object's methods; `_ready` describes partial sums of a dot product of this vector's
         # CURRENT contents with `partner` (possibly itself) that a fused kernel left behind.
         self.version = 0
         self._ready = None
         self._partial_bufs = {}
+
+    # -- storage ---------------------------------------------------------------------------
+    def _settle(self) -> None:
+        """Run an update that was being held back, before anyone looks at or writes the storage."""
+        d = self._deferred
+        if d is not None:
+            d.run()
+
+    @property
+    def data(self) -> torch.Tensor:
+        """The whole buffer, halo room included."""
+        self._settle()
+        return self._data
+
+    @property
+    def owned(self) -> torch.Tensor:
+        """This rank's elements, pieces in colour order."""
+        self._settle()
+        return self._owned
 
     # -- accessors (src/PartitionedVector.hpp:52-72) ------------------------------------
     def get_name(self) -> str:
@@ -144,16 +186,26 @@ class PartitionedVector:
             if self.piece_sizes[i]:
                 self.ctx.backend.scal(self.piece(i), futs)
 
-    def axpy(self, *args, speculate: bool = False) -> None:
+    def axpy(self, *args, speculate: bool = False, defer: bool = False, on_outcome=None) -> None:
         """axpy(alpha, x) | axpy(numer, denom, x) | axpy(numer1, numer2, denom, x):
         self <- fma(get_alpha(scalars), x, self).
 
         speculate: use the fused axpy + squared-norm leaf, so that a dot(self, self) that
-        follows before the next write only has to add up the partial sums."""
+        follows before the next write only has to add up the partial sums.
+        defer: hold the update back until either vector's storage is next looked at.  If the
+        next thing to happen to x is x.xpay(beta, r) (CG: x_sol += alpha p, then p <- r + beta p),
+        both run as one pass over x; anything else makes the update run first, on its own.
+        Results are the same either way.  on_outcome(fused) is told which of the two happened."""
         *scalars, x = args
         if not 1 <= len(scalars) <= 3:
             raise TypeError("axpy takes 1 to 3 scalars and a vector")
         self._check_same_shape(x)
+        if defer and x is not self and getattr(self.ctx.backend, "axpy_xpay", None) is not None:
+            self._scalars(scalars)  # type checks now, not when it runs
+            self._settle()
+            x._settle()
+            self._deferred = x._deferred = _DeferredAxpy(self, x, list(scalars), on_outcome)
+            return
         futs = self._scalars(scalars)
         be = self.ctx.backend
         fused = speculate and x is not self and getattr(be, "axpy_sqnorm", None) is not None
@@ -177,6 +229,18 @@ class PartitionedVector:
             raise TypeError("xpay takes 1 or 2 scalars and a vector")
         self._check_same_shape(x)
         futs = self._scalars(scalars)
+        d = self._deferred
+        if d is not None and d.p is self and x is not d.z and x is not self and x._deferred is None:
+            # z <- fma(alpha, self, z) was held back: one pass over self serves both updates
+            d.detach(True)
+            z = d.z
+            futs_a = z._scalars(d.scalars)
+            self._touch()
+            z._touch()
+            for i in range(len(self.piece_sizes)):
+                if self.piece_sizes[i]:
+                    self.ctx.backend.axpy_xpay(z.piece(i), futs_a, self.piece(i), futs, x.piece(i))
+            return
         self._touch()
         for i in range(len(self.piece_sizes)):
             if self.piece_sizes[i]:

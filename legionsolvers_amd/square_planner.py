@@ -55,6 +55,9 @@ class SquarePlanner:
         self._fused_dot_issued = 0
         self._fused_dot_used = 0
         self._fused_dot_pending = None
+        # bets of the held-back solution update (see axpy)
+        self._deferred_issued = 0
+        self._deferred_fused = 0
 
     def get_context(self):
         return self.ctx
@@ -182,8 +185,19 @@ class SquarePlanner:
         # Workspace vectors are only ever written through the planner, so the fused
         # axpy + squared norm can serve a dot(dst, dst) that follows (CG: r.r after r -= a q).
         speculate = self.ctx.fuse and dst_index >= 2
+        # An update of the solution by a workspace vector is held back: if that vector's own
+        # update comes next (CG: x += alpha p ... p <- r + beta p) both share one pass over it.
+        # A bet like the fused product + dot: kept up only while at least half of them are won
+        # (GMRES and BiCGStab lose every one).
+        defer = (self.ctx.fuse and dst_index == 0 and src_index >= 2
+                 and (self._deferred_issued < 4 or 2 * self._deferred_fused >= self._deferred_issued))
         for i in range(self.get_num_spaces()):
-            self.get_vector(dst_index, i).axpy(*scalars, self.get_vector(src_index, i), speculate=speculate)
+            self.get_vector(dst_index, i).axpy(*scalars, self.get_vector(src_index, i), speculate=speculate,
+                                               defer=defer, on_outcome=self._deferred_outcome if defer else None)
+
+    def _deferred_outcome(self, fused: bool) -> None:
+        self._deferred_issued += 1
+        self._deferred_fused += 1 if fused else 0
 
     def xpay(self, dst_index: int, *args) -> None:
         """xpay(dst, alpha, src) | xpay(dst, numer, denom, src)."""

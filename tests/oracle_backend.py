@@ -64,6 +64,10 @@ class OracleBackend:
         partials[0] = float(oracle.dot(_np(y), _np(y)))
         return 1
 
+    def axpy_xpay(self, z, futs_a, p, futs_b, r):
+        self.axpy(z, futs_a, p)   # z from the old p ...
+        self.xpay(p, futs_b, r)   # ... then p
+
     def csr_spmv_dot_slots(self, rows, nnz, dtype):
         return 1
 

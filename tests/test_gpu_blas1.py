@@ -334,3 +334,35 @@ def test_sum_partials_two_stage(suf):
         out2 = torch.full((1,), -1.0, dtype=tdt, device="cuda")
         _lib.call(f"lsk_sum_partials_{suf}", count, P(vd), P(out2), None, 0, stream())
         assert float(out2) == float(out)
+
+
+@pytest.mark.parametrize("suf", ["f32", "f64"])
+@pytest.mark.parametrize("offset", [0, 1])
+def test_axpy_xpay_fused(suf, offset):
+    """z <- fma(a, p, z); p <- fma(b, p, r) in one pass: both bit-exact with the oracle's axpy
+    followed by its xpay (alpha from 2 futures, beta from 2 futures, as CG passes them)."""
+    npdt, tdt = DT[suf]
+    rng = np.random.default_rng(19)
+    for n in SIZES + [(1 << 22) + 11]:
+        r = rng.standard_normal(n + offset).astype(npdt)
+        p = rng.standard_normal(n + offset).astype(npdt)
+        z = rng.standard_normal(n + offset).astype(npdt)
+        fa = rng.standard_normal(2).astype(npdt)
+        fb = rng.standard_normal(2).astype(npdt)
+        print(f"case axpy_xpay_{suf} n={n} offset={offset}", flush=True)
+        alpha = oracle.get_alpha([fa[0], fa[1]], npdt)
+        beta = oracle.get_alpha([fb[0], fb[1]], npdt)
+        want_z, want_p = z.copy(), p.copy()
+        oracle.axpy(alpha, np.ascontiguousarray(p[offset:]), want_z[offset:])
+        oracle.xpay(beta, np.ascontiguousarray(r[offset:]), want_p[offset:])
+        rd, pd, zd, fad, fbd = dev(r), dev(p), dev(z), dev(fa), dev(fb)
+        _lib.call(f"lsk_axpy_xpay_dev_{suf}", n, 2, P(fad[0:1]), P(fad[1:2]), None, None,
+                  2, P(fbd[0:1]), P(fbd[1:2]), None, None, P(rd[offset:]), P(pd[offset:]), P(zd[offset:]), stream())
+        assert np.array_equal(bits(zd.cpu().numpy()), bits(want_z)), n
+        assert np.array_equal(bits(pd.cpu().numpy()), bits(want_p)), n
+        assert np.array_equal(bits(rd.cpu().numpy()), bits(r)), n
+    v = dev(np.ones(8, npdt))
+    one = dev(np.ones(1, npdt))
+    rc = getattr(_lib.lib(), f"lsk_axpy_xpay_dev_{suf}")(8, 1, P(one), None, None, None, 1, P(one), None, None, None,
+                                                         P(v), P(v), P(dev(np.ones(8, npdt))), stream())
+    assert rc == -2  # the three vectors must differ
