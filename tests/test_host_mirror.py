@@ -308,3 +308,46 @@ def test_planner_compresses_the_structure_and_falls_back(monkeypatch):
     mpl = hc.mirror_planner(ctx, "csr", gapped, row, col, val, n, 2, np.float64)
     matrix = mpl.row_partitioned_matrices[0].matrix
     assert matrix.col32 is None and not matrix.rowoff
+
+
+def test_held_back_axpy_is_invisible_to_readers():
+    """axpy(defer=True) on the oracle backend: reading either vector makes the update happen
+    first; a following xpay on the source fuses with it when nothing looked in between; both
+    ways give the values of the plain sequence."""
+    from legionsolvers_amd import Scalar
+    ctx = Context(backend=OracleBackend())
+    part = IndexPartition.equal(IndexSpace(0, 99), 3)
+    rng = np.random.default_rng(5)
+    init = {k: torch.from_numpy(rng.standard_normal(100)) for k in "zpr"}
+    a, b = Scalar(ctx, 0.75, torch.float64), Scalar(ctx, -1.25, torch.float64)
+
+    def fresh():
+        out = {}
+        for k in "zpr":
+            v = PartitionedVector(ctx, k, part, torch.float64)
+            v.owned.copy_(init[k])
+            out[k] = v
+        return out
+
+    plain = fresh()
+    plain["z"].axpy(a, plain["p"])
+    plain["p"].xpay(b, plain["r"])
+    outcomes = []
+    fused = fresh()
+    fused["z"].axpy(a, fused["p"], defer=True, on_outcome=outcomes.append)
+    assert fused["z"]._deferred is not None and fused["p"]._deferred is fused["z"]._deferred
+    fused["p"].xpay(b, fused["r"])
+    assert outcomes == [True] and fused["z"]._deferred is None
+    peeked = fresh()
+    peeked["z"].axpy(a, peeked["p"], defer=True, on_outcome=outcomes.append)
+    seen = peeked["z"].to_host().clone()          # a reader in between: the update runs now
+    assert outcomes == [True, False] and torch.equal(seen, plain["z"].to_host())
+    peeked["p"].xpay(b, peeked["r"])
+    for k in "zpr":
+        assert torch.equal(fused[k].to_host(), plain[k].to_host())
+        assert torch.equal(peeked[k].to_host(), plain[k].to_host())
+    # writing the source first also settles the update before the write
+    w = fresh()
+    w["z"].axpy(a, w["p"], defer=True)
+    w["p"].scal(b)
+    assert torch.equal(w["z"].to_host(), plain["z"].to_host())
