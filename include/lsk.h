@@ -386,6 +386,20 @@ int lsk_coo_spmv_c32_f64(int64_t nnz, const uint32_t *row32, const uint32_t *col
                          const double *x, int64_t x_extent, double *y, int64_t y_first, int64_t y_last,
                          lsk_stream_t stream);
 
+/* Column-blocked entry order for matrices whose x gathers have no locality (unstructured COO):
+ * order[i] = the entry that comes i-th when the entries are sorted by column block
+ * col32 / block_cols (stable: inside a block they keep their order, e.g. rows ascending).  With
+ * the fields gathered through `order` (lsk_gather_*: dst[i] = src[order[i]]) every run of entries
+ * reads one block of x, which stays in L2 when block_cols * sizeof(T) is a few MiB; the product
+ * kernel and its results (up to the order of the atomic additions) are unchanged.  nnz < 2^31.
+ * Set-up time: allocates and frees its scratch, returns when done.  No counterpart in the
+ * reference. */
+int lsk_coo_block_order_u32(int64_t nnz, const uint32_t *col32, int64_t x_extent, int64_t block_cols,
+                            uint32_t *order, lsk_stream_t stream);
+int lsk_gather_u32(int64_t n, const uint32_t *src, const uint32_t *order, uint32_t *dst, lsk_stream_t stream);
+int lsk_gather_f32(int64_t n, const float *src, const uint32_t *order, float *dst, lsk_stream_t stream);
+int lsk_gather_f64(int64_t n, const double *src, const uint32_t *order, double *dst, lsk_stream_t stream);
+
 /* ------------------------------------------------ set-up helpers (device side) ------ */
 /* out[0] = min idx[i], out[1] = max idx[i] (out = {INT64_MAX, INT64_MIN} when n == 0):
  * the bounding interval of create_partition_by_image over a column field

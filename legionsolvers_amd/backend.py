@@ -185,6 +185,24 @@ class HipBackend:
         _lib.call("lsk_csr_compress_cols_u32", col.numel(), _ptr(col), x_lo, x_hi, _ptr(out), self.stream())
         return out
 
+    def coo_block_order(self, col32: torch.Tensor, x_extent: int, block_cols: int):
+        """Entry order sorted (stably) by column block of `block_cols` columns, as uint32 positions
+        in an int32 tensor; None when there are too many entries for it.  Synchronises."""
+        order = torch.empty(col32.numel(), dtype=torch.int32, device=self.device)
+        code = self.lib.lsk_coo_block_order_u32(col32.numel(), _ptr(col32), x_extent, block_cols, _ptr(order),
+                                                self.stream())
+        if code == _lib.LSK_ERR_UNSUPPORTED:
+            return None
+        _lib.check(code)
+        return order
+
+    def gather(self, src: torch.Tensor, order: torch.Tensor) -> torch.Tensor:
+        """src[order] for the 32-bit index fields and the entry values."""
+        kind = "u32" if src.dtype == torch.int32 else _lib.suffix(src.dtype)
+        dst = torch.empty_like(src)
+        _lib.call(f"lsk_gather_{kind}", src.numel(), _ptr(src), _ptr(order), _ptr(dst), self.stream())
+        return dst
+
     def csr_compress_rows(self, rects: torch.Tensor, k_base: int, nnz: int):
         """rows + 1 32-bit offsets into the piece's col/val arrays (the classic row pointer; bit
         pattern of uint32 in an int32 tensor), or None when the rects are not back to back inside

@@ -4,6 +4,7 @@
 // column field.  Integer work only; results are bit-identical to the reference's serial
 // per-piece walk, which starts from the grid origin for every piece and dominates set-up
 // time at 512^3 -- here every row is generated independently.
+#include <algorithm>
 #include <climits>
 
 #include <hipcub/hipcub.hpp>
@@ -236,6 +237,41 @@ __global__ __launch_bounds__(kBlock) void halo_rows_kernel(long long rows, long 
     }
 }
 
+// Column-block id of every entry (col32 / block_cols; the "outside the window" marker goes to the
+// last block) and its position, as the key / value pairs of the stable sort below.
+__global__ __launch_bounds__(kBlock) void block_keys_kernel(int64_t nnz, const uint32_t *__restrict__ col32,
+                                                            uint32_t block_cols, uint32_t last_block,
+                                                            uint32_t *__restrict__ keys,
+                                                            uint32_t *__restrict__ pos) {
+    const int64_t stride = int64_t(gridDim.x) * kBlock;
+    for (int64_t k = int64_t(blockIdx.x) * kBlock + threadIdx.x; k < nnz; k += stride) {
+        const uint32_t c = col32[k];
+        keys[k] = c == 0xffffffffu ? last_block : c / block_cols;
+        pos[k] = static_cast<uint32_t>(k);
+    }
+}
+
+template <typename E>
+__global__ __launch_bounds__(kBlock) void gather_kernel(int64_t n, const E *__restrict__ src,
+                                                        const uint32_t *__restrict__ order, E *__restrict__ dst) {
+    const int64_t stride = int64_t(gridDim.x) * kBlock;
+    for (int64_t k = int64_t(blockIdx.x) * kBlock + threadIdx.x; k < n; k += stride) dst[k] = src[order[k]];
+}
+
+template <typename E>
+int launch_gather(const char *name, int64_t n, const E *src, const uint32_t *order, E *dst, lsk_stream_t stream) {
+    if (n < 0) return lsk::fail(LSK_ERR_ARG, "%s: negative length", name);
+    if (n == 0) return LSK_OK;
+    if (!src || !order || !dst) return lsk::fail(LSK_ERR_ARG, "%s: null pointer", name);
+    if (static_cast<const void *>(src) == static_cast<const void *>(dst))
+        return lsk::fail(LSK_ERR_ARG, "%s: cannot permute in place", name);
+    int blocks = grid_for(n);
+    if (blocks > 16 * lsk::kMaxGridBlocks) blocks = 16 * lsk::kMaxGridBlocks;
+    gather_kernel<E><<<blocks, kBlock, 0, lsk::as_stream(stream)>>>(n, src, order, dst);
+    LSK_LAUNCH_CHECK();
+    return LSK_OK;
+}
+
 } // namespace
 
 extern "C" {
@@ -306,6 +342,68 @@ int lsk_stencil_fill_coo_f64(int dim, const int64_t *extent, int noffsets, const
                              double *val, lsk_stream_t stream) {
     return launch_fill<double, true>("lsk_stencil_fill_coo_f64", dim, extent, noffsets, offsets,
                                      coeffs, row_lo, row_hi, rects, k_base, row, col, val, stream);
+}
+
+int lsk_coo_block_order_u32(int64_t nnz, const uint32_t *col32, int64_t x_extent, int64_t block_cols,
+                            uint32_t *order, lsk_stream_t stream) {
+    if (nnz < 0 || x_extent < 0) return lsk::fail(LSK_ERR_ARG, "lsk_coo_block_order_u32: negative size");
+    if (nnz == 0) return LSK_OK;
+    if (!col32 || !order) return lsk::fail(LSK_ERR_ARG, "lsk_coo_block_order_u32: null pointer");
+    if (block_cols < 1 || block_cols > 0xffffffffLL || x_extent > 0xffffffffLL)
+        return lsk::fail(LSK_ERR_ARG, "lsk_coo_block_order_u32: block of %lld columns, window of %lld",
+                         (long long)block_cols, (long long)x_extent);
+    if (nnz > 0x7fffffffLL)
+        return lsk::decline(LSK_ERR_UNSUPPORTED, "lsk_coo_block_order_u32: more than 2^31 - 1 entries");
+    hipStream_t s = lsk::as_stream(stream);
+    const uint32_t last_block = static_cast<uint32_t>(lsk::ceil_div(std::max<int64_t>(x_extent, 1), block_cols));
+    int bits = 1;
+    while ((1u << bits) <= last_block && bits < 32) ++bits;
+    uint32_t *keys = nullptr, *keys_out = nullptr, *pos = nullptr;
+    void *temp = nullptr;
+    size_t temp_bytes = 0;
+    int status = LSK_OK;
+    auto release = [&] {
+        (void)hipFree(keys);
+        (void)hipFree(keys_out);
+        (void)hipFree(pos);
+        (void)hipFree(temp);
+    };
+#define LSK_TRY(expr)                                                                               \
+    do {                                                                                            \
+        const hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess && status == LSK_OK) status = lsk::hip_fail(e_, #expr, __FILE__, __LINE__); \
+    } while (0)
+    const size_t bytes = static_cast<size_t>(nnz) * sizeof(uint32_t);
+    LSK_TRY(hipMalloc(reinterpret_cast<void **>(&keys), bytes));
+    LSK_TRY(hipMalloc(reinterpret_cast<void **>(&keys_out), bytes));
+    LSK_TRY(hipMalloc(reinterpret_cast<void **>(&pos), bytes));
+    if (status == LSK_OK) {
+        int blocks = grid_for(nnz);
+        if (blocks > 16 * lsk::kMaxGridBlocks) blocks = 16 * lsk::kMaxGridBlocks;
+        block_keys_kernel<<<blocks, kBlock, 0, s>>>(nnz, col32, static_cast<uint32_t>(block_cols), last_block, keys, pos);
+        LSK_TRY(hipGetLastError());
+        // radix sort is stable: inside a block the entries keep their order (rows ascending)
+        LSK_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, temp_bytes, keys, keys_out, pos, order,
+                                                   static_cast<int>(nnz), 0, bits, s));
+        LSK_TRY(hipMalloc(&temp, temp_bytes ? temp_bytes : 1));
+        if (status == LSK_OK)
+            LSK_TRY(hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys, keys_out, pos, order,
+                                                       static_cast<int>(nnz), 0, bits, s));
+        LSK_TRY(hipStreamSynchronize(s)); // set-up time: the scratch is freed before returning
+    }
+#undef LSK_TRY
+    release();
+    return status;
+}
+
+int lsk_gather_u32(int64_t n, const uint32_t *src, const uint32_t *order, uint32_t *dst, lsk_stream_t stream) {
+    return launch_gather<uint32_t>("lsk_gather_u32", n, src, order, dst, stream);
+}
+int lsk_gather_f32(int64_t n, const float *src, const uint32_t *order, float *dst, lsk_stream_t stream) {
+    return launch_gather<float>("lsk_gather_f32", n, src, order, dst, stream);
+}
+int lsk_gather_f64(int64_t n, const double *src, const uint32_t *order, double *dst, lsk_stream_t stream) {
+    return launch_gather<double>("lsk_gather_f64", n, src, order, dst, stream);
 }
 
 int lsk_inclusive_sum_i64(int64_t n, const int64_t *in, int64_t *out, lsk_stream_t stream) {

@@ -565,6 +565,50 @@ def test_rects_to_indptr_bit_exact():
         assert np.array_equal(out.cpu().numpy(), oracle.rects_to_indptr(piece))
 
 
+def test_coo_block_order_and_gather():
+    """The stable sort by column block and the gathers, against numpy; then the product on the
+    re-ordered fields equals the product on the row-ordered ones up to the order of additions."""
+    rng = np.random.default_rng(81)
+    for n, extent, block in ((1, 10, 4), (1000, 77, 8), (300_000, 1 << 20, 1 << 12), (70_000, 5000, 5000), (4097, 3, 1)):
+        print(f"case coo_block_order n={n} extent={extent} block={block}", flush=True)
+        c = rng.integers(0, extent, size=n).astype(np.uint32)
+        c[rng.integers(0, n, size=max(n // 50, 1))] = 0xFFFFFFFF  # columns outside the window
+        cd = dev(c.view(np.int32))
+        order = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+        _lib.call("lsk_coo_block_order_u32", n, P(cd), extent, block, P(order), stream())
+        last = -(-extent // block)
+        keys = np.where(c == 0xFFFFFFFF, last, c // block)
+        want = np.argsort(keys, kind="stable")
+        got = order.cpu().numpy().view(np.uint32)
+        assert np.array_equal(got, want.astype(np.uint32))
+        for arr, name in ((c.view(np.int32), "lsk_gather_u32"), (rng.standard_normal(n).astype(np.float32), "lsk_gather_f32"),
+                          (rng.standard_normal(n), "lsk_gather_f64")):
+            src = dev(arr)
+            dst = torch.empty_like(src)
+            _lib.call(name, n, P(src), P(order), P(dst), stream())
+            assert np.array_equal(dst.cpu().numpy(), arr[want])
+    # product on re-ordered fields
+    n_rows, n_cols, nnz = 5000, 40_000, 200_000
+    r = np.sort(rng.integers(0, n_rows, size=nnz)).astype(np.uint32)
+    c = rng.integers(0, n_cols, size=nnz).astype(np.uint32)
+    v = rng.standard_normal(nnz)
+    x = rng.standard_normal(n_cols)
+    rd, cd, vd, xd = dev(r.view(np.int32)), dev(c.view(np.int32)), dev(v), dev(x)
+    y0 = torch.zeros(n_rows, dtype=torch.float64, device="cuda")
+    _lib.call("lsk_coo_spmv_c32_f64", nnz, P(rd), P(cd), P(vd), P(xd), n_cols, P(y0), 0, n_rows - 1, stream())
+    order = torch.empty(nnz, dtype=torch.int32, device="cuda")
+    _lib.call("lsk_coo_block_order_u32", nnz, P(cd), n_cols, 4096, P(order), stream())
+    rb, cb, vb = torch.empty_like(rd), torch.empty_like(cd), torch.empty_like(vd)
+    _lib.call("lsk_gather_u32", nnz, P(rd), P(order), P(rb), stream())
+    _lib.call("lsk_gather_u32", nnz, P(cd), P(order), P(cb), stream())
+    _lib.call("lsk_gather_f64", nnz, P(vd), P(order), P(vb), stream())
+    y1 = torch.zeros(n_rows, dtype=torch.float64, device="cuda")
+    _lib.call("lsk_coo_spmv_c32_f64", nnz, P(rb), P(cb), P(vb), P(xd), n_cols, P(y1), 0, n_rows - 1, stream())
+    bound = np.zeros(n_rows)
+    np.add.at(bound, r.astype(np.int64), np.abs(v * x[c.astype(np.int64)]))
+    assert np.all(np.abs((y1 - y0).cpu().numpy()) <= 1e-13 * (bound + 1e-300))
+
+
 def test_inclusive_sum_bit_exact():
     rng = np.random.default_rng(71)
     for n in (1, 2, 255, 256, 257, 100_003, 3_000_000):
