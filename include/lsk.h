@@ -319,10 +319,11 @@ int lsk_csr_spmv_tune_f64(int64_t rows, int64_t nnz, const int64_t *rects, int64
  * aborts, whatever lsk_set_abort_on_error says).
  * lsk_csr_spmv_c32_* is lsk_csr_spmv_* on those arrays: `x` points at the window's first
  * element, `x_extent` = x_hi - x_lo + 1 of the compression; a run of rows [a, b) of the piece is
- * multiplied by passing rowoff32 + a, rows = b - a and the same col32 / val.  It reads 4 bytes of
- * column and 4 of row structure instead of 8 and 16; tiles and the order of additions are the
- * same, so y is bit-identical to lsk_csr_spmv_*.  _dot_ and _tune_ as the 64-bit entry points
- * of those names. */
+ * multiplied by passing rowoff32 + a, rows = b - a, the same col32 / val, and as nnz the number of
+ * entries of those rows (rowoff32[b] - rowoff32[a]; it only sizes the tiles, by nnz / rows).
+ * It reads 4 bytes of column and 4 of row structure instead of 8 and 16; tiles and the order of
+ * additions are the same, so y is bit-identical to lsk_csr_spmv_*.  _dot_ and _tune_ as the
+ * 64-bit entry points of those names. */
 int lsk_csr_compress_cols_u32(int64_t nnz, const int64_t *col, int64_t x_lo, int64_t x_hi,
                               uint32_t *col32, lsk_stream_t stream);
 int lsk_csr_compress_rows_u32(int64_t rows, int64_t nnz, const int64_t *rects, int64_t k_base,

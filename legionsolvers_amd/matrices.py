@@ -312,7 +312,8 @@ class CSRMatrix(AbstractMatrix):
                         off, n_arr = (k_lo - self.k_base) if nnz else 0, nnz
                     else:
                         off, n_arr = (ka - self.k_base) if n_run else 0, n_run
-                    be.csr_spmv(rb - ra, n_arr, rowf, ka if n_run else self.k_base,
+                    # (nnz = the entries of THESE rows: the kernel sizes its tiles by nnz / rows)
+                    be.csr_spmv(rb - ra, n_run, rowf, ka if n_run else self.k_base,
                                 col[off:off + n_arr], self.val[off:off + n_arr], x, x_lo, x_hi,
                                 dst.piece(i)[ra:rb], beta, self.placement.get(c, 0))
                 continue
