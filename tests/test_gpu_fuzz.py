@@ -105,6 +105,21 @@ def test_spmv_random_structures(gpu_ctx, suf, kind):
         yh = yd.cpu().numpy().astype(np.float64)
         assert np.all(np.abs(yh - want.astype(np.float64)) <= lim)
         assert abs(float(out) - float(np.sum(yh * w))) <= (1e-12 if suf == "f64" else 1e-5) * float(np.sum(np.abs(yh * w))) + 1e-300
+        # the same piece on the set-up-time 32-bit structure: bit-identical y and partial sums
+        got64, part64 = yd.clone(), partials.clone()
+        c32 = torch.empty(nnz, dtype=torch.int32, device="cuda")
+        off32 = torch.empty(rows + 1, dtype=torch.int32, device="cuda")
+        _lib.call("lsk_csr_compress_cols_u32", nnz, P(cd), x_lo, x_hi, P(c32), stream())
+        _lib.call("lsk_csr_compress_rows_u32", rows, nnz, P(rd), k_base, P(off32), stream())
+        yd = dev(y0)
+        _lib.call(f"lsk_csr_spmv_c32_{suf}", rows, nnz, P(off32), P(c32), P(vd), P(xd), x_hi - x_lo + 1, P(yd),
+                  beta, stream())
+        assert torch.equal(yd, got64), "32-bit structure changes the product"
+        yd = dev(y0)
+        partials.zero_()
+        _lib.call(f"lsk_csr_spmv_c32_dot_{suf}", rows, nnz, P(off32), P(c32), P(vd), P(xd), x_hi - x_lo + 1, P(yd),
+                  beta, P(wd), P(partials), slots, ctypes.byref(count), stream())
+        assert torch.equal(yd, got64) and torch.equal(partials, part64)
         # the same entries as COO (row-sorted, then shuffled), accumulating into y0
         live = lens.sum()
         if live:
@@ -123,4 +138,16 @@ def test_spmv_random_structures(gpu_ctx, suf, kind):
                     torch.cuda.synchronize()
                     err = np.abs(yd.cpu().numpy().astype(np.float64) - want_c.astype(np.float64))
                     assert np.all(err <= lim * 4), ("coo", variant, float(err.max()))
+                _lib.call("lsk_set_option", b"coo.variant", 1)
+                # 32-bit index fields, rows counted from a random origin at or below row 0's id
+                r32 = torch.empty(int(live), dtype=torch.int32, device="cuda")
+                c32c = torch.empty(int(live), dtype=torch.int32, device="cuda")
+                _lib.call("lsk_csr_compress_cols_u32", int(live), P(rcd), 0, rows - 1, P(r32), stream())
+                _lib.call("lsk_csr_compress_cols_u32", int(live), P(ccd), x_lo, x_hi, P(c32c), stream())
+                yd = dev(y0)
+                _lib.call(f"lsk_coo_spmv_c32_{suf}", int(live), P(r32), P(c32c), P(vcd), P(xd), x_hi - x_lo + 1,
+                          P(yd), 0, rows - 1, stream())
+                torch.cuda.synchronize()
+                err = np.abs(yd.cpu().numpy().astype(np.float64) - want_c.astype(np.float64))
+                assert np.all(err <= lim * 4), ("coo 32-bit", float(err.max()))
             _lib.call("lsk_set_option", b"coo.variant", 1)
