@@ -220,6 +220,18 @@ int lsk_axpy_sqnorm_dev_f64(int64_t n, int nf, const double *f0, const double *f
                             const double *f3, const double *x, double *y, double *partials,
                             int64_t capacity, int *count, lsk_stream_t stream);
 
+/* Fused axpy and dot with a third vector: y <- fma(alpha, x, y) as lsk_axpy_dev_*, and
+ * partials[0 .. *count) <- per-workgroup shares of sum_i y_new[i] * w[i] (w == y gives
+ * lsk_axpy_sqnorm_dev_*; w may be x).  GMRES's modified Gram-Schmidt sweep w' <- w' - h_k v_k followed
+ * by h_{k+1} = v_{k+1}.w' (src/GMRESSolver.hpp:92-100) in 4 vector passes instead of 5.  No
+ * counterpart in the reference. */
+int lsk_axpy_dot_dev_f32(int64_t n, int nf, const float *f0, const float *f1, const float *f2,
+                         const float *f3, const float *x, float *y, const float *w, float *partials,
+                         int64_t capacity, int *count, lsk_stream_t stream);
+int lsk_axpy_dot_dev_f64(int64_t n, int nf, const double *f0, const double *f1, const double *f2,
+                         const double *f3, const double *x, double *y, const double *w, double *partials,
+                         int64_t capacity, int *count, lsk_stream_t stream);
+
 /* Fused axpy and xpay over one read of p: z <- fma(alpha, p, z) and p <- fma(beta, p, r), both from
  * the old p, alpha = get_alpha(a0..) and beta = get_alpha(b0..) evaluated on the device.  CG's
  * x <- x + alpha p (src/CGSolver.hpp:48) deferred to its p <- r + beta p (:54), between which x and p

@@ -111,6 +111,7 @@ PROTOTYPES.update(_typed(_FT, lambda s, t: {
                                    ctypes.POINTER(_i64), _p]),
     f"lsk_axpy_sqnorm_{s}": (_i, [_i64, t, _p, _p, _p, _i64, ctypes.POINTER(_i), _p]),
     f"lsk_axpy_sqnorm_dev_{s}": (_i, [_i64, _i, _p, _p, _p, _p, _p, _p, _p, _i64, ctypes.POINTER(_i), _p]),
+    f"lsk_axpy_dot_dev_{s}": (_i, [_i64, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i64, ctypes.POINTER(_i), _p]),
     f"lsk_axpy_xpay_dev_{s}": (_i, [_i64, _i, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p]),
     f"lsk_sum_partials_{s}": (_i, [_i64, _p, _p, _p, _sz, _p]),
     f"lsk_csr_spmv_tune_{s}": (_i, [_i64, _i64, _p, _i64, _p, _p, _p, _i64, _i64, _p, _p,

@@ -90,6 +90,17 @@ class HipBackend:
                   _ptr(partials), partials.numel(), ctypes.byref(count), self.stream())
         return count.value
 
+    def axpy_dot(self, y: torch.Tensor, futs, x: torch.Tensor, w, partials: torch.Tensor) -> int:
+        """y <- fma(alpha, x, y); partials[:count] <- shares of sum(y_new * w) (w None: of sum(y_new^2)).
+        Returns count."""
+        if w is None:
+            return self.axpy_sqnorm(y, futs, x, partials)
+        nf, p = self._futs(futs)
+        count = ctypes.c_int(0)
+        _lib.call(f"lsk_axpy_dot_dev_{_lib.suffix(y.dtype)}", y.numel(), nf, *p, _ptr(x), _ptr(y), _ptr(w),
+                  _ptr(partials), partials.numel(), ctypes.byref(count), self.stream())
+        return count.value
+
     def axpy_xpay(self, z: torch.Tensor, futs_a, p: torch.Tensor, futs_b, r: torch.Tensor) -> None:
         """z <- fma(alpha, p, z) and p <- fma(beta, p, r) from the old p, one pass."""
         nfa, pa = self._futs(futs_a)

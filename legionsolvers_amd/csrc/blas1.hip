@@ -301,12 +301,16 @@ int launch_dot(const char *name, int64_t n, const T *v, const T *w, T *result, v
 // the values are in registers anyway, so the reduction that usually follows an axpy in a Krylov
 // step (CG's r <- r - a q; rr = r.r) costs no second pass over y.  The partials are summed by
 // sum_partials when (and if) the caller wants the norm.
-template <typename T, typename E, int EN>
+// OTHER: out[block] <- share of sum(y_new * w) for a third vector w instead (GMRES's modified
+// Gram-Schmidt: w' <- w' - h v_k, then v_{k+1}.w').
+template <typename T, typename E, int EN, bool OTHER = false>
 __global__ __launch_bounds__(kBlock) void axpy_sqnorm_kernel(int64_t n, Alpha<T> a, const T *x, T *y,
-                                                             T *__restrict__ out, int form) {
+                                                             T *__restrict__ out, int form,
+                                                             const T *w = nullptr) {
     const T alpha = resolve_alpha(a);
     const int64_t ne = n / EN;
     const E *xe = reinterpret_cast<const E *>(x);
+    const E *we = reinterpret_cast<const E *>(w);
     E *ye = reinterpret_cast<E *>(y);
     const int64_t gstride = int64_t(gridDim.x) * kBlock;
     const int64_t inner = form ? kBlock : gstride;
@@ -316,11 +320,12 @@ __global__ __launch_bounds__(kBlock) void axpy_sqnorm_kernel(int64_t n, Alpha<T>
     const bool first = (blockIdx.x == 0 && threadIdx.x == 0);
     T acc[4] = {T(0), T(0), T(0), T(0)};
     for (; i + 3 * inner < ne; i += outer) {
-        E xv[4], yv[4];
+        E xv[4], yv[4], wv[OTHER ? 4 : 1];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             xv[u] = xe[i + u * inner];
             yv[u] = ye[i + u * inner];
+            if constexpr (OTHER) wv[u] = we[i + u * inner];
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -328,7 +333,8 @@ __global__ __launch_bounds__(kBlock) void axpy_sqnorm_kernel(int64_t n, Alpha<T>
             if constexpr (EN == 1) r = apply<T, OP_AXPY>(alpha, xv[u], yv[u]);
             else r = apply_v<T, OP_AXPY>(alpha, xv[u], yv[u]);
             ye[i + u * inner] = r;
-            acc[u] = dot_v<T>(r, r, acc[u]);
+            if constexpr (OTHER) acc[u] = dot_v<T>(r, wv[u], acc[u]);
+            else acc[u] = dot_v<T>(r, r, acc[u]);
         }
     }
 #pragma unroll
@@ -339,14 +345,15 @@ __global__ __launch_bounds__(kBlock) void axpy_sqnorm_kernel(int64_t n, Alpha<T>
             if constexpr (EN == 1) r = apply<T, OP_AXPY>(alpha, xe[j], ye[j]);
             else r = apply_v<T, OP_AXPY>(alpha, xe[j], ye[j]);
             ye[j] = r;
-            acc[u] = dot_v<T>(r, r, acc[u]);
+            if constexpr (OTHER) acc[u] = dot_v<T>(r, we[j], acc[u]);
+            else acc[u] = dot_v<T>(r, r, acc[u]);
         }
     }
     if (EN > 1 && first) {
         for (int64_t j = ne * EN; j < n; ++j) {
             const T r = apply<T, OP_AXPY>(alpha, x[j], y[j]);
             y[j] = r;
-            acc[1] = fma_t(r, r, acc[1]);
+            acc[1] = fma_t(r, OTHER ? w[j] : r, acc[1]);
         }
     }
     const T total = block_sum((acc[0] + acc[1]) + (acc[2] + acc[3]));
@@ -355,7 +362,7 @@ __global__ __launch_bounds__(kBlock) void axpy_sqnorm_kernel(int64_t n, Alpha<T>
 
 template <typename T>
 int launch_axpy_sqnorm(const char *name, int64_t n, Alpha<T> a, const T *x, T *y, T *partials,
-                       int64_t capacity, int *count, lsk_stream_t stream) {
+                       int64_t capacity, int *count, lsk_stream_t stream, const T *w = nullptr) {
     if (n < 0) return lsk::fail(LSK_ERR_ARG, "%s: negative length %lld", name, (long long)n);
     if (!count) return lsk::fail(LSK_ERR_ARG, "%s: null count", name);
     *count = 0;
@@ -368,13 +375,17 @@ int launch_axpy_sqnorm(const char *name, int64_t n, Alpha<T> a, const T *x, T *y
         if (!fs[i]) return lsk::fail(LSK_ERR_ARG, "%s: future %d is null", name, i);
     using V = typename Vec<T>::type;
     constexpr int VN = Vec<T>::N;
-    const bool vec = lsk::aligned16(y) && lsk::aligned16(x);
+    if (w == y) w = nullptr; // the vector's own squared norm
+    const bool vec = lsk::aligned16(y) && lsk::aligned16(x) && (!w || lsk::aligned16(w));
     const int blocks = vec ? stream_grid(n / VN + 1) : stream_grid(n);
     if (capacity < blocks)
         return lsk::fail(LSK_ERR_ARG, "%s: room for %lld partial sums, %d needed", name, (long long)capacity, blocks);
     hipStream_t s = lsk::as_stream(stream);
     const int form = lsk::options().blas1_form;
-    if (vec) axpy_sqnorm_kernel<T, V, VN><<<blocks, kBlock, 0, s>>>(n, a, x, y, partials, form);
+    if (w) {
+        if (vec) axpy_sqnorm_kernel<T, V, VN, true><<<blocks, kBlock, 0, s>>>(n, a, x, y, partials, form, w);
+        else axpy_sqnorm_kernel<T, T, 1, true><<<blocks, kBlock, 0, s>>>(n, a, x, y, partials, form, w);
+    } else if (vec) axpy_sqnorm_kernel<T, V, VN><<<blocks, kBlock, 0, s>>>(n, a, x, y, partials, form);
     else axpy_sqnorm_kernel<T, T, 1><<<blocks, kBlock, 0, s>>>(n, a, x, y, partials, form);
     LSK_LAUNCH_CHECK();
     *count = blocks;
@@ -711,6 +722,14 @@ size_t lsk_dot_workspace_bytes(int64_t n) {
         return launch_axpy_sqnorm<T>("lsk_axpy_sqnorm_dev_" #SUFFIX, n,                           \
                                      dev_alpha<T>(nf, f0, f1, f2, f3), x, y, partials, capacity,  \
                                      count, s);                                                   \
+    }                                                                                             \
+    int lsk_axpy_dot_dev_##SUFFIX(int64_t n, int nf, const T *f0, const T *f1, const T *f2,       \
+                                  const T *f3, const T *x, T *y, const T *w, T *partials,         \
+                                  int64_t capacity, int *count, lsk_stream_t s) {                 \
+        if (!w && n > 0) return lsk::fail(LSK_ERR_ARG, "lsk_axpy_dot_dev_" #SUFFIX ": null w");   \
+        return launch_axpy_sqnorm<T>("lsk_axpy_dot_dev_" #SUFFIX, n,                              \
+                                     dev_alpha<T>(nf, f0, f1, f2, f3), x, y, partials, capacity,  \
+                                     count, s, w);                                                \
     }                                                                                             \
     int lsk_axpy_xpay_dev_##SUFFIX(int64_t n, int nfa, const T *a0, const T *a1, const T *a2, const T *a3, \
                                    int nfb, const T *b0, const T *b1, const T *b2, const T *b3,   \

@@ -195,7 +195,7 @@ class CSRMatrix(AbstractMatrix):
             out[i] = runs
         return out
 
-    REDRAWS = 4  # extra placements of the arrays tried at set-up (draws repeat after a handful)
+    REDRAWS = 6  # extra placements of the arrays tried at set-up (draws repeat after a handful)
 
     def _redraw_arrays(self, x, x_lo, x_hi, y, kernel_partition, range_partition, pieces) -> None:
         """Where the driver puts rects/col/val in HBM moves the product's time by +-6 % (same

@@ -194,13 +194,16 @@ class PartitionedVector:
         follows before the next write only has to add up the partial sums.
         defer: hold the update back until either vector's storage is next looked at.  If the
         next thing to happen to x is x.xpay(beta, r) (CG: x_sol += alpha p, then p <- r + beta p),
-        both run as one pass over x; anything else makes the update run first, on its own.
+        both run as one pass over x; if it is a dot product with self as an operand (CG: r -= alpha q,
+        then r.r; GMRES: w -= h v_k, then v_{k+1}.w), the update leaves that dot's partial sums
+        behind; anything else makes the update run first, on its own.
         Results are the same either way.  on_outcome(fused) is told which of the two happened."""
         *scalars, x = args
         if not 1 <= len(scalars) <= 3:
             raise TypeError("axpy takes 1 to 3 scalars and a vector")
         self._check_same_shape(x)
-        if defer and x is not self and getattr(self.ctx.backend, "axpy_xpay", None) is not None:
+        if defer and x is not self and getattr(self.ctx.backend, "axpy_xpay", None) is not None \
+                and getattr(self.ctx.backend, "axpy_dot", None) is not None:
             self._scalars(scalars)  # type checks now, not when it runs
             self._settle()
             x._settle()
@@ -252,6 +255,27 @@ class PartitionedVector:
         self._check_same_shape(x)
         be = self.ctx.backend
         n = len(self.piece_sizes)
+        # An update of one of the operands that is being held back runs now, fused with this dot.
+        d = self._deferred if self._deferred is not None and self._deferred.z is self else x._deferred
+        if d is not None and d.z in (self, x):
+            z = d.z
+            other = x if z is self else self
+            if other is z or other._deferred is None or other._deferred is d:
+                d.detach(True)
+                futs = z._scalars(d.scalars)
+                z._touch()
+                slots = out if n == 1 else be.empty(n, self.dtype)
+                for i in range(n):
+                    dst = slots[i:i + 1]
+                    if not z.piece_sizes[i]:
+                        be.sum_partials(0, None, dst)
+                        continue
+                    buf = z._partials("ad", i, be.SQNORM_SLOTS)
+                    count = be.axpy_dot(z.piece(i), futs, d.p.piece(i), None if other is z else other.piece(i), buf)
+                    be.sum_partials(count, buf, dst)
+                if n > 1:
+                    be.sum_scalars(slots, out)
+                return
         ready = self._ready_for(x) or x._ready_for(self)  # partial sums a fused leaf left behind
 
         def piece_dot(i, dst):

@@ -56,8 +56,8 @@ class SquarePlanner:
         self._fused_dot_used = 0
         self._fused_dot_pending = None
         # bets of the held-back solution update (see axpy)
-        self._deferred_issued = 0
-        self._deferred_fused = 0
+        self._deferred_issued = [0, 0]  # [into the solution, into a workspace vector]
+        self._deferred_fused = [0, 0]
 
     def get_context(self):
         return self.ctx
@@ -184,20 +184,25 @@ class SquarePlanner:
         scalars = [self._scalar(s) for s in scalars]
         # Workspace vectors are only ever written through the planner, so the fused
         # axpy + squared norm can serve a dot(dst, dst) that follows (CG: r.r after r -= a q).
-        speculate = self.ctx.fuse and dst_index >= 2
-        # An update of the solution by a workspace vector is held back: if that vector's own
-        # update comes next (CG: x += alpha p ... p <- r + beta p) both share one pass over it.
-        # A bet like the fused product + dot: kept up only while at least half of them are won
-        # (GMRES and BiCGStab lose every one).
-        defer = (self.ctx.fuse and dst_index == 0 and src_index >= 2
-                 and (self._deferred_issued < 4 or 2 * self._deferred_fused >= self._deferred_issued))
+        # Held-back updates (PartitionedVector.axpy(defer=True)): an update of the solution by a
+        # workspace vector may share one pass with that vector's own update (CG: x += alpha p ...
+        # p <- r + beta p); an update of a workspace vector may leave the partial sums of the dot
+        # product that follows (CG: r -= alpha q, r.r; GMRES: w -= h v_k, v_{k+1}.w).  Bets, like the
+        # fused product + dot: each kind is kept up only while at least half of them are won.
+        kind = 0 if dst_index == 0 else 1
+        issued, won = self._deferred_issued[kind], self._deferred_fused[kind]
+        defer = (self.ctx.fuse and src_index >= 2 and src_index != dst_index and dst_index != 1
+                 and (issued < 4 or 2 * won >= issued))
+        # (the older form of the second bet, for when it is not being placed: axpy + squared norm)
+        speculate = self.ctx.fuse and dst_index >= 2 and not defer
+        outcome = (lambda fused, k=kind: self._deferred_outcome(k, fused)) if defer else None
         for i in range(self.get_num_spaces()):
             self.get_vector(dst_index, i).axpy(*scalars, self.get_vector(src_index, i), speculate=speculate,
-                                               defer=defer, on_outcome=self._deferred_outcome if defer else None)
+                                               defer=defer, on_outcome=outcome)
 
-    def _deferred_outcome(self, fused: bool) -> None:
-        self._deferred_issued += 1
-        self._deferred_fused += 1 if fused else 0
+    def _deferred_outcome(self, kind: int, fused: bool) -> None:
+        self._deferred_issued[kind] += 1
+        self._deferred_fused[kind] += 1 if fused else 0
 
     def xpay(self, dst_index: int, *args) -> None:
         """xpay(dst, alpha, src) | xpay(dst, numer, denom, src)."""

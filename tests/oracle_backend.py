@@ -64,6 +64,11 @@ class OracleBackend:
         partials[0] = float(oracle.dot(_np(y), _np(y)))
         return 1
 
+    def axpy_dot(self, y, futs, x, w, partials):
+        self.axpy(y, futs, x)
+        partials[0] = float(oracle.dot(_np(y), _np(y if w is None else w)))
+        return 1
+
     def axpy_xpay(self, z, futs_a, p, futs_b, r):
         self.axpy(z, futs_a, p)   # z from the old p ...
         self.xpay(p, futs_b, r)   # ... then p

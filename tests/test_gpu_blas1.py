@@ -366,3 +366,43 @@ def test_axpy_xpay_fused(suf, offset):
     rc = getattr(_lib.lib(), f"lsk_axpy_xpay_dev_{suf}")(8, 1, P(one), None, None, None, 1, P(one), None, None, None,
                                                          P(v), P(v), P(dev(np.ones(8, npdt))), stream())
     assert rc == -2  # the three vectors must differ
+
+
+@pytest.mark.parametrize("suf", ["f32", "f64"])
+@pytest.mark.parametrize("offset", [0, 1])
+def test_axpy_dot_fused(suf, offset):
+    """y <- fma(alpha, x, y) with the partial sums of y_new . w for a third vector w: y bit-exact with
+    the oracle's axpy, the sum within the dot tolerance and bit-reproducible; w == y is the squared
+    norm, w == x is allowed."""
+    npdt, tdt = DT[suf]
+    tol = 1e-13 if suf == "f64" else 2e-6
+    rng = np.random.default_rng(23)
+    for n in SIZES + [(1 << 22) + 11]:
+        x = rng.standard_normal(n + offset).astype(npdt)
+        y = rng.standard_normal(n + offset).astype(npdt)
+        w = rng.standard_normal(n + offset).astype(npdt)
+        f = rng.standard_normal(1).astype(npdt)
+        print(f"case axpy_dot_{suf} n={n} offset={offset}", flush=True)
+        want = y.copy()
+        oracle.axpy(f[0], np.ascontiguousarray(x[offset:]), want[offset:])
+        fd = dev(f)
+        for which in ("third", "self", "x"):
+            xd, yd, wd = dev(x), dev(y), dev(w)
+            other = {"third": wd, "self": yd, "x": xd}[which]
+            ref = {"third": w, "self": want, "x": x}[which]
+            exact = float(np.sum(want[offset:].astype(np.float64) * ref[offset:].astype(np.float64)))
+            scale = float(np.sum(np.abs(want[offset:].astype(np.float64) * ref[offset:].astype(np.float64))))
+            results = []
+            for _ in range(2):
+                yd = dev(y)
+                other = yd if which == "self" else other
+                partials = torch.full((2048,), 7.0, dtype=tdt, device="cuda")
+                count = ctypes.c_int(-1)
+                _lib.call(f"lsk_axpy_dot_dev_{suf}", n, 1, P(fd), None, None, None, P(xd[offset:]), P(yd[offset:]),
+                          P(other[offset:]), P(partials), 2048, ctypes.byref(count), stream())
+                assert np.array_equal(bits(yd.cpu().numpy()), bits(want)), (n, which)
+                out = torch.full((1,), -1.0, dtype=tdt, device="cuda")
+                _lib.call(f"lsk_sum_partials_{suf}", count.value, P(partials), P(out), None, 0, stream())
+                assert abs(float(out) - exact) <= tol * scale + 1e-300, (n, which)
+                results.append(float(out))
+            assert results[0] == results[1]

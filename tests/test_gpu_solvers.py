@@ -236,7 +236,7 @@ def test_held_back_solution_update(gpu_ctx):
             solver.step()
             if step % 2 == 1:
                 seen.append(mpl.get_vector(0, 0).to_host().clone())
-        runs.append((seen, mpl._deferred_issued, mpl._deferred_fused))
+        runs.append((seen, mpl._deferred_issued[0], mpl._deferred_fused[0]))
     (fused_seen, issued, won), (plain_seen, issued0, _) = runs
     assert issued == 6 and won == 6 and issued0 == 0
     for a, b in zip(fused_seen, plain_seen):
@@ -247,7 +247,7 @@ def test_held_back_solution_update(gpu_ctx):
     solver = BiCGStabSolver(mpl)
     for _ in range(6):
         solver.step()
-    assert mpl._deferred_fused == 0 and mpl._deferred_issued <= 5
+    assert mpl._deferred_fused[0] == 0 and mpl._deferred_issued[0] <= 5
 
 
 def test_column_blocked_coo_follows_the_oracle(gpu_ctx, monkeypatch):
