@@ -351,3 +351,36 @@ def test_held_back_axpy_is_invisible_to_readers():
     w["z"].axpy(a, w["p"], defer=True)
     w["p"].scal(b)
     assert torch.equal(w["z"].to_host(), plain["z"].to_host())
+
+
+def test_held_back_axpy_fuses_with_the_next_dot():
+    """axpy(defer=True) followed by a dot product with the updated vector: one fused leaf, same
+    values as the plain sequence (oracle backend); with a third vector, with itself, with the
+    source; a dot product of two other vectors leaves the update pending."""
+    from legionsolvers_amd import Scalar
+    ctx = Context(backend=OracleBackend())
+    part = IndexPartition.equal(IndexSpace(0, 199), 4)
+    rng = np.random.default_rng(6)
+    init = {k: torch.from_numpy(rng.standard_normal(200)) for k in "zpwu"}
+    a = Scalar(ctx, -0.375, torch.float64)
+
+    def fresh():
+        out = {}
+        for k in "zpwu":
+            v = PartitionedVector(ctx, k, part, torch.float64)
+            v.owned.copy_(init[k])
+            out[k] = v
+        return out
+
+    for partner in "wzp":
+        plain, held = fresh(), fresh()
+        plain["z"].axpy(a, plain["p"])
+        want = plain["z"].dot(plain[partner]).get_value()
+        outcomes = []
+        held["z"].axpy(a, held["p"], defer=True, on_outcome=outcomes.append)
+        assert held["w"].dot(held["u"]).get_value() == plain["w"].dot(plain["u"]).get_value()
+        assert held["z"]._deferred is not None          # untouched by a dot of two other vectors
+        got = (held[partner].dot(held["z"]) if partner == "w" else held["z"].dot(held[partner])).get_value()
+        assert outcomes == [True] and held["z"]._deferred is None and held["p"]._deferred is None
+        assert abs(got - want) <= 1e-13 * abs(want)
+        assert torch.equal(held["z"].to_host(), plain["z"].to_host())
