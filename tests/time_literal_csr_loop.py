@@ -4,7 +4,7 @@ every row, EVERY entry of the kernel piece and tests whether it lies in the row'
 Times the literal restatement (oracle_csr_matvec_literal_*) against the O(nnz) form the oracle uses
 elsewhere (same products, same order) on small 27-point systems; CPU only.
 
-    python tools/literal_csr_timing.py
+    python tests/time_literal_csr_loop.py
 """
 import os
 import sys
