@@ -399,6 +399,14 @@ int lsk_coo_spmv_c32_f64(int64_t nnz, const uint32_t *row32, const uint32_t *col
                          const double *x, int64_t x_extent, double *y, int64_t y_first, int64_t y_last,
                          lsk_stream_t stream);
 
+/* x[i] <- a uniform value in [0, 1) that depends on `seed` and the GLOBAL element index
+ * first_index + i only: one splitmix64 step of seed + (index + 1) * 0x9e3779b97f4a7c15, its top 53
+ * bits / 2^53 (f64) or top 24 bits / 2^24 (f32).  Replaces RandomFillTask (src/UtilityTasks.cpp:
+ * 128-166: a std::mt19937 seeded from std::random_device per task, serial, different on every run)
+ * with something reproducible and independent of the partition. */
+int lsk_random_fill_f32(int64_t n, uint64_t seed, int64_t first_index, float *x, lsk_stream_t stream);
+int lsk_random_fill_f64(int64_t n, uint64_t seed, int64_t first_index, double *x, lsk_stream_t stream);
+
 /* Column-blocked entry order for matrices whose x gathers have no locality (unstructured COO):
  * order[i] = the entry that comes i-th when the entries are sorted by column block
  * col32 / block_cols (stable: inside a block they keep their order, e.g. rows ascending).  With

@@ -122,6 +122,7 @@ PROTOTYPES.update(_typed(_FT, lambda s, t: {
     f"lsk_csr_spmv_c32_tune_{s}": (_i, [_i64, _i64, _p, _p, _p, _p, _i64, _p, _p,
                                         ctypes.POINTER(_i), ctypes.POINTER(ctypes.c_float)]),
     f"lsk_coo_spmv_{s}": (_i, [_i64, _p, _p, _p, _p, _i64, _i64, _p, _i64, _i64, _p]),
+    f"lsk_random_fill_{s}": (_i, [_i64, ctypes.c_uint64, _i64, _p, _p]),
     f"lsk_coo_spmv_c32_{s}": (_i, [_i64, _p, _p, _p, _p, _i64, _p, _i64, _i64, _p]),
     f"lsk_stencil_fill_csr_{s}": (_i, [_i, _p, _i, _p, _p, _i64, _i64, _p, _i64, _p, _p, _p]),
     f"lsk_stencil_fill_coo_{s}": (_i, [_i, _p, _i, _p, _p, _i64, _i64, _p, _i64, _p, _p, _p, _p]),

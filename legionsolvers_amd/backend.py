@@ -64,6 +64,10 @@ class HipBackend:
     def fill(self, x: torch.Tensor, value) -> None:
         _lib.call(f"lsk_fill_{_lib.suffix(x.dtype)}", x.numel(), value, _ptr(x), self.stream())
 
+    def random_fill(self, x: torch.Tensor, seed: int, first_index: int) -> None:
+        _lib.call(f"lsk_random_fill_{_lib.suffix(x.dtype)}", x.numel(), seed & 0xFFFFFFFFFFFFFFFF, first_index,
+                  _ptr(x), self.stream())
+
     def copy(self, dst: torch.Tensor, src: torch.Tensor) -> None:
         _lib.call(f"lsk_copy_{_lib.suffix(dst.dtype)}", dst.numel(), _ptr(src), _ptr(dst), self.stream())
 

@@ -237,6 +237,38 @@ __global__ __launch_bounds__(kBlock) void halo_rows_kernel(long long rows, long 
     }
 }
 
+// Uniform [0, 1) value of global element `index` under `seed`: one splitmix64 step of
+// seed + (index + 1) * golden ratio, top 53 (double) or 24 (float) bits.  A function of the global
+// index alone, so a vector's contents do not depend on how it is partitioned.
+__device__ __forceinline__ unsigned long long splitmix64(unsigned long long z) {
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    return z ^ (z >> 31);
+}
+template <typename T>
+__global__ __launch_bounds__(kBlock) void random_fill_kernel(int64_t n, unsigned long long seed, int64_t first,
+                                                             T *__restrict__ x) {
+    const int64_t stride = int64_t(gridDim.x) * kBlock;
+    for (int64_t i = int64_t(blockIdx.x) * kBlock + threadIdx.x; i < n; i += stride) {
+        const unsigned long long r =
+            splitmix64(seed + static_cast<unsigned long long>(first + i + 1) * 0x9e3779b97f4a7c15ull);
+        if constexpr (sizeof(T) == 8) x[i] = static_cast<T>(r >> 11) * (1.0 / 9007199254740992.0);
+        else x[i] = static_cast<T>(r >> 40) * (1.0f / 16777216.0f);
+    }
+}
+
+template <typename T>
+int launch_random_fill(const char *name, int64_t n, uint64_t seed, int64_t first, T *x, lsk_stream_t stream) {
+    if (n < 0) return lsk::fail(LSK_ERR_ARG, "%s: negative length", name);
+    if (n == 0) return LSK_OK;
+    if (!x) return lsk::fail(LSK_ERR_ARG, "%s: null vector", name);
+    int blocks = grid_for(n);
+    if (blocks > 16 * lsk::kMaxGridBlocks) blocks = 16 * lsk::kMaxGridBlocks;
+    random_fill_kernel<T><<<blocks, kBlock, 0, lsk::as_stream(stream)>>>(n, seed, first, x);
+    LSK_LAUNCH_CHECK();
+    return LSK_OK;
+}
+
 // Column-block id of every entry (col32 / block_cols; the "outside the window" marker goes to the
 // last block) and its position, as the key / value pairs of the stable sort below.
 __global__ __launch_bounds__(kBlock) void block_keys_kernel(int64_t nnz, const uint32_t *__restrict__ col32,
@@ -342,6 +374,13 @@ int lsk_stencil_fill_coo_f64(int dim, const int64_t *extent, int noffsets, const
                              double *val, lsk_stream_t stream) {
     return launch_fill<double, true>("lsk_stencil_fill_coo_f64", dim, extent, noffsets, offsets,
                                      coeffs, row_lo, row_hi, rects, k_base, row, col, val, stream);
+}
+
+int lsk_random_fill_f32(int64_t n, uint64_t seed, int64_t first_index, float *x, lsk_stream_t stream) {
+    return launch_random_fill<float>("lsk_random_fill_f32", n, seed, first_index, x, stream);
+}
+int lsk_random_fill_f64(int64_t n, uint64_t seed, int64_t first_index, double *x, lsk_stream_t stream) {
+    return launch_random_fill<double>("lsk_random_fill_f64", n, seed, first_index, x, stream);
 }
 
 int lsk_coo_block_order_u32(int64_t nnz, const uint32_t *col32, int64_t x_extent, int64_t block_cols,

@@ -169,6 +169,18 @@ class PartitionedVector:
     def zero_fill(self) -> None:
         self.constant_fill(0.0)
 
+    def random_fill(self, seed: int = 0) -> None:
+        """Uniform [0, 1) entries that depend on `seed` and the global element index only (so the
+        same on any partition and any number of ranks).  The reference has the task but never
+        wired it to the class (RandomFillTask, src/UtilityTasks.cpp:128-166; "TODO: random_fill"
+        in test/Test02VectorOperations.cpp:128), and seeds it from std::random_device."""
+        if self.index_space.dim != 1:
+            raise NotImplementedError("random_fill numbers the elements of 1-D vectors")
+        self._touch()
+        for i, c in enumerate(self.colors):
+            if self.piece_sizes[i]:
+                self.ctx.backend.random_fill(self.piece(i), seed, self.index_partition.pieces[c].lo[0])
+
     def assign(self, x: "PartitionedVector") -> "PartitionedVector":
         """operator=(const PartitionedVector &): index copy, piece by piece."""
         self._check_same_shape(x)

@@ -265,3 +265,19 @@ def task_id_tdi(block, t, n, i):
 
 def task_id_tdddiii(block, t, n1, n2, n3, i1, i2, i3):
     return int(lib().oracle_task_id_tdddiii(block, t, n1, n2, n3, i1, i2, i3))
+
+
+def random_fill(n: int, seed: int, first_index: int, dtype=np.float64) -> np.ndarray:
+    """What lsk_random_fill_* writes: one splitmix64 step of seed + (index + 1) * golden ratio per
+    global index, top 53 bits / 2^53 (float64) or top 24 bits / 2^24 (float32).  (The reference's
+    RandomFillTask, src/UtilityTasks.cpp:128-166, is seeded from std::random_device: there is
+    nothing to be bit-exact with; this pins the replacement.)"""
+    with np.errstate(over="ignore"):
+        idx = np.arange(first_index + 1, first_index + 1 + n, dtype=np.uint64)
+        z = np.uint64(seed & 0xFFFFFFFFFFFFFFFF) + idx * np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    if np.dtype(dtype) == np.float64:
+        return (z >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+    return ((z >> np.uint64(40)).astype(np.float32) * np.float32(1.0 / 16777216.0)).astype(np.float32)

@@ -44,6 +44,9 @@ class OracleBackend:
     def fill(self, x, value):
         x.fill_(value)
 
+    def random_fill(self, x, seed, first_index):
+        x.copy_(torch.from_numpy(oracle.random_fill(x.numel(), seed, first_index, _np(x).dtype)))
+
     def copy(self, dst, src):
         dst.copy_(src)
 

@@ -406,3 +406,24 @@ def test_axpy_dot_fused(suf, offset):
                 assert abs(float(out) - exact) <= tol * scale + 1e-300, (n, which)
                 results.append(float(out))
             assert results[0] == results[1]
+
+
+@pytest.mark.parametrize("suf", ["f32", "f64"])
+def test_random_fill_bit_exact_and_partition_independent(gpu_ctx, suf):
+    from legionsolvers_amd import IndexPartition, IndexSpace, PartitionedVector
+    npdt, tdt = DT[suf]
+    for n, seed, first in ((0, 1, 0), (1, 0, 0), (1000, 7, 123456789012), (70001, 2**63 + 5, 3)):
+        x = torch.full((n,), -1.0, dtype=tdt, device="cuda")
+        _lib.call(f"lsk_random_fill_{suf}", n, seed, first, P(x), stream())
+        want = oracle.random_fill(n, seed, first, npdt)
+        got = x.cpu().numpy()
+        assert np.array_equal(bits(got), bits(want))
+        assert n == 0 or (got.min() >= 0.0 and got.max() < 1.0)
+    whole = None
+    for pieces in (1, 3, 7):
+        v = PartitionedVector(gpu_ctx, "v", IndexPartition.equal(IndexSpace(0, 9999), pieces), tdt)
+        v.random_fill(seed=42)
+        h = v.to_host()
+        whole = h if whole is None else whole
+        assert torch.equal(h, whole)
+    assert 0.45 < float(whole.double().mean()) < 0.55
