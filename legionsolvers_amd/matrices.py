@@ -420,7 +420,12 @@ class COOMatrix(AbstractMatrix):
             t1.synchronize()
             return t0.elapsed_time(t1) / 3
 
-        if mode == "1" or timed(*blocked) < timed(self.row32, self.col32, self.val):
+        t_blocked = timed(*blocked)
+        t_rows = timed(self.row32, self.col32, self.val) if mode != "1" else float("inf")
+        if os.environ.get("LSK_TUNE_VERBOSE"):
+            print(f"[lsk] COO entry order: rows {t_rows:.3f} ms, column blocks {t_blocked:.3f} ms",
+                  file=sys.stderr, flush=True)
+        if t_blocked < t_rows:
             self.row32, self.col32, self.val_blocked = blocked
             self.blocked = True
 
