@@ -247,6 +247,11 @@ class CSRMatrix(AbstractMatrix):
             t = time_current()
             if os.environ.get("LSK_TUNE_VERBOSE"):
                 print(f"[lsk] array placement: {best:.3f} ms held, {t:.3f} ms redrawn", file=sys.stderr, flush=True)
+                if os.environ.get("LSK_TUNE_VERBOSE") == "2":
+                    col_now = self.col32 if compressed else self.col
+                    print(f"[lsk]   redrawn at val {self.val.data_ptr():#x} col {col_now.data_ptr():#x} "
+                          f"(val - col = {(self.val.data_ptr() - col_now.data_ptr()) / 2**30:.3f} GiB)",
+                          file=sys.stderr, flush=True)
             if t < best:
                 best = t
             elif compressed:
