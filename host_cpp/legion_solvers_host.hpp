@@ -40,6 +40,8 @@ template <typename T> struct Abi;
         static constexpr auto sum_scalars = lsk_sum_scalars_##SUF;                                 \
         static constexpr auto csr_spmv = lsk_csr_spmv_##SUF;                                       \
         static constexpr auto csr_spmv_c32 = lsk_csr_spmv_c32_##SUF;                               \
+        static constexpr auto csr_spmv_c32_tune = lsk_csr_spmv_c32_tune_##SUF;                     \
+        static constexpr auto csr_spmv_tune = lsk_csr_spmv_tune_##SUF;                             \
         static constexpr auto coo_spmv = lsk_coo_spmv_##SUF;                                       \
         static constexpr auto stencil_fill_csr = lsk_stencil_fill_csr_##SUF;                       \
         static constexpr auto stencil_fill_coo = lsk_stencil_fill_coo_##SUF;                       \
@@ -306,6 +308,7 @@ public:
             pieces_.push_back(std::move(p));
         }
         if (compress && col_.size() > 0 && domain_ > 0) try_compress();
+        tune();
     }
     bool compressed() const { return col32_.size() > 0; }
     bool accumulates_only() const override { return false; }
@@ -316,6 +319,7 @@ public:
             const int64_t rows = range_.volume(c);
             if (rows <= 0) continue;
             const Piece &p = pieces_[c];
+            check(lsk_set_option("xcd_remap", p.placement));
             if (compressed())
                 check(Abi<T>::csr_spmv_c32(rows, p.nnz, p.rowoff.get(), col32_.get() + p.k_lo, val_.get() + p.k_lo,
                                            src.data(), domain_, dst.piece(c), beta, ctx_->stream()));
@@ -329,8 +333,32 @@ public:
 private:
     struct Piece {
         int64_t k_lo = 0, nnz = 0;
+        int placement = 0; // tile -> XCD placement the library measured fastest for this piece
         DeviceArray<uint32_t> rowoff;
     };
+    // Set-up-time choice of the tile placement, per piece of at least kTuneMinRows rows (the
+    // library times a few candidates on the piece itself; a speed hint, results do not depend on it).
+    static constexpr int64_t kTuneMinRows = int64_t(1) << 21;
+    void tune() {
+        int64_t most = 0;
+        for (int c = 0; c < range_.colors(); ++c) most = std::max(most, range_.volume(c));
+        if (most < kTuneMinRows || domain_ <= 0) return;
+        DeviceArray<T> x(domain_), y(most);
+        check(Abi<T>::fill(domain_, T(0), x.get(), ctx_->stream()));
+        for (int c = 0; c < range_.colors(); ++c) {
+            const int64_t rows = range_.volume(c);
+            Piece &p = pieces_[c];
+            if (rows < kTuneMinRows || p.nnz <= 0) continue;
+            float ms = 0.0f;
+            if (compressed())
+                check(Abi<T>::csr_spmv_c32_tune(rows, p.nnz, p.rowoff.get(), col32_.get() + p.k_lo, val_.get() + p.k_lo,
+                                                x.get(), domain_, y.get(), ctx_->stream(), &p.placement, &ms));
+            else
+                check(Abi<T>::csr_spmv_tune(rows, p.nnz, rects_.get() + 2 * range_.piece[c].first, p.k_lo,
+                                            col_.get() + p.k_lo, val_.get() + p.k_lo, x.get(), 0, domain_ - 1, y.get(),
+                                            ctx_->stream(), &p.placement, &ms));
+        }
+    }
     void try_compress() {
         DeviceArray<uint32_t> col32(col_.size());
         if (lsk_csr_compress_cols_u32(col_.size(), col_.get(), 0, domain_ - 1, col32.get(), ctx_->stream()) != LSK_OK)
