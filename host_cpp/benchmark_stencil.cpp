@@ -3,7 +3,9 @@
 // on one matrix, rhs = 1, x0 = 0), same warm-up / timed trace structure (:201-262) and the same
 // three output lines.  Extensions for tests: -systems 1 solves a single system, -coo 1 builds the
 // COO form of the matrix, -f32 1 uses float entries, -restart N sets GMRES's restart length
-// (the reference hard-codes 10), -history 1 prints the solver's scalar history one value per line.
+// (the reference hard-codes 10), -history 1 prints the solver's scalar history one value per line,
+// -compress 0 / -fuse 0 / -redraws 0 turn the 32-bit structure, the held-back updates and the
+// set-up-time array redraws off.
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -18,7 +20,7 @@ namespace {
 
 struct Args {
     long dim = 1, solver = 1, nx = 16, ny = 16, nz = 16, vp = 4, it = 20, pt = 1;
-    long systems = 2, coo = 0, f32 = 0, restart = 10, history = 0, compress = 1;
+    long systems = 2, coo = 0, f32 = 0, restart = 10, history = 0, compress = 1, fuse = 1, redraws = 4;
 };
 
 Args parse(int argc, char **argv) {
@@ -27,7 +29,8 @@ Args parse(int argc, char **argv) {
         {"-dim", &Args::dim}, {"-solver", &Args::solver}, {"-nx", &Args::nx}, {"-ny", &Args::ny},
         {"-nz", &Args::nz}, {"-vp", &Args::vp}, {"-it", &Args::it}, {"-pt", &Args::pt},
         {"-systems", &Args::systems}, {"-coo", &Args::coo}, {"-f32", &Args::f32}, {"-restart", &Args::restart},
-        {"-history", &Args::history}, {"-compress", &Args::compress}};
+        {"-history", &Args::history}, {"-compress", &Args::compress}, {"-fuse", &Args::fuse},
+        {"-redraws", &Args::redraws}};
     for (int i = 1; i + 1 < argc; i += 2) {
         bool known = false;
         for (const auto &t : table)
@@ -93,10 +96,12 @@ template <typename T> int main_typed(const Args &a) {
         matrix = std::make_unique<COOMatrix<T>>(create_linearized_coo_stencil_matrix<T>(ctx, extent, st, partition));
     else
         matrix = std::make_unique<CSRMatrix<T>>(
-            create_linearized_csr_stencil_matrix<T>(ctx, extent, st, partition, a.compress != 0));
+            create_linearized_csr_stencil_matrix<T>(ctx, extent, st, partition, a.compress != 0,
+                                                    static_cast<int>(a.redraws)));
 
     std::vector<std::unique_ptr<PartitionedVector<T>>> sols, rhss;
     SquarePlanner<T> planner(ctx);
+    planner.set_fusion(a.fuse != 0);
     for (long s = 0; s < a.systems; ++s) {
         sols.push_back(std::make_unique<PartitionedVector<T>>(ctx, s ? "sol1" : "sol", partition));
         sols.back()->zero_fill();

@@ -38,6 +38,10 @@ template <typename T> struct Abi;
         static constexpr auto dot = lsk_dot_##SUF;                                                 \
         static constexpr auto scalar_op = lsk_scalar_op_##SUF;                                     \
         static constexpr auto sum_scalars = lsk_sum_scalars_##SUF;                                 \
+        static constexpr auto sum_partials = lsk_sum_partials_##SUF;                               \
+        static constexpr auto axpy_sqnorm_dev = lsk_axpy_sqnorm_dev_##SUF;                         \
+        static constexpr auto axpy_dot_dev = lsk_axpy_dot_dev_##SUF;                               \
+        static constexpr auto axpy_xpay_dev = lsk_axpy_xpay_dev_##SUF;                             \
         static constexpr auto csr_spmv = lsk_csr_spmv_##SUF;                                       \
         static constexpr auto csr_spmv_c32 = lsk_csr_spmv_c32_##SUF;                               \
         static constexpr auto csr_spmv_c32_tune = lsk_csr_spmv_c32_tune_##SUF;                     \
@@ -202,16 +206,26 @@ struct EqualPartition {
 };
 
 // PartitionedVector<T> (src/PartitionedVector.hpp): one dense buffer, coloured by the partition.
+//
+// Held-back updates.  axpy(alpha, x, /*defer=*/true) does not launch at once: the two vectors
+// remember it, and the next thing that happens decides how it runs.  x.xpay(beta, r) next (CG:
+// x_sol += alpha p, then p <- r + beta p): both in one pass over x.  A dot product with the updated
+// vector next (CG: r -= alpha q, then r.r; GMRES: w -= h v_k, then v_{k+1}.w): the update leaves
+// that dot's partial sums behind.  Anything else that reaches either vector's storage (data(),
+// piece(), to_host(), any operation) runs the update first, on its own.  Values are the same
+// either way; pointers from data() / piece() are to be fetched again after an operation rather than
+// kept, as a Legion accessor is valid for one mapping only.
 template <typename T> class PartitionedVector {
 public:
     PartitionedVector(const Context &ctx, std::string name, const EqualPartition &partition)
-        : ctx_(&ctx), name_(std::move(name)), part_(partition), data_(partition.n), slots_(partition.colors()) {}
+        : ctx_(&ctx), name_(std::move(name)), part_(partition), data_(partition.n), slots_(partition.colors()),
+          partials_(static_cast<int64_t>(partition.colors()) * kPartials) {}
     const Context &context() const { return *ctx_; }
     const EqualPartition &partition() const { return part_; }
     const std::string &name() const { return name_; }
-    T *data() const { return data_.get(); }
-    T *piece(int c) const { return data_.get() + part_.piece[c].first; }
-    std::vector<T> to_host() const { return data_.to_host(*ctx_); }
+    T *data() const { settle(); return data_.get(); }
+    T *piece(int c) const { settle(); return raw_piece(c); }
+    std::vector<T> to_host() const { settle(); return data_.to_host(*ctx_); }
 
     void constant_fill(T value) { each([&](int c) { check(Abi<T>::fill(part_.volume(c), value, piece(c), ctx_->stream())); }); }
     void zero_fill() { constant_fill(T(0)); }
@@ -221,6 +235,9 @@ public:
         return *this;
     }
     PartitionedVector(const PartitionedVector &) = delete;
+    ~PartitionedVector() {
+        if (deferred_) detach(); // never leave the partner pointing at a dead vector
+    }
 
     // alpha = get_alpha(futures) (src/LegionUtilities.cpp:72-97): f0, f0/f1, f0*f1/f2, f0*f1/(f2*f3)
     void scal(const std::vector<Scalar<T>> &alpha) {
@@ -228,8 +245,15 @@ public:
         const int nf = futures(alpha, f);
         each([&](int c) { check(Abi<T>::scal_dev(part_.volume(c), nf, f[0], f[1], f[2], f[3], piece(c), ctx_->stream())); });
     }
-    void axpy(const std::vector<Scalar<T>> &alpha, const PartitionedVector &x) {
+    void axpy(const std::vector<Scalar<T>> &alpha, PartitionedVector &x, bool defer = false) {
         same_partition(x);
+        if (alpha.size() > 4) throw std::invalid_argument("alpha takes at most 4 futures");
+        if (defer && &x != this) {
+            settle();
+            x.settle();
+            deferred_ = x.deferred_ = std::make_shared<Deferred>(Deferred{this, &x, alpha});
+            return;
+        }
         const T *f[4];
         const int nf = futures(alpha, f);
         each([&](int c) {
@@ -240,6 +264,17 @@ public:
         same_partition(x);
         const T *f[4];
         const int nf = futures(alpha, f);
+        if (deferred_ && deferred_->p == this && &x != deferred_->z && &x != this && !x.deferred_) {
+            // z <- fma(a, this, z) was held back: one pass over this vector serves both updates
+            const std::shared_ptr<Deferred> d = detach();
+            const T *fa[4];
+            const int nfa = futures(d->scalars, fa);
+            each([&](int c) {
+                check(Abi<T>::axpy_xpay_dev(part_.volume(c), nfa, fa[0], fa[1], fa[2], fa[3], nf, f[0], f[1], f[2], f[3],
+                                            x.raw_piece(c), raw_piece(c), d->z->raw_piece(c), ctx_->stream()));
+            });
+            return;
+        }
         each([&](int c) {
             check(Abi<T>::xpay_dev(part_.volume(c), nf, f[0], f[1], f[2], f[3], x.piece(c), piece(c), ctx_->stream()));
         });
@@ -248,17 +283,62 @@ public:
     // over the future map (src/PartitionedVector.cpp:353-357).
     Scalar<T> dot(const PartitionedVector &w) const {
         same_partition(w);
+        Scalar<T> out = Scalar<T>::uninitialised(*ctx_);
         // the pieces' results live in a buffer of this vector; everything is ordered on one stream,
         // so the next dot may reuse it
+        std::shared_ptr<Deferred> d = (deferred_ && deferred_->z == this) ? deferred_ : w.deferred_;
+        if (d && (d->z == this || d->z == &w)) {
+            PartitionedVector *z = d->z;
+            const PartitionedVector *other = z == this ? &w : this;
+            if (other == z || !other->deferred_ || other->deferred_ == d) {
+                // an update of one operand was held back: it runs now and leaves this dot's partial sums
+                z->detach();
+                const T *f[4];
+                const int nf = futures(d->scalars, f);
+                for (int c = 0; c < part_.colors(); ++c) {
+                    T *buf = z->partials_.get() + static_cast<int64_t>(c) * kPartials;
+                    int count = 0;
+                    if (part_.volume(c) > 0) {
+                        if (other == z)
+                            check(Abi<T>::axpy_sqnorm_dev(part_.volume(c), nf, f[0], f[1], f[2], f[3], d->p->raw_piece(c),
+                                                          z->raw_piece(c), buf, kPartials, &count, ctx_->stream()));
+                        else
+                            check(Abi<T>::axpy_dot_dev(part_.volume(c), nf, f[0], f[1], f[2], f[3], d->p->raw_piece(c),
+                                                       z->raw_piece(c), other->raw_piece(c), buf, kPartials, &count,
+                                                       ctx_->stream()));
+                    }
+                    check(Abi<T>::sum_partials(count, buf, slots_.get() + c, nullptr, 0, ctx_->stream()));
+                }
+                check(Abi<T>::sum_scalars(part_.colors(), slots_.get(), out.writable(), ctx_->stream()));
+                return out;
+            }
+        }
         for (int c = 0; c < part_.colors(); ++c)
             check(Abi<T>::dot(part_.volume(c), piece(c), w.piece(c), slots_.get() + c, ctx_->workspace(),
                               ctx_->workspace_bytes(), ctx_->stream()));
-        Scalar<T> out = Scalar<T>::uninitialised(*ctx_);
         check(Abi<T>::sum_scalars(part_.colors(), slots_.get(), out.writable(), ctx_->stream()));
         return out;
     }
 
 private:
+    static constexpr int kPartials = 2048; // partial sums a fused leaf writes per piece, at most
+    struct Deferred {
+        PartitionedVector *z, *p; // z <- fma(alpha, p, z), not launched yet
+        std::vector<Scalar<T>> scalars;
+    };
+    std::shared_ptr<Deferred> detach() const {
+        std::shared_ptr<Deferred> d = deferred_;
+        d->z->deferred_.reset();
+        d->p->deferred_.reset();
+        return d;
+    }
+    void settle() const { // run an update that was being held back, before the storage is touched
+        if (deferred_) {
+            const std::shared_ptr<Deferred> d = detach();
+            d->z->axpy(d->scalars, *d->p);
+        }
+    }
+    T *raw_piece(int c) const { return data_.get() + part_.piece[c].first; }
     template <typename F> void each(F &&f) {
         for (int c = 0; c < part_.colors(); ++c)
             if (part_.volume(c) > 0) f(c);
@@ -275,7 +355,9 @@ private:
     std::string name_;
     EqualPartition part_;
     DeviceArray<T> data_;
-    DeviceArray<T> slots_; // one dot result per piece
+    DeviceArray<T> slots_;    // one dot result per piece
+    DeviceArray<T> partials_; // partial sums of the fused leaves, kPartials per piece
+    mutable std::shared_ptr<Deferred> deferred_;
 };
 
 // AbstractMatrix (src/AbstractMatrix.hpp) as the planner uses it.
@@ -294,7 +376,7 @@ public:
 template <typename T> class CSRMatrix : public AbstractMatrix<T> {
 public:
     CSRMatrix(const Context &ctx, const EqualPartition &range, int64_t domain_size, DeviceArray<int64_t> rects,
-              DeviceArray<int64_t> col, DeviceArray<T> val, bool compress = true)
+              DeviceArray<int64_t> col, DeviceArray<T> val, bool compress = true, int redraws = 4)
         : ctx_(&ctx), range_(range), domain_(domain_size), rects_(std::move(rects)), col_(std::move(col)),
           val_(std::move(val)) {
         for (int c = 0; c < range_.colors(); ++c) {
@@ -308,7 +390,43 @@ public:
             pieces_.push_back(std::move(p));
         }
         if (compress && col_.size() > 0 && domain_ > 0) try_compress();
-        tune();
+        float best = tune();
+        // Where the driver puts the arrays in HBM moves the product's time by several per cent, and
+        // user code cannot steer it; so the arrays are copied into fresh allocations a few times
+        // and the fastest set is kept (needs room for a second copy; stops quietly without).
+        for (int i = 0; i < redraws && best > 0.0f && compressed(); ++i) {
+            try {
+                DeviceArray<uint32_t> col32(col32_.size());
+                DeviceArray<T> val(val_.size());
+                std::vector<DeviceArray<uint32_t>> offs;
+                check(lsk_memcpy_d2d(col32.get(), col32_.get(), static_cast<size_t>(col32_.size()) * 4, ctx.stream()));
+                check(lsk_memcpy_d2d(val.get(), val_.get(), static_cast<size_t>(val_.size()) * sizeof(T), ctx.stream()));
+                for (auto &p : pieces_) {
+                    offs.emplace_back(p.rowoff.size());
+                    check(lsk_memcpy_d2d(offs.back().get(), p.rowoff.get(), static_cast<size_t>(p.rowoff.size()) * 4,
+                                         ctx.stream()));
+                }
+                ctx.synchronize();
+                std::vector<int> held;
+                for (auto &p : pieces_) held.push_back(p.placement);
+                std::swap(col32, col32_);
+                std::swap(val, val_);
+                for (size_t c = 0; c < pieces_.size(); ++c) std::swap(offs[c], pieces_[c].rowoff);
+                const float ms = tune();
+                if (ms > 0.0f && ms < best) {
+                    best = ms; // the old set is freed on leaving the scope
+                } else {
+                    std::swap(col32, col32_);
+                    std::swap(val, val_);
+                    for (size_t c = 0; c < pieces_.size(); ++c) {
+                        std::swap(offs[c], pieces_[c].rowoff);
+                        pieces_[c].placement = held[c];
+                    }
+                }
+            } catch (const std::runtime_error &) {
+                break;
+            }
+        }
     }
     bool compressed() const { return col32_.size() > 0; }
     bool accumulates_only() const override { return false; }
@@ -339,10 +457,11 @@ private:
     // Set-up-time choice of the tile placement, per piece of at least kTuneMinRows rows (the
     // library times a few candidates on the piece itself; a speed hint, results do not depend on it).
     static constexpr int64_t kTuneMinRows = int64_t(1) << 21;
-    void tune() {
+    float tune() { // returns the milliseconds of one product over the tuned pieces (0: nothing tuned)
         int64_t most = 0;
+        float total = 0.0f;
         for (int c = 0; c < range_.colors(); ++c) most = std::max(most, range_.volume(c));
-        if (most < kTuneMinRows || domain_ <= 0) return;
+        if (most < kTuneMinRows || domain_ <= 0) return total;
         DeviceArray<T> x(domain_), y(most);
         check(Abi<T>::fill(domain_, T(0), x.get(), ctx_->stream()));
         for (int c = 0; c < range_.colors(); ++c) {
@@ -357,7 +476,9 @@ private:
                 check(Abi<T>::csr_spmv_tune(rows, p.nnz, rects_.get() + 2 * range_.piece[c].first, p.k_lo,
                                             col_.get() + p.k_lo, val_.get() + p.k_lo, x.get(), 0, domain_ - 1, y.get(),
                                             ctx_->stream(), &p.placement, &ms));
+            total += ms;
         }
+        return total;
     }
     void try_compress() {
         DeviceArray<uint32_t> col32(col_.size());
@@ -457,8 +578,13 @@ public:
     void zero_fill(int dst) { for (auto *v : vectors_.at(dst)) v->zero_fill(); }
     void copy(int dst, int src) { for (size_t s = 0; s < vectors_.at(dst).size(); ++s) *vectors_[dst][s] = *vectors_.at(src)[s]; }
     void scal(int dst, const std::vector<Scalar<T>> &alpha) { for (auto *v : vectors_.at(dst)) v->scal(alpha); }
+    // An update by a workspace vector is held back (see PartitionedVector): into the solution it may
+    // share a pass with that vector's own update, into a workspace vector it may serve the dot
+    // product that follows.  set_fusion(false) launches every leaf as it is asked for.
+    void set_fusion(bool on) { fuse_ = on; }
     void axpy(int dst, const std::vector<Scalar<T>> &alpha, int src) {
-        for (size_t s = 0; s < vectors_.at(dst).size(); ++s) vectors_[dst][s]->axpy(alpha, *vectors_.at(src)[s]);
+        const bool defer = fuse_ && src >= 2 && dst != RHS && dst != src;
+        for (size_t s = 0; s < vectors_.at(dst).size(); ++s) vectors_[dst][s]->axpy(alpha, *vectors_.at(src)[s], defer);
     }
     void xpay(int dst, const std::vector<Scalar<T>> &alpha, int src) {
         for (size_t s = 0; s < vectors_.at(dst).size(); ++s) vectors_[dst][s]->xpay(alpha, *vectors_.at(src)[s]);
@@ -490,6 +616,7 @@ private:
         return static_cast<int>(vectors_[index].size()) - 1;
     }
     const Context *ctx_;
+    bool fuse_ = true;
     std::vector<std::vector<PartitionedVector<T> *>> vectors_;
     std::vector<std::unique_ptr<PartitionedVector<T>>> owned_;
     std::vector<Entry> matrices_;

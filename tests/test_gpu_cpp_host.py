@@ -70,3 +70,15 @@ def test_compressed_structure_prints_the_same():
     structure print the same history to the last digit."""
     flags = ("-dim", 3, "-nx", 20, "-ny", 17, "-nz", 33, "-vp", 2, "-it", 9, "-systems", 1, "-history", 1)
     assert run(*flags)[2] == run(*flags, "-compress", 0)[2]
+
+
+@pytest.mark.parametrize("solver", [1, 2, 3])
+def test_held_back_updates_print_the_same_solution(solver):
+    """-fuse 0 (every leaf launched as asked for) against the default (updates held back and fused
+    with the xpay / dot that follows): the same history up to the summation order of the dots."""
+    flags = ("-dim", 4, "-nx", 11, "-ny", 12, "-nz", 13, "-vp", 3, "-solver", solver, "-it", 7, "-restart", 4,
+             "-history", 1)
+    hist_f, sums_f, _ = run(*flags)
+    hist_p, sums_p, _ = run(*flags, "-fuse", 0)
+    np.testing.assert_allclose(hist_f, hist_p, rtol=1e-11)
+    np.testing.assert_allclose(sums_f["solution_sum_of_squares"], sums_p["solution_sum_of_squares"], rtol=1e-10)
