@@ -421,6 +421,26 @@ int lsk_gather_u32(int64_t n, const uint32_t *src, const uint32_t *order, uint32
 int lsk_gather_f32(int64_t n, const float *src, const uint32_t *order, float *dst, lsk_stream_t stream);
 int lsk_gather_f64(int64_t n, const double *src, const uint32_t *order, double *dst, lsk_stream_t stream);
 
+/* The transposed product (CSRRmatvecTask / COORmatvecTask: registered by the reference,
+ * src/Initialize.cpp:464-479, with bodies that are assert(false) on CPU and GPU alike,
+ * src/CSRMatrixTasks.cpp:95-100, src/COOMatrixTasks.cpp:78-83, src/CSRMatrixTasks.cu:159-164) is
+ * served without atomics: at set-up the entries are sorted by column once, which gives the CSR
+ * form of the transpose in the 32-bit structure of lsk_csr_spmv_c32_*; every y <- A^T x is then
+ * that kernel, deterministic and at the same rate as y <- A x.  The sort is
+ * lsk_coo_block_order_u32 with block_cols = 1 (stable: inside a column the rows ascend) followed
+ * by lsk_gather_*; the two helpers below supply what a CSR matrix lacks for it.
+ *
+ * lsk_csr_entry_rows_u32: row32[k - k_base] <- r for every entry k of rect r (0-based in `rects`,
+ * arguments as lsk_csr_spmv_*), 0xffffffff for an entry inside no rect; rows < 2^32 - 1.
+ * lsk_sorted_key_offsets_u32: offsets[c] <- the number of keys[0..n) below c, for c = 0..nkeys
+ * (nkeys + 1 values; keys ascending): the row offsets of the transposed structure, with
+ * offsets[nkeys] = the entries whose column lies inside the window (the marker 0xffffffff sorts
+ * behind them). */
+int lsk_csr_entry_rows_u32(int64_t rows, int64_t nnz, const int64_t *rects, int64_t k_base, uint32_t *row32,
+                           lsk_stream_t stream);
+int lsk_sorted_key_offsets_u32(int64_t n, const uint32_t *keys, int64_t nkeys, uint32_t *offsets,
+                               lsk_stream_t stream);
+
 /* ------------------------------------------------ set-up helpers (device side) ------ */
 /* out[0] = min idx[i], out[1] = max idx[i] (out = {INT64_MAX, INT64_MIN} when n == 0):
  * the bounding interval of create_partition_by_image over a column field

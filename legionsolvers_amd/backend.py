@@ -218,6 +218,19 @@ class HipBackend:
         _lib.call(f"lsk_gather_{kind}", src.numel(), _ptr(src), _ptr(order), _ptr(dst), self.stream())
         return dst
 
+    def csr_entry_rows(self, rects: torch.Tensor, k_base: int, nnz: int) -> torch.Tensor:
+        """Row (0-based in `rects`) of every kernel entry, as uint32 in an int32 tensor; 0xffffffff
+        for an entry inside no rect."""
+        out = torch.empty(nnz, dtype=torch.int32, device=self.device)
+        _lib.call("lsk_csr_entry_rows_u32", rects.shape[0], nnz, _ptr(rects), k_base, _ptr(out), self.stream())
+        return out
+
+    def sorted_key_offsets(self, keys: torch.Tensor, nkeys: int) -> torch.Tensor:
+        """nkeys + 1 offsets: how many of the ascending uint32 `keys` lie below 0, 1, .. nkeys."""
+        out = torch.empty(nkeys + 1, dtype=torch.int32, device=self.device)
+        _lib.call("lsk_sorted_key_offsets_u32", keys.numel(), _ptr(keys), nkeys, _ptr(out), self.stream())
+        return out
+
     def csr_compress_rows(self, rects: torch.Tensor, k_base: int, nnz: int):
         """rows + 1 32-bit offsets into the piece's col/val arrays (the classic row pointer; bit
         pattern of uint32 in an int32 tensor), or None when the rects are not back to back inside

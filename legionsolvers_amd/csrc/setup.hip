@@ -283,6 +283,40 @@ __global__ __launch_bounds__(kBlock) void block_keys_kernel(int64_t nnz, const u
     }
 }
 
+// Row (counted from the first rect) of every kernel entry -- the row field a COO copy of the same
+// matrix would hold; an entry inside no rect keeps the marker 0xffffffff.
+__global__ __launch_bounds__(kBlock) void mark_all_kernel(int64_t n, uint32_t *__restrict__ out) {
+    const int64_t stride = int64_t(gridDim.x) * kBlock;
+    for (int64_t k = int64_t(blockIdx.x) * kBlock + threadIdx.x; k < n; k += stride) out[k] = 0xffffffffu;
+}
+__global__ __launch_bounds__(kBlock) void entry_rows_kernel(int64_t rows, int64_t nnz,
+                                                            const long long *__restrict__ rects, long long k_base,
+                                                            uint32_t *__restrict__ out) {
+    const int64_t stride = int64_t(gridDim.x) * kBlock;
+    for (int64_t r = int64_t(blockIdx.x) * kBlock + threadIdx.x; r < rows; r += stride) {
+        long long lo = rects[2 * r] - k_base, hi = rects[2 * r + 1] - k_base;
+        if (lo < 0) lo = 0;
+        if (hi >= nnz) hi = nnz - 1;
+        for (long long k = lo; k <= hi; ++k) out[k] = static_cast<uint32_t>(r);
+    }
+}
+
+// out[c] = number of keys below c, for c = 0 .. nkeys, in an ascending key array: the row offsets of
+// the CSR structure whose rows are the keys.
+__global__ __launch_bounds__(kBlock) void sorted_key_offsets_kernel(int64_t n, const uint32_t *__restrict__ keys,
+                                                                    int64_t nkeys, uint32_t *__restrict__ out) {
+    const int64_t stride = int64_t(gridDim.x) * kBlock;
+    for (int64_t c = int64_t(blockIdx.x) * kBlock + threadIdx.x; c <= nkeys; c += stride) {
+        int64_t lo = 0, hi = n; // first position whose key is >= c
+        while (lo < hi) {
+            const int64_t mid = lo + (hi - lo) / 2;
+            if (static_cast<int64_t>(keys[mid]) < c) lo = mid + 1;
+            else hi = mid;
+        }
+        out[c] = static_cast<uint32_t>(lo);
+    }
+}
+
 template <typename E>
 __global__ __launch_bounds__(kBlock) void gather_kernel(int64_t n, const E *__restrict__ src,
                                                         const uint32_t *__restrict__ order, E *__restrict__ dst) {
@@ -443,6 +477,40 @@ int lsk_gather_f32(int64_t n, const float *src, const uint32_t *order, float *ds
 }
 int lsk_gather_f64(int64_t n, const double *src, const uint32_t *order, double *dst, lsk_stream_t stream) {
     return launch_gather<double>("lsk_gather_f64", n, src, order, dst, stream);
+}
+
+int lsk_csr_entry_rows_u32(int64_t rows, int64_t nnz, const int64_t *rects, int64_t k_base, uint32_t *row32,
+                           lsk_stream_t stream) {
+    if (rows < 0 || nnz < 0) return lsk::fail(LSK_ERR_ARG, "lsk_csr_entry_rows_u32: negative size");
+    if (rows > 0xfffffffeLL)
+        return lsk::fail(LSK_ERR_UNSUPPORTED, "lsk_csr_entry_rows_u32: %lld rows do not fit 32 bits", (long long)rows);
+    if (nnz == 0) return LSK_OK;
+    if (!row32 || (rows > 0 && !rects)) return lsk::fail(LSK_ERR_ARG, "lsk_csr_entry_rows_u32: null pointer");
+    hipStream_t s = lsk::as_stream(stream);
+    int blocks = grid_for(nnz);
+    if (blocks > 16 * lsk::kMaxGridBlocks) blocks = 16 * lsk::kMaxGridBlocks;
+    mark_all_kernel<<<blocks, kBlock, 0, s>>>(nnz, row32);
+    LSK_LAUNCH_CHECK();
+    if (rows == 0) return LSK_OK;
+    blocks = grid_for(rows);
+    if (blocks > 16 * lsk::kMaxGridBlocks) blocks = 16 * lsk::kMaxGridBlocks;
+    entry_rows_kernel<<<blocks, kBlock, 0, s>>>(rows, nnz, reinterpret_cast<const long long *>(rects), k_base, row32);
+    LSK_LAUNCH_CHECK();
+    return LSK_OK;
+}
+
+int lsk_sorted_key_offsets_u32(int64_t n, const uint32_t *keys, int64_t nkeys, uint32_t *offsets,
+                               lsk_stream_t stream) {
+    if (n < 0 || nkeys < 0) return lsk::fail(LSK_ERR_ARG, "lsk_sorted_key_offsets_u32: negative size");
+    if (n > 0xffffffffLL || nkeys > 0xfffffffeLL)
+        return lsk::fail(LSK_ERR_UNSUPPORTED, "lsk_sorted_key_offsets_u32: %lld entries, %lld keys do not fit 32 bits",
+                         (long long)n, (long long)nkeys);
+    if (!offsets || (n > 0 && !keys)) return lsk::fail(LSK_ERR_ARG, "lsk_sorted_key_offsets_u32: null pointer");
+    int blocks = grid_for(nkeys + 1);
+    if (blocks > 16 * lsk::kMaxGridBlocks) blocks = 16 * lsk::kMaxGridBlocks;
+    sorted_key_offsets_kernel<<<blocks, kBlock, 0, lsk::as_stream(stream)>>>(n, keys, nkeys, offsets);
+    LSK_LAUNCH_CHECK();
+    return LSK_OK;
 }
 
 int lsk_inclusive_sum_i64(int64_t n, const int64_t *in, int64_t *out, lsk_stream_t stream) {

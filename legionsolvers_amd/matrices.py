@@ -48,10 +48,75 @@ class AbstractMatrix:
                kernel_partition: PiecePartition, beta: int) -> None:
         raise NotImplementedError
 
-    def rmatvec(self, *args, **kwargs):
-        # CSRRmatvecTask / COORmatvecTask are assert(false) in the reference
-        # (src/CSRMatrixTasks.cpp:95-100, src/COOMatrixTasks.cpp:78-83).
-        raise NotImplementedError("rmatvec is not implemented (nor in the reference)")
+    def rmatvec(self, out: torch.Tensor, out_lo: int, out_hi: int, src: torch.Tensor, src_lo: int,
+                beta: int) -> None:
+        """out <- A_local^T src + beta out, where A_local is this rank's block of rows, `src` holds
+        the rank's rows (global index of src[0]: src_lo) and `out` the window out_lo..out_hi of the
+        domain.  CSRRmatvecTask / COORmatvecTask are registered by the reference but their bodies
+        are assert(false) (src/CSRMatrixTasks.cpp:95-100, src/COOMatrixTasks.cpp:78-83) and nothing
+        launches them; here the product runs on the transpose built once at set-up."""
+        raise NotImplementedError
+
+
+class TransposedBlock:
+    """CSR form, in the 32-bit structure, of the transpose of one rank's block of a matrix: one
+    row per element of the window x_lo..x_hi of the domain (columns outside it are dropped, as
+    every product drops them), column ids counted from the rank's first row.  Built by stable
+    sorts of the entries by column, so inside a row of the transpose the entries keep the order
+    they have in the matrix; products are deterministic (no atomics).
+
+    The entries are transposed in runs of at most CHUNK (a sort handles fewer than 2^31, and its
+    scratch stays bounded); every run becomes a structure of its own over the part of the window
+    its columns span, and the runs' products accumulate in order.  For row-sorted entries of a
+    banded matrix those parts barely overlap, so the extra passes over `out` are short."""
+
+    CHUNK = 1 << 30
+
+    def __init__(self, be, col: torch.Tensor, row32: torch.Tensor, val: torch.Tensor,
+                 x_lo: int, x_hi: int, local_rows: int):
+        """col: the int64 global column ids; row32: rows counted from the rank's first row."""
+        self.window = (int(x_lo), int(x_hi))
+        self.local_rows = int(local_rows)
+        self.parts = []  # (offset into the window, rows, row offsets, column ids, values, entries)
+        for k0 in range(0, val.numel() if x_hi >= x_lo else 0, self.CHUNK):
+            k1 = min(k0 + self.CHUNK, val.numel())
+            lo, hi = be.index_bounds(col[k0:k1])
+            lo, hi = max(lo, x_lo), min(hi, x_hi)
+            if hi < lo:
+                continue
+            extent = hi - lo + 1
+            keys = be.csr_compress_cols(col[k0:k1], lo, hi)
+            order = be.coo_block_order(keys, extent, 1)
+            keys = be.gather(keys, order)
+            rowoff = be.sorted_key_offsets(keys, extent)
+            del keys
+            nnz = int(rowoff[-1].item()) & 0xFFFFFFFF  # entries with a column inside the window
+            if nnz:
+                self.parts.append((lo - x_lo, extent, rowoff, be.gather(row32[k0:k1], order)[:nnz].clone(),
+                                   be.gather(val[k0:k1], order)[:nnz].clone(), nnz))
+
+    def apply(self, be, out: torch.Tensor, src: torch.Tensor, beta: int) -> None:
+        extent = self.window[1] - self.window[0] + 1
+        if out.numel() != max(extent, 0) or src.numel() != self.local_rows:
+            raise ValueError("rmatvec: vectors do not match the block the transpose was built for")
+        if extent <= 0:
+            return
+        whole = len(self.parts) == 1 and self.parts[0][1] == extent
+        if beta == 0 and not whole:
+            be.fill(out, 0)
+        for off, rows, rowoff, col32, val, nnz in self.parts:
+            be.csr_spmv(rows, nnz, rowoff, 0, col32, val, src, 0, self.local_rows - 1,
+                        out[off:off + rows], beta if whole else 1)
+
+
+def _transposed_for(matrix, out_lo: int, out_hi: int, src: torch.Tensor, src_lo: int) -> "TransposedBlock":
+    t = getattr(matrix, "_transposed", None)
+    if t is None or t.window != (out_lo, out_hi) or t.local_rows != src.numel() or matrix._transposed_origin != src_lo:
+        if out_hi - out_lo + 1 > matrix.ctx.backend.COMPRESS_MAX_EXTENT or src.numel() > matrix.ctx.backend.COMPRESS_MAX_EXTENT:
+            raise NotImplementedError("rmatvec: window or block of 2^32 - 1 elements or more")
+        t = matrix._transposed = matrix.transpose(out_lo, out_hi, src_lo, src.numel())
+        matrix._transposed_origin = src_lo
+    return t
 
 
 class CSRMatrix(AbstractMatrix):
@@ -76,6 +141,17 @@ class CSRMatrix(AbstractMatrix):
         self.col32 = None         # compress(): the column field as 32-bit offsets into ...
         self.col32_window = None  # ... this window (x_lo, x_hi)
         self.rowoff = {}          # ... and per piece colour rows + 1 32-bit offsets of the rows' entries
+
+    def transpose(self, x_lo: int, x_hi: int, row_lo: int, rows: int) -> TransposedBlock:
+        """The transpose of this rank's rows against the window x_lo..x_hi of the domain."""
+        if row_lo != self.row_lo or rows != self.rows:
+            raise ValueError("rmatvec: the source vector does not hold exactly this rank's rows")
+        be = self.ctx.backend
+        return TransposedBlock(be, self.col, be.csr_entry_rows(self.rects, self.k_base, self.nnz), self.val,
+                               x_lo, x_hi, rows)
+
+    def rmatvec(self, out, out_lo, out_hi, src, src_lo, beta):
+        _transposed_for(self, out_lo, out_hi, src, src_lo).apply(self.ctx.backend, out, src, beta)
 
     TUNE_MIN_ROWS = 1 << 21  # pieces below this are not worth the ~30 trial launches
     FUSE_DOT_MAX_ROW_LENGTH = 16.0
@@ -379,6 +455,16 @@ class COOMatrix(AbstractMatrix):
         self.row_origin = int(row_lo)
         self._try_column_blocks(x_lo, x_hi, kernel_partition, range_partition)
         return True
+
+    def transpose(self, x_lo: int, x_hi: int, row_lo: int, rows: int) -> TransposedBlock:
+        """The transpose of the entries whose row lies in row_lo..row_lo+rows-1 (this rank's rows)
+        against the window x_lo..x_hi of the domain."""
+        be = self.ctx.backend
+        return TransposedBlock(be, self.col, be.csr_compress_cols(self.row, row_lo, row_lo + rows - 1), self.val,
+                               x_lo, x_hi, rows)
+
+    def rmatvec(self, out, out_lo, out_hi, src, src_lo, beta):
+        _transposed_for(self, out_lo, out_hi, src, src_lo).apply(self.ctx.backend, out, src, beta)
 
     BLOCK_BYTES = 4 << 20        # of x per column block: what one XCD's L2 holds beside the stream
     BLOCK_MIN_WINDOW = 16 << 20  # smaller x windows are not worth re-ordering for

@@ -39,6 +39,7 @@ class _MatrixEntry:
         self.plan: HaloPlan = plan
         self.split = split   # CSRMatrix.halo_split: rows that can be multiplied before the halo lands
         self.staging = None  # ghost buffer for source vectors without halo room
+        self.rstaging = None  # rmatvec: the product over the whole window, and one landing buffer per peer
 
 
 class SquarePlanner:
@@ -305,6 +306,51 @@ class SquarePlanner:
             self._fused_dot_pending = frozenset((dst_idx, src_idx))
         else:
             self._fused_dot_pending = None
+
+    def rmatvec(self, dst_idx: int, src_idx: int) -> None:
+        """dst <- A^T src over all registered matrices: vector `src_idx` is read in every matrix's
+        range space, vector `dst_idx` written in its domain space.  The reference registers the
+        leaf tasks for this (src/Initialize.cpp:464-479) but their bodies are assert(false) and its
+        planner has no such method; it is what LSQR / BiCG-type solvers need.
+        Every process multiplies the transpose of its own block of rows, which yields sums over
+        the window of the domain its rows touch: the part it owns is added to dst, the rest is the
+        halo exchange of matvec run backwards -- sent to the owners, who add what arrives in
+        ascending order of the sender's rank (deterministic)."""
+        be, comm = self.ctx.backend, self.ctx.comm
+        touched = set()
+        for e in self.row_partitioned_matrices:
+            dst = self.get_vector(dst_idx, e.domain_index)
+            src = self.get_vector(src_idx, e.range_index)
+            first = e.domain_index not in touched
+            touched.add(e.domain_index)
+            dst._touch()
+            plan = e.plan
+            own_lo, own_hi = dst.own_lo, dst.own_hi
+            if not plan.recvs and not plan.sends:
+                e.matrix.rmatvec(dst.owned, own_lo, own_hi, src.owned, src.own_lo, 0 if first else 1)
+                continue
+            w_lo, w_hi = own_lo - plan.pad_lo, own_hi + plan.pad_hi
+            if e.rstaging is None:
+                e.rstaging = (be.empty(w_hi - w_lo + 1, self.dtype),
+                              [(t, be.empty(t.count, self.dtype)) for t in sorted(plan.sends, key=lambda t: t.peer)])
+            window, landing = e.rstaging
+            e.matrix.rmatvec(window, w_lo, w_hi, src.owned, src.own_lo, 0)
+            handle = comm.exchange_start(
+                [(t.peer, window[t.start - w_lo:t.start - w_lo + t.count]) for t in plan.recvs],
+                [(t.peer, buf) for t, buf in landing])
+            if dst.local_size:
+                mine = window[own_lo - w_lo:own_lo - w_lo + dst.local_size]
+                if first:
+                    be.copy(dst.owned, mine)
+                else:
+                    be.axpy(dst.owned, [], mine)   # no futures: alpha = 1
+            comm.exchange_finish(handle)
+            for t, buf in landing:
+                be.axpy(dst.owned[t.start - own_lo:t.start - own_lo + t.count], [], buf)
+        for i in range(self.get_num_spaces()):
+            if i not in touched:
+                self.get_vector(dst_idx, i).zero_fill()
+        self._fused_dot_pending = None
 
     def _fused_dot_pays(self) -> bool:
         """The fused product + dot is a bet on the caller's next dot product (CG wins it every

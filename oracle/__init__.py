@@ -152,6 +152,38 @@ def csr_matvec(rects, k_base, col, val, x, x_lo, x_hi, y, beta=0, literal=False,
         getattr(lib(), name + _SUF[dt])(*common, ctypes.c_int(beta))
 
 
+def coo_rmatvec(row, col, val, x, x_lo, x_hi, y, y_lo, y_hi) -> None:
+    """y[col-y_lo] += val * x[row-x_lo], entries visited in ascending order: the loop of
+    src/COOMatrixTasks.cpp:67-74 with the two index fields exchanged.  The reference's own
+    COORmatvecTask body is assert(false) (src/COOMatrixTasks.cpp:78-83), so this definition is
+    not pinned by any output of the reference: parity unpinned."""
+    coo_matvec(col, row, val, x, x_lo, x_hi, y, y_lo, y_hi)
+
+
+def csr_entry_rows(rects, k_base, nnz) -> np.ndarray:
+    """Row (0-based in rects) of every kernel entry k_base..k_base+nnz-1, -1 for an entry inside
+    no rect: the row field of the COO form of the same matrix."""
+    rects = _chk(rects, np.int64)
+    out = np.full(nnz, -1, dtype=np.int64)
+    for r in range(rects.shape[0]):
+        lo, hi = max(int(rects[r, 0]) - k_base, 0), min(int(rects[r, 1]) - k_base, nnz - 1)
+        if hi >= lo:
+            out[lo:hi + 1] = r
+    return out
+
+
+def csr_rmatvec(rects, k_base, col, val, x, x_lo, y, y_lo, y_hi, beta=0) -> None:
+    """y <- A^T x + beta y for the CSR rows `rects` (row r reads x[r], the global index of x[0] is
+    x_lo): coo_rmatvec over the entries in kernel order.  CSRRmatvecTask is assert(false) in the
+    reference (src/CSRMatrixTasks.cpp:95-100): parity unpinned."""
+    if not beta:
+        y[:] = 0
+    rows = csr_entry_rows(rects, k_base, val.size)
+    live = rows >= 0
+    coo_rmatvec(rows[live] + x_lo, _chk(col, np.int64)[live], val[live], x, x_lo, x_lo + rects.shape[0] - 1,
+                y, y_lo, y_hi)
+
+
 def rects_to_indptr(rects: np.ndarray) -> np.ndarray:
     """src/CuSPARSEHelpers.hpp:20-30."""
     rects = _chk(rects, np.int64)

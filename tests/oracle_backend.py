@@ -141,6 +141,23 @@ class OracleBackend:
             c = np.where(cu == 0xFFFFFFFF, x_lo - 1, cu + x_lo)
         oracle.coo_matvec(r, c, _np(val), _np(x), x_lo, x_hi, _np(y), y_lo, y_hi)
 
+    def csr_entry_rows(self, rects, k_base, nnz):
+        rows = oracle.csr_entry_rows(_np(rects), k_base, nnz)
+        return torch.from_numpy(np.where(rows < 0, 0xFFFFFFFF, rows).astype(np.uint32).view(np.int32))
+
+    def coo_block_order(self, col32, x_extent, block_cols):
+        u = _np(col32).view(np.uint32).astype(np.int64)
+        last = -(-max(x_extent, 1) // block_cols)
+        keys = np.where(u == 0xFFFFFFFF, last, u // block_cols)
+        return torch.from_numpy(np.argsort(keys, kind="stable").astype(np.uint32).view(np.int32))
+
+    def gather(self, src, order):
+        return src[torch.from_numpy(_np(order).view(np.uint32).astype(np.int64))].contiguous()
+
+    def sorted_key_offsets(self, keys, nkeys):
+        u = _np(keys).view(np.uint32).astype(np.int64)
+        return torch.from_numpy(np.searchsorted(u, np.arange(nkeys + 1), side="left").astype(np.uint32).view(np.int32))
+
     def csr_halo_rows(self, rows, nnz, rects, k_base, col, lo, hi):
         r, c = _np(rects), _np(col)
         below, above = -1, rows

@@ -277,3 +277,76 @@ def test_column_blocked_coo_follows_the_oracle(gpu_ctx, monkeypatch):
     want = opl.get_vector(0, 0)
     got = mpl.get_vector(0, 0).to_host().numpy()
     assert np.abs(got - want).max() <= 1e-9 * np.abs(want).max()
+
+
+@pytest.mark.parametrize("kind", ["csr", "coo"])
+@pytest.mark.parametrize("pieces", [1, 3])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_transposed_product_matches_oracle(gpu_ctx, kind, pieces, dtype, monkeypatch):
+    """SquarePlanner.rmatvec (CSRRmatvecTask / COORmatvecTask, assert(false) in the reference:
+    parity unpinned there) on an unsymmetric 27-point matrix against the oracle's entry-by-entry
+    loop; a second matrix into the same space accumulates; <A A^T y, y> = <A^T y, A^T y>."""
+    print(f"case rmatvec {kind} pieces={pieces} {np.dtype(dtype).name}", flush=True)
+    rects, row, col, val, n = hc.stencil_problem(4, (9, 7, 8), dtype=dtype)
+    rng = np.random.default_rng(11)
+    val = rng.standard_normal(val.size).astype(dtype)
+    y = rng.standard_normal(n).astype(dtype)
+    pl = hc.mirror_planner(gpu_ctx, kind, rects, row, col, val, n, pieces, dtype, y)
+    pl.allocate_workspace(2)
+    pl.rmatvec(2, 1)
+    got = pl.get_vector(2, 0).to_host().numpy()
+    want = np.zeros(n, dtype)
+    oracle.csr_rmatvec(rects, 0, col, val, y, 0, want, 0, n - 1)
+    tol = 1e-12 if dtype == np.float64 else 2e-5
+    np.testing.assert_allclose(got, want, rtol=tol, atol=tol)
+    pl.matvec(3, 2)
+    lhs, rhs = pl.dot(3, 1).get_value(), pl.dot(2, 2).get_value()
+    assert abs(lhs - rhs) <= 50 * tol * abs(rhs)
+    again = pl.get_vector(2, 0).to_host().numpy()
+    pl.rmatvec(2, 1)  # deterministic: the same bits on every call
+    assert np.array_equal(pl.get_vector(2, 0).to_host().numpy(), again)
+    # transposed in several runs of entries: the runs' products accumulate to the same sums
+    from legionsolvers_amd.matrices import TransposedBlock
+    monkeypatch.setattr(TransposedBlock, "CHUNK", 157)
+    pl.row_partitioned_matrices[0].matrix._transposed = None
+    pl.rmatvec(2, 1)
+    assert len(pl.row_partitioned_matrices[0].matrix._transposed.parts) > 3
+    np.testing.assert_allclose(pl.get_vector(2, 0).to_host().numpy(), want, rtol=tol, atol=tol)
+    pl.add_row_partitioned_matrix(pl.row_partitioned_matrices[0].matrix, 0, 0)
+    pl.rmatvec(2, 1)
+    np.testing.assert_allclose(pl.get_vector(2, 0).to_host().numpy(), 2 * want, rtol=tol, atol=2 * tol)
+
+
+def test_transposed_product_of_a_rectangular_window(gpu_ctx):
+    """The leaf level of rmatvec on a random matrix whose columns partly fall outside the output
+    window and whose kernel holds entries that no rect covers: both are dropped, as the oracle
+    drops them; the helper arrays are bit-exact."""
+    from legionsolvers_amd.matrices import CSRMatrix
+    be = gpu_ctx.backend
+    rng = np.random.default_rng(3)
+    rows, ncols, k_base, row_lo = 3000, 5000, 17, 40
+    counts = rng.integers(0, 9, rows)
+    gaps = rng.integers(0, 2, rows)          # stray entries between rects
+    lo = k_base + np.cumsum(np.concatenate([[0], (counts + gaps)[:-1]]))
+    rects = np.stack([lo, lo + counts - 1], axis=1).astype(np.int64)
+    nnz = int((counts + gaps).sum())
+    col = rng.integers(0, ncols, nnz).astype(np.int64)
+    val = rng.standard_normal(nnz)
+    x = rng.standard_normal(rows)
+    w_lo, w_hi = 700, 4100
+    print(f"case rmatvec leaf rows={rows} nnz={nnz} window={w_lo}..{w_hi}", flush=True)
+    row32 = be.csr_entry_rows(hc.to_dev(gpu_ctx, rects), k_base, nnz).cpu().numpy().view(np.uint32)
+    ref_rows = oracle.csr_entry_rows(rects, k_base, nnz)
+    assert np.array_equal(row32, np.where(ref_rows < 0, 0xFFFFFFFF, ref_rows).astype(np.uint32))
+    keys = np.sort(rng.integers(0, 50, 1000)).astype(np.uint32)
+    keys[-7:] = 0xFFFFFFFF
+    off = be.sorted_key_offsets(hc.to_dev(gpu_ctx, keys.view(np.int32)), 60).cpu().numpy().view(np.uint32)
+    assert np.array_equal(off, np.searchsorted(keys.astype(np.int64), np.arange(61), side="left"))
+    m = CSRMatrix(gpu_ctx, hc.to_dev(gpu_ctx, rects), k_base, hc.to_dev(gpu_ctx, col), hc.to_dev(gpu_ctx, val),
+                  IndexSpace(0, row_lo + rows - 1), row_lo)
+    out = torch.full((w_hi - w_lo + 1,), 0.5, dtype=torch.float64, device=gpu_ctx.device)
+    want = np.full(w_hi - w_lo + 1, 0.5)
+    for beta in (1, 0):
+        m.rmatvec(out, w_lo, w_hi, hc.to_dev(gpu_ctx, x), row_lo, beta)
+        oracle.csr_rmatvec(rects, k_base, col, val, x, row_lo, want, w_lo, w_hi, beta=beta)
+        np.testing.assert_allclose(out.cpu().numpy(), want, rtol=1e-12, atol=1e-13)

@@ -130,6 +130,39 @@ def test_solver_sequences_match_oracle(ctx, solver_name, dtype):
         assert [s.get_value() for s in sm.omega] == [float(v) for v in so.omega]
 
 
+@pytest.mark.parametrize("kind", ["csr", "coo"])
+@pytest.mark.parametrize("pieces", [1, 3])
+def test_transposed_product_matches_oracle(ctx, kind, pieces, monkeypatch):
+    """SquarePlanner.rmatvec on an unsymmetric matrix against the oracle's entry-by-entry loop and
+    against scipy; a second matrix into the same space accumulates; <A x, y> = <x, A^T y>."""
+    import scipy.sparse as sp
+    rects, row, col, val, n = hc.stencil_problem(4, (5, 4, 3))
+    rng = np.random.default_rng(11)
+    val = rng.standard_normal(val.size)
+    y = rng.standard_normal(n)
+    pl = hc.mirror_planner(ctx, kind, rects, row, col, val, n, pieces, np.float64, y)
+    pl.allocate_workspace(2)
+    pl.rmatvec(2, 1)
+    got = pl.get_vector(2, 0).to_host().numpy()
+    want = np.zeros(n)
+    oracle.csr_rmatvec(rects, 0, col, val, y, 0, want, 0, n - 1)
+    np.testing.assert_allclose(got, want, rtol=1e-13, atol=1e-14)
+    np.testing.assert_allclose(got, sp.coo_matrix((val, (row, col)), shape=(n, n)).T @ y, rtol=1e-12, atol=1e-13)
+    pl.matvec(3, 2)  # <A (A^T y), y> = <A^T y, A^T y>
+    lhs, rhs = pl.dot(3, 1).get_value(), pl.dot(2, 2).get_value()
+    assert abs(lhs - rhs) <= 1e-12 * abs(rhs)
+    # transposed in several runs of entries: the runs' products accumulate to the same sums
+    from legionsolvers_amd.matrices import TransposedBlock
+    monkeypatch.setattr(TransposedBlock, "CHUNK", 157)
+    pl.row_partitioned_matrices[0].matrix._transposed = None
+    pl.rmatvec(2, 1)
+    assert len(pl.row_partitioned_matrices[0].matrix._transposed.parts) > 3
+    np.testing.assert_allclose(pl.get_vector(2, 0).to_host().numpy(), want, rtol=1e-13, atol=1e-13)
+    pl.add_row_partitioned_matrix(pl.row_partitioned_matrices[0].matrix, 0, 0)
+    pl.rmatvec(2, 1)
+    np.testing.assert_allclose(pl.get_vector(2, 0).to_host().numpy(), 2 * want, rtol=1e-13, atol=1e-14)
+
+
 def test_planner_rejects_mismatched_inputs(ctx):
     ip4 = IndexPartition.equal(IndexSpace(0, 19), 4)
     ip2 = IndexPartition.equal(IndexSpace(0, 19), 2)
@@ -187,6 +220,13 @@ def _worker(rank, world, port, out_dir):
         solver.step()
         solver.step()
         results["gmres_sol"] = hc.gather_vector(ctx, pl.get_vector(0, 0))
+        # (d) transposed product of an unsymmetric matrix: the halo exchange run backwards
+        val_u = np.random.default_rng(7).standard_normal(val.size)
+        for kind in ("csr", "coo"):
+            pl = hc.mirror_planner(ctx, kind, rects, row, col, val_u, n, 4, np.float64, rhs)
+            pl.allocate_workspace(1)
+            pl.rmatvec(2, 1)
+            results[f"rmatvec_{kind}"] = hc.gather_vector(ctx, pl.get_vector(2, 0))
         if rank == 0:
             torch.save(results, os.path.join(out_dir, "results.pt"))
         dist.barrier()
@@ -213,6 +253,11 @@ def test_two_rank_gloo_matches_oracle(tmp_path, krylov_golden):
     so.step()
     so.step()
     np.testing.assert_allclose(res["gmres_sol"], opl.get_vector(0, 0), rtol=1e-9, atol=1e-12)
+    val_u = np.random.default_rng(7).standard_normal(val.size)
+    want = np.zeros(n)
+    oracle.csr_rmatvec(rects, 0, col, val_u, rhs, 0, want, 0, n - 1)
+    for kind in ("csr", "coo"):
+        np.testing.assert_allclose(res[f"rmatvec_{kind}"], want, rtol=1e-12, atol=1e-13)
 
 
 # ------------------------------------------------------------------ eight gloo ranks -------
