@@ -5,8 +5,11 @@
 // COO form of the matrix, -f32 1 uses float entries, -restart N sets GMRES's restart length
 // (the reference hard-codes 10), -history 1 prints the solver's scalar history one value per line,
 // -compress 0 / -fuse 0 / -redraws 0 turn the 32-bit structure, the held-back updates and the
-// set-up-time array redraws off.
+// set-up-time array redraws off, -adjoint N (after the solve) multiplies the solution by the
+// transpose and prints it against the product itself (the stencil matrices are symmetric) and both
+// sides of <A x, b> = <x, A^T b>; N > 1 transposes in runs of N entries.
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -20,7 +23,7 @@ namespace {
 
 struct Args {
     long dim = 1, solver = 1, nx = 16, ny = 16, nz = 16, vp = 4, it = 20, pt = 1;
-    long systems = 2, coo = 0, f32 = 0, restart = 10, history = 0, compress = 1, fuse = 1, redraws = 4;
+    long systems = 2, coo = 0, f32 = 0, restart = 10, history = 0, compress = 1, fuse = 1, redraws = 4, adjoint = 0;
 };
 
 Args parse(int argc, char **argv) {
@@ -30,7 +33,7 @@ Args parse(int argc, char **argv) {
         {"-nz", &Args::nz}, {"-vp", &Args::vp}, {"-it", &Args::it}, {"-pt", &Args::pt},
         {"-systems", &Args::systems}, {"-coo", &Args::coo}, {"-f32", &Args::f32}, {"-restart", &Args::restart},
         {"-history", &Args::history}, {"-compress", &Args::compress}, {"-fuse", &Args::fuse},
-        {"-redraws", &Args::redraws}};
+        {"-redraws", &Args::redraws}, {"-adjoint", &Args::adjoint}};
     for (int i = 1; i + 1 < argc; i += 2) {
         bool known = false;
         for (const auto &t : table)
@@ -79,6 +82,21 @@ void run(const Context &ctx, const Args &a, Solver &solver, SquarePlanner<T> &pl
         }
         std::printf("solution_sum %.17g\nsolution_sum_of_squares %.17g\n", sum, sum2);
     }
+    if (a.adjoint) { // vector 2 is workspace of every solver and free once the steps are done
+        planner.rmatvec(2, 0);
+        const auto atx = planner.get_vector(2, 0).to_host();
+        planner.matvec(2, 0);
+        const auto ax = planner.get_vector(2, 0).to_host();
+        double diff = 0.0, scale = 0.0;
+        for (size_t i = 0; i < ax.size(); ++i) {
+            diff = std::max(diff, std::fabs(static_cast<double>(atx[i]) - static_cast<double>(ax[i])));
+            scale = std::max(scale, std::fabs(static_cast<double>(ax[i])));
+        }
+        const double ax_b = static_cast<double>(planner.dot(2, 1).get());
+        planner.rmatvec(2, 1);
+        const double x_atb = static_cast<double>(planner.dot(0, 2).get());
+        std::printf("transposed_product_max_difference %.3g of %.3g\nadjoint %.17g %.17g\n", diff, scale, ax_b, x_atb);
+    }
 }
 
 template <typename T> int main_typed(const Args &a) {
@@ -94,10 +112,12 @@ template <typename T> int main_typed(const Args &a) {
     std::unique_ptr<AbstractMatrix<T>> matrix;
     if (a.coo)
         matrix = std::make_unique<COOMatrix<T>>(create_linearized_coo_stencil_matrix<T>(ctx, extent, st, partition));
-    else
-        matrix = std::make_unique<CSRMatrix<T>>(
-            create_linearized_csr_stencil_matrix<T>(ctx, extent, st, partition, a.compress != 0,
-                                                    static_cast<int>(a.redraws)));
+    else {
+        auto csr = std::make_unique<CSRMatrix<T>>(create_linearized_csr_stencil_matrix<T>(
+            ctx, extent, st, partition, a.compress != 0, static_cast<int>(a.redraws)));
+        if (a.adjoint > 1) csr->transpose_chunk = a.adjoint;
+        matrix = std::move(csr);
+    }
 
     std::vector<std::unique_ptr<PartitionedVector<T>>> sols, rhss;
     SquarePlanner<T> planner(ctx);

@@ -47,6 +47,7 @@ template <typename T> struct Abi;
         static constexpr auto csr_spmv_c32_tune = lsk_csr_spmv_c32_tune_##SUF;                     \
         static constexpr auto csr_spmv_tune = lsk_csr_spmv_tune_##SUF;                             \
         static constexpr auto coo_spmv = lsk_coo_spmv_##SUF;                                       \
+        static constexpr auto gather = lsk_gather_##SUF;                                           \
         static constexpr auto stencil_fill_csr = lsk_stencil_fill_csr_##SUF;                       \
         static constexpr auto stencil_fill_coo = lsk_stencil_fill_coo_##SUF;                       \
     }
@@ -366,7 +367,71 @@ public:
     virtual ~AbstractMatrix() = default;
     // dst <- beta * dst + A src, one leaf per colour of dst's partition
     virtual void matvec(PartitionedVector<T> &dst, const PartitionedVector<T> &src, int beta) const = 0;
+    // dst <- beta * dst + A^T src.  CSRRmatvecTask / COORmatvecTask are registered by the reference
+    // (src/Initialize.cpp:464-479) with bodies that are assert(false) (src/CSRMatrixTasks.cpp:95-100,
+    // src/COOMatrixTasks.cpp:78-83) and nothing launches them; here the product runs on the
+    // transpose, built on the first call.
+    virtual void rmatvec(PartitionedVector<T> &dst, const PartitionedVector<T> &src, int beta) const = 0;
     virtual bool accumulates_only() const = 0;
+};
+
+// The CSR form of the transpose of a matrix, in the library's 32-bit structure: one row per element
+// of the domain, column ids = the matrix's rows.  Built by stable sorts of the entries by column, in
+// runs of at most kChunk entries (a sort takes fewer than 2^31); every run becomes a structure of
+// its own over the interval of the domain its columns span, and the runs' products accumulate in
+// order.  Products are lsk_csr_spmv_c32_*: no atomics, the same bits on every call.
+template <typename T> class Transposed {
+public:
+    static constexpr int64_t kChunk = int64_t(1) << 30;
+    // col: the int64 global column of every entry; row32: its row (0xffffffff: entry to be dropped)
+    Transposed(const Context &ctx, int64_t nnz, const int64_t *col, const uint32_t *row32, const T *val,
+               int64_t domain, int64_t rows, int64_t chunk = kChunk)
+        : ctx_(&ctx), domain_(domain), rows_(rows) {
+        lsk_stream_t s = ctx.stream();
+        for (int64_t k0 = 0; k0 < nnz && domain > 0; k0 += chunk) {
+            const int64_t n = std::min(chunk, nnz - k0);
+            DeviceArray<int64_t> bounds(2);
+            check(lsk_index_bounds_i64(n, col + k0, bounds.get(), s));
+            const auto b = bounds.to_host(ctx);
+            Part p;
+            p.first = std::max<int64_t>(b[0], 0);
+            p.extent = std::min<int64_t>(b[1], domain - 1) - p.first + 1;
+            if (p.extent <= 0) continue;
+            DeviceArray<uint32_t> keys(n), order(n), sorted(n);
+            check(lsk_csr_compress_cols_u32(n, col + k0, p.first, p.first + p.extent - 1, keys.get(), s));
+            check(lsk_coo_block_order_u32(n, keys.get(), p.extent, 1, order.get(), s));
+            check(lsk_gather_u32(n, keys.get(), order.get(), sorted.get(), s));
+            p.offsets = DeviceArray<uint32_t>(p.extent + 1);
+            check(lsk_sorted_key_offsets_u32(n, sorted.get(), p.extent, p.offsets.get(), s));
+            p.nnz = p.offsets.to_host(ctx, p.extent, 1)[0]; // entries whose column lies inside the domain
+            if (p.nnz <= 0) continue;
+            p.col32 = DeviceArray<uint32_t>(n);
+            p.val = DeviceArray<T>(n);
+            check(lsk_gather_u32(n, row32 + k0, order.get(), p.col32.get(), s));
+            check(Abi<T>::gather(n, val + k0, order.get(), p.val.get(), s));
+            ctx.synchronize(); // the scratch arrays go out of scope
+            parts_.push_back(std::move(p));
+        }
+    }
+    int runs() const { return static_cast<int>(parts_.size()); }
+    void apply(T *out, const T *src, int beta) const {
+        if (domain_ <= 0) return;
+        const bool whole = parts_.size() == 1 && parts_[0].extent == domain_;
+        if (beta == 0 && !whole) check(Abi<T>::fill(domain_, T(0), out, ctx_->stream()));
+        for (const Part &p : parts_)
+            check(Abi<T>::csr_spmv_c32(p.extent, p.nnz, p.offsets.get(), p.col32.get(), p.val.get(), src, rows_,
+                                       out + p.first, whole ? beta : 1, ctx_->stream()));
+    }
+
+private:
+    struct Part {
+        int64_t first = 0, extent = 0, nnz = 0;
+        DeviceArray<uint32_t> offsets, col32;
+        DeviceArray<T> val;
+    };
+    const Context *ctx_;
+    int64_t domain_, rows_;
+    std::vector<Part> parts_;
 };
 
 // CSRMatrix<T> (src/CSRMatrix.hpp) in the reference's layout: per row a {lo, hi} rect of global
@@ -447,6 +512,20 @@ public:
                                        dst.piece(c), beta, ctx_->stream()));
         }
     }
+    void rmatvec(PartitionedVector<T> &dst, const PartitionedVector<T> &src, int beta) const override {
+        if (!(src.partition() == range_) || dst.partition().n != domain_)
+            throw std::invalid_argument("matrix and vectors do not fit");
+        if (!transposed_) {
+            DeviceArray<uint32_t> row32(col_.size());
+            check(lsk_csr_entry_rows_u32(range_.n, col_.size(), rects_.get(), 0, row32.get(), ctx_->stream()));
+            transposed_ = std::make_unique<Transposed<T>>(*ctx_, col_.size(), col_.get(), row32.get(), val_.get(),
+                                                          domain_, range_.n, transpose_chunk);
+        }
+        check(lsk_set_option("xcd_remap", 0));
+        transposed_->apply(dst.data(), src.data(), beta);
+    }
+    int transposed_runs() const { return transposed_ ? transposed_->runs() : 0; }
+    int64_t transpose_chunk = Transposed<T>::kChunk; // entries per run of the transposition (tests lower it)
 
 private:
     struct Piece {
@@ -506,6 +585,7 @@ private:
     DeviceArray<T> val_;
     DeviceArray<uint32_t> col32_;
     std::vector<Piece> pieces_;
+    mutable std::unique_ptr<Transposed<T>> transposed_;
 };
 
 // COOMatrix<T> (src/COOMatrix.hpp): int64 global row and column ids, T entries, row-sorted, so the
@@ -528,6 +608,18 @@ public:
                                    ctx_->stream()));
         }
     }
+    void rmatvec(PartitionedVector<T> &dst, const PartitionedVector<T> &src, int beta) const override {
+        if (!(src.partition() == range_) || dst.partition().n != domain_)
+            throw std::invalid_argument("matrix and vectors do not fit");
+        if (!transposed_) {
+            DeviceArray<uint32_t> row32(row_.size());
+            check(lsk_csr_compress_cols_u32(row_.size(), row_.get(), 0, range_.n - 1, row32.get(), ctx_->stream()));
+            transposed_ = std::make_unique<Transposed<T>>(*ctx_, col_.size(), col_.get(), row32.get(), val_.get(),
+                                                          domain_, range_.n);
+        }
+        check(lsk_set_option("xcd_remap", 0));
+        transposed_->apply(dst.data(), src.data(), beta);
+    }
 
 private:
     const Context *ctx_;
@@ -536,6 +628,7 @@ private:
     DeviceArray<int64_t> row_, col_;
     DeviceArray<T> val_;
     std::vector<std::pair<int64_t, int64_t>> entries_;
+    mutable std::unique_ptr<Transposed<T>> transposed_;
 };
 
 // SquarePlanner<T> (src/SquarePlanner.hpp): the solution / right-hand-side / workspace vectors of
@@ -601,6 +694,17 @@ public:
             if (!touched[e.range] && e.matrix->accumulates_only()) y.zero_fill();
             e.matrix->matvec(y, *vectors_.at(src)[e.domain], touched[e.range] || e.matrix->accumulates_only() ? 1 : 0);
             touched[e.range] = true;
+        }
+        for (size_t s = 0; s < touched.size(); ++s)
+            if (!touched[s]) vectors_[dst][s]->zero_fill();
+    }
+    // dst <- A^T src over all matrices: `src` is read in every matrix's range space, `dst` written in
+    // its domain space (the reference's planner has no such method).
+    void rmatvec(int dst, int src) {
+        std::vector<bool> touched(vectors_.at(dst).size(), false);
+        for (const auto &e : matrices_) {
+            e.matrix->rmatvec(*vectors_[dst][e.domain], *vectors_.at(src)[e.range], touched[e.domain] ? 1 : 0);
+            touched[e.domain] = true;
         }
         for (size_t s = 0; s < touched.size(); ++s)
             if (!touched[s]) vectors_[dst][s]->zero_fill();

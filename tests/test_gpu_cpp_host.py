@@ -28,7 +28,7 @@ def run(*flags):
     lines = res.stdout.splitlines()
     assert lines[0] == "Performed 5 warmup traces." and lines[1].startswith("Performed ")
     assert lines[2].startswith("Achieved ") and lines[2].endswith("ms per iteration.")
-    values = [l for l in lines[3:] if not l.startswith("solution_")]
+    values = [l for l in lines[3:] if not l[:1].isalpha()]
     sums = {l.split()[0]: float(l.split()[1]) for l in lines[3:] if l.startswith("solution_")}
     return [float(v) for v in values], sums, lines[3:]
 
@@ -82,3 +82,16 @@ def test_held_back_updates_print_the_same_solution(solver):
     hist_p, sums_p, _ = run(*flags, "-fuse", 0)
     np.testing.assert_allclose(hist_f, hist_p, rtol=1e-11)
     np.testing.assert_allclose(sums_f["solution_sum_of_squares"], sums_p["solution_sum_of_squares"], rtol=1e-10)
+
+
+@pytest.mark.parametrize("coo,f32,chunk", [(0, 0, 1), (0, 0, 5000), (1, 0, 1), (0, 1, 1)])
+def test_transposed_product(coo, f32, chunk):
+    """-adjoint: x after 4 CG steps times the transpose (built in one run of entries, or in runs of
+    5000) against x times the matrix, which is symmetric, and <A x, b> = <x, A^T b>."""
+    _, _, raw = run("-dim", 4, "-nx", 12, "-ny", 11, "-nz", 10, "-vp", 3, "-it", 4, "-systems", 1, "-coo", coo,
+                    "-f32", f32, "-adjoint", chunk)
+    diff, _, scale = [l for l in raw if l.startswith("transposed_product_max_difference")][0].split()[1:]
+    lhs, rhs = (float(v) for v in [l for l in raw if l.startswith("adjoint")][0].split()[1:])
+    tol = 1e-5 if f32 else 1e-13
+    assert float(scale) > 0.5 and float(diff) <= tol * float(scale)
+    assert abs(lhs - rhs) <= 100 * tol * abs(lhs)
