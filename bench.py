@@ -39,10 +39,11 @@ from legionsolvers_amd import benchmark_stencil as bs  # noqa: E402
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak
 
 
-def spmv_kernel_time(ctx, matrix, planner, reps: int, compressed: bool = True) -> float:
+def spmv_kernel_time(ctx, matrix, planner, reps: int, form: str) -> float:
     """Mean seconds of one CSR SpMV launch on this rank (the kernel alone, no halo traffic),
-    from HIP events recorded on the launch stream.  compressed=False times the form that reads
-    the reference's 64-bit columns and rects instead of the set-up-time 32-bit copies."""
+    from HIP events recorded on the launch stream.  form: "sliced" = whatever the planner launches
+    (the sliced-pattern copy when the matrix got one), "c32" = the set-up-time 32-bit copy of the
+    structure, "int64" = the reference's 64-bit columns and rects as handed over."""
     entry = planner.row_partitioned_matrices[0]
     src = planner.get_vector(2, 0)  # P
     dst = planner.get_vector(3, 0)  # Q
@@ -52,13 +53,15 @@ def spmv_kernel_time(ctx, matrix, planner, reps: int, compressed: bool = True) -
         x_lo, x_hi = x_lo - plan.pad_lo, x_hi + plan.pad_hi
     base = src.own_lo - src.pad_lo
     x = src.data[x_lo - base:x_hi - base + 1]
-    if not compressed:
-        held, matrix.col32_window = matrix.col32_window, None
-        try:
-            return spmv_kernel_time_inner(ctx, matrix, entry, dst, x, x_lo, x_hi, reps)
-        finally:
-            matrix.col32_window = held
-    return spmv_kernel_time_inner(ctx, matrix, entry, dst, x, x_lo, x_hi, reps)
+    held = matrix.sliced_window, matrix.col32_window
+    try:
+        if form in ("c32", "int64"):
+            matrix.sliced_window = None
+        if form == "int64":
+            matrix.col32_window = None
+        return spmv_kernel_time_inner(ctx, matrix, entry, dst, x, x_lo, x_hi, reps)
+    finally:
+        matrix.sliced_window, matrix.col32_window = held
 
 
 def spmv_kernel_time_inner(ctx, matrix, entry, dst, x, x_lo, x_hi, reps: int) -> float:
@@ -143,25 +146,43 @@ def main():
     iters_per_s = args.steps / seconds
     rr = solver.residual_norm_squared[-1].get_value()
 
-    # the dominant kernel against its roofline (this rank's launch)
-    # (bytes of the layout the kernel reads: 4-byte columns when the set-up copy exists, else 8)
+    # the dominant kernel against its roofline (this rank's launch), priced on the bytes of the
+    # layout it reads: the sliced-pattern copy (values in slices of 64 rows, no column array), else
+    # the 32-bit copy of the structure, else the 64-bit arrays as handed over
+    sliced = bool(matrix.sliced)
     compressed = matrix.col32 is not None
-    col_bytes = 4 if compressed else 8       # per entry, beside the 8-byte value
-    row_bytes = 4 + 16 if compressed else 32  # per row: offset or rect, x once, y once
-    t_spmv = spmv_kernel_time(ctx, matrix, planner, reps=20, compressed=compressed)
-    algo_bytes = matrix.nnz * (8 + col_bytes) + matrix.rows * row_bytes
-    achieved = algo_bytes / t_spmv / 1e9
-    spmv_gbps_job = ((nnz_total * (8 + col_bytes) + rows * row_bytes)
-                     / ctx.comm.max_over_ranks(t_spmv, ctx.device) / 1e9)
-    # the same product on the reference's own 64-bit column field, for comparison
-    t_spmv64 = spmv_kernel_time(ctx, matrix, planner, reps=20, compressed=False) if compressed else t_spmv
+    algo_bytes32 = matrix.nnz * 12 + matrix.rows * 20
     algo_bytes64 = matrix.nnz * 16 + matrix.rows * 32
-    traffic = traffic64 = None
+    if sliced:
+        parts = list(matrix.sliced.values())
+        algo_bytes = (sum(p.padded_entries for p in parts) * 8 + matrix.rows * 16 + sum(p.slices for p in parts) * 16
+                      + sum(p.masked_slices for p in parts) * 64 * 4 + sum(p.mixed_slices for p in parts) * 64)
+        kernel = "sliced_spmv_kernel<double, 9>"
+        layout = ("values copied once at set-up into slices of 64 rows, one column-pattern id per slice (27 "
+                  "patterns), no column array and no row offsets; every row summed in entry order, bit for bit "
+                  "the reference's CPU loop")
+    elif compressed:
+        algo_bytes, kernel = algo_bytes32, "csr_spmv_wave_kernel<double, unsigned int, 5, false, 8, false>"
+        layout = ("32-bit copies of the structure made once at set-up (window-relative columns, row offsets); "
+                  "bit-identical products")
+    else:
+        algo_bytes, kernel = algo_bytes64, "csr_spmv_wave_kernel<double, long, 5, false, 8, false>"
+        layout = "int64 global columns and 16-byte rects as handed over"
+    t_spmv = spmv_kernel_time(ctx, matrix, planner, reps=20, form="sliced")
+    achieved = algo_bytes / t_spmv / 1e9
+    # the whole job's product: every rank's bytes over the slowest rank's launch
+    job_bytes = ctx.comm.all_gather_object(algo_bytes)
+    spmv_gbps_job = sum(job_bytes) / ctx.comm.max_over_ranks(t_spmv, ctx.device) / 1e9
+    # the same product on the other layouts, for comparison
+    t_spmv32 = spmv_kernel_time(ctx, matrix, planner, reps=20, form="c32") if (sliced and compressed) else t_spmv
+    t_spmv64 = spmv_kernel_time(ctx, matrix, planner, reps=20, form="int64") if (sliced or compressed) else t_spmv
+    traffic = traffic32 = traffic64 = None
     traffic_file = os.path.join(REPO, "profiles", "spmv_hbm_traffic.json")
     if world == 1 and n1 == 512 and os.path.exists(traffic_file):
         measured = json.load(open(traffic_file))
         traffic64 = measured.get("bytes_per_launch")
-        traffic = measured.get("bytes_per_launch_c32") if compressed else traffic64
+        traffic32 = measured.get("bytes_per_launch_c32")
+        traffic = measured.get("bytes_per_launch_sliced") if sliced else traffic32 if compressed else traffic64
 
     # the reference's own set-up: two identical systems per step
     del solver, planner
@@ -188,9 +209,7 @@ def main():
                         "3-D 27-pt stencil, fp64 CSR with int64 indices and 16-byte row rects, "
                         "rhs=1, x0=0, one row block per GPU",
             "rows": rows, "nnz": nnz_total, "pieces": world,
-            "structure_layout": ("32-bit copies of the structure made once at set-up (window-relative columns, "
-                                 "row offsets); bit-identical products") if compressed
-                                else "int64 global columns and 16-byte rects as handed over",
+            "structure_layout": layout,
         },
         "spmv_gbps": spmv_gbps_job,
         "two_system_iters_per_s": two_system,
@@ -198,11 +217,16 @@ def main():
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-            "kernel": ("csr_spmv_wave_kernel<double, unsigned int, 5, false, 8, false>" if compressed
-                       else "csr_spmv_wave_kernel<double, long, 5, false, 8, false>"),
+            "kernel": kernel,
             "ms_per_launch": t_spmv * 1e3,
             "algorithmic_bytes_per_launch": algo_bytes,
-            "tile_placement": sorted(set(matrix.placement.values())) or [0],
+            "tile_placement": sorted(set((matrix.sliced_placement if sliced else matrix.placement).values())) or [0],
+        },
+        "roofline_32bit_structure": {
+            "bound": "hbm", "achieved": algo_bytes32 / t_spmv32 / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": algo_bytes32 / t_spmv32 / 1e9 / HBM_PEAK_GBPS, "traffic": traffic32,
+            "kernel": "csr_spmv_wave_kernel<double, unsigned int, 5, false, 8, false>", "ms_per_launch": t_spmv32 * 1e3,
+            "algorithmic_bytes_per_launch": algo_bytes32,
         },
         "roofline_int64_columns": {
             "bound": "hbm", "achieved": algo_bytes64 / t_spmv64 / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",

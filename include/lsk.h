@@ -441,6 +441,43 @@ int lsk_csr_entry_rows_u32(int64_t rows, int64_t nnz, const int64_t *rects, int6
 int lsk_sorted_key_offsets_u32(int64_t n, const uint32_t *keys, int64_t nkeys, uint32_t *offsets,
                                lsk_stream_t stream);
 
+/* ------------------------------------------------ CSR product on sliced row patterns --- */
+/* A set-up-time re-layout for CSR matrices whose rows repeat a few column patterns (every
+ * linearised stencil: col = row + one of a few lists of distances; at most 64 patterns of at most
+ * 32 entries).  lsk_csr_sliced_create_* gives every row the id of its pattern, verifies every entry
+ * against the pattern table, and copies the values into slices of 64 consecutive rows stored
+ * entry-major (short rows padded with zeros); lsk_csr_sliced_spmv_* then computes rows
+ * row_begin..row_end-1 of y <- A x + beta y from that copy alone: no column array and no row
+ * offsets are read.  Every row is summed by one lane in ascending entry order with separate
+ * multiply and add, which is bit for bit the loop of the reference's CPU task
+ * (src/CSRMatrixTasks.cpp:73-91); the reference's GPU task hands the arrays to cuSPARSE instead
+ * (src/CSRMatrixTasks.cu:117-150).
+ *
+ * rows, nnz, rects, k_base, col, val as lsk_csr_spmv_*; row_first = global index of rects' first
+ * row; x_lo..x_hi = the window of the input vector every product will be given (x[0] = element
+ * x_lo); y[0] = the first row.  The structure holds a COPY of the values: remake it when they change.
+ * create answers LSK_ERR_UNSUPPORTED (never an abort) when the matrix has no such structure
+ * (more patterns, longer rows, a column outside the window, rects outside the piece, or padding
+ * that would cost more than the column array saves): stay with lsk_csr_spmv_c32_* / lsk_csr_spmv_*.
+ * Set-up time: allocates, synchronises.  lsk_csr_sliced_info: out[0] = padded entries (the values
+ * one product reads), out[1] = slices, out[2] = slices whose rows fit no common distance list (every
+ * lane looks its own up), out[3] = patterns, out[4] = slices whose rows differ but are ordered parts
+ * of one list (run like uniform ones, with a 32-bit mask per row); out holds 5 values.
+ * Option "xcd_remap" places the workgroups as for lsk_csr_spmv_*. */
+typedef struct lsk_csr_sliced lsk_csr_sliced_t;
+int lsk_csr_sliced_create_f32(int64_t rows, int64_t nnz, const int64_t *rects, int64_t k_base, const int64_t *col,
+                              const float *val, int64_t row_first, int64_t x_lo, int64_t x_hi, lsk_stream_t stream,
+                              lsk_csr_sliced_t **out);
+int lsk_csr_sliced_create_f64(int64_t rows, int64_t nnz, const int64_t *rects, int64_t k_base, const int64_t *col,
+                              const double *val, int64_t row_first, int64_t x_lo, int64_t x_hi, lsk_stream_t stream,
+                              lsk_csr_sliced_t **out);
+int lsk_csr_sliced_spmv_f32(const lsk_csr_sliced_t *m, int64_t row_begin, int64_t row_end, const float *x, float *y,
+                            int beta, lsk_stream_t stream);
+int lsk_csr_sliced_spmv_f64(const lsk_csr_sliced_t *m, int64_t row_begin, int64_t row_end, const double *x, double *y,
+                            int beta, lsk_stream_t stream);
+int lsk_csr_sliced_info(const lsk_csr_sliced_t *m, int64_t *out);
+int lsk_csr_sliced_destroy(lsk_csr_sliced_t *m);
+
 /* ------------------------------------------------ set-up helpers (device side) ------ */
 /* out[0] = min idx[i], out[1] = max idx[i] (out = {INT64_MAX, INT64_MIN} when n == 0):
  * the bounding interval of create_partition_by_image over a column field

@@ -79,6 +79,12 @@ PROTOTYPES = {
     "lsk_gather_u32": (_i, [_i64, _p, _p, _p, _p]),
     "lsk_gather_f32": (_i, [_i64, _p, _p, _p, _p]),
     "lsk_gather_f64": (_i, [_i64, _p, _p, _p, _p]),
+    "lsk_csr_sliced_create_f32": (_i, [_i64, _i64, _p, _i64, _p, _p, _i64, _i64, _i64, _p, _p]),
+    "lsk_csr_sliced_create_f64": (_i, [_i64, _i64, _p, _i64, _p, _p, _i64, _i64, _i64, _p, _p]),
+    "lsk_csr_sliced_spmv_f32": (_i, [_p, _i64, _i64, _p, _p, _i, _p]),
+    "lsk_csr_sliced_spmv_f64": (_i, [_p, _i64, _i64, _p, _p, _i, _p]),
+    "lsk_csr_sliced_info": (_i, [_p, _p]),
+    "lsk_csr_sliced_destroy": (_i, [_p]),
     "lsk_csr_entry_rows_u32": (_i, [_i64, _i64, _p, _i64, _p, _p]),
     "lsk_sorted_key_offsets_u32": (_i, [_i64, _p, _i64, _p, _p]),
     "lsk_inclusive_sum_i64": (_i, [_i64, _p, _p, _p]),

@@ -166,6 +166,29 @@ class HipBackend:
         _lib.call(f"lsk_csr_spmv_{_lib.suffix(val.dtype)}", rows, nnz, _ptr(rects), k_base, _ptr(col),
                   _ptr(val), _ptr(x), x_lo, x_hi, _ptr(y), beta, self.stream())
 
+    def csr_sliced_create(self, rows: int, nnz: int, rects: torch.Tensor, k_base: int, col: torch.Tensor,
+                          val: torch.Tensor, row_first: int, x_lo: int, x_hi: int):
+        """The sliced-pattern copy of a CSR piece for products against the window x_lo..x_hi (a
+        SlicedStructure), or None when the matrix has no such structure.  Synchronises."""
+        handle = ctypes.c_void_p(0)
+        code = getattr(self.lib, f"lsk_csr_sliced_create_{_lib.suffix(val.dtype)}")(
+            rows, nnz, _ptr(rects), k_base, _ptr(col), _ptr(val), row_first, x_lo, x_hi, self.stream(),
+            ctypes.byref(handle))
+        if code == _lib.LSK_ERR_UNSUPPORTED:
+            return None
+        _lib.check(code)
+        return SlicedStructure(self.lib, handle, val.dtype)
+
+    def csr_sliced_spmv(self, sliced: "SlicedStructure", row_begin: int, row_end: int, x: torch.Tensor,
+                        y: torch.Tensor, beta: int, placement: int = 0) -> None:
+        """Rows row_begin..row_end-1 of y <- A x + beta y; x[0] is the window's first element, y[0] the
+        piece's first row."""
+        if placement != self._placement:
+            _lib.call("lsk_set_option", b"xcd_remap", placement)
+            self._placement = placement
+        _lib.call(f"lsk_csr_sliced_spmv_{_lib.suffix(sliced.dtype)}", sliced.handle, row_begin, row_end, _ptr(x),
+                  _ptr(y), beta, self.stream())
+
     def csr_spmv_tune(self, rows: int, nnz: int, rects: torch.Tensor, k_base: int, col: torch.Tensor,
                       val: torch.Tensor, x: torch.Tensor, x_lo: int, x_hi: int,
                       y: torch.Tensor) -> Tuple[int, float]:
@@ -274,3 +297,24 @@ class HipBackend:
         if not bool(live.any()):
             return (0, -1)
         return int(lo[live].min().item()), int(hi[live].max().item())
+
+
+class SlicedStructure:
+    """Owner of one lsk_csr_sliced_t (device memory held by the library, freed with this object)."""
+
+    def __init__(self, lib, handle, dtype):
+        self.lib, self.handle, self.dtype = lib, handle, dtype
+        out = (ctypes.c_int64 * 5)()
+        _lib.check(lib.lsk_csr_sliced_info(handle, out))
+        self.padded_entries, self.slices, self.mixed_slices, self.patterns, self.masked_slices = (int(v) for v in out)
+
+    def close(self) -> None:
+        if self.handle:
+            self.lib.lsk_csr_sliced_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -141,6 +141,9 @@ class CSRMatrix(AbstractMatrix):
         self.col32 = None         # compress(): the column field as 32-bit offsets into ...
         self.col32_window = None  # ... this window (x_lo, x_hi)
         self.rowoff = {}          # ... and per piece colour rows + 1 32-bit offsets of the rows' entries
+        self.sliced = {}          # slice_structure(): piece colour -> sliced-pattern copy of the piece ...
+        self.sliced_window = None # ... for products against this window
+        self.sliced_placement = {}
 
     def transpose(self, x_lo: int, x_hi: int, row_lo: int, rows: int) -> TransposedBlock:
         """The transpose of this rank's rows against the window x_lo..x_hi of the domain."""
@@ -163,6 +166,8 @@ class CSRMatrix(AbstractMatrix):
         override = os.environ.get("LSK_FUSE_SPMV_DOT")
         if override is not None:
             return override != "0"
+        if self.sliced:
+            return False  # the sliced-pattern product saves more bytes than the fused dot does
         return self.rows > 0 and self.nnz / self.rows <= self.FUSE_DOT_MAX_ROW_LENGTH
 
     def compress(self, x_lo: int, x_hi: int, kernel_partition, range_partition) -> bool:
@@ -194,6 +199,85 @@ class CSRMatrix(AbstractMatrix):
         self.rowoff = rowoff
         self.col32 = cols(self.col, x_lo, x_hi)
         self.col32_window = (int(x_lo), int(x_hi))
+        return True
+
+    SLICED_REDRAWS = 6
+
+    def slice_structure(self, x_lo: int, x_hi: int, kernel_partition, range_partition) -> bool:
+        """Set-up-time re-layout for matrices whose rows repeat a few column patterns (every
+        linearised stencil): per piece a copy of the values in slices of 64 rows plus one pattern id
+        per row; products against the window x_lo..x_hi then read no column array and no row
+        structure, and sum every row in entry order with separate multiply and add -- bit for bit
+        the loop of src/CSRMatrixTasks.cpp:73-91.  All pieces or none.  LSK_SLICED=0 turns it off.
+        For large pieces the tile placement is then chosen by timing, and the copy is made up to
+        SLICED_REDRAWS more times, keeping the fastest (where the driver puts an array in HBM
+        moves the product's time by several per cent)."""
+        be = self.ctx.backend
+        maker = getattr(be, "csr_sliced_create", None)
+        if maker is None or os.environ.get("LSK_SLICED", "1") == "0" or x_hi < x_lo or self.nnz == 0:
+            return False
+
+        def make(i, c):
+            p = range_partition.pieces[c]
+            k_lo, k_hi = kernel_partition.intervals[i]
+            nnz = max(k_hi - k_lo + 1, 0)
+            r0, off = p.lo[0] - self.row_lo, k_lo - self.k_base
+            return maker(p.volume, nnz, self.rects[r0:r0 + p.volume], k_lo, self.col[off:off + nnz],
+                         self.val[off:off + nnz], p.lo[0], x_lo, x_hi)
+
+        made = {}
+        for i, c in enumerate(kernel_partition.colors):
+            k_lo, k_hi = kernel_partition.intervals[i]
+            if range_partition.pieces[c].volume == 0 or k_hi < k_lo:
+                continue
+            made[c] = make(i, c)
+            if made[c] is None:
+                return False
+        if not made:
+            return False
+        self.sliced, self.sliced_window = made, (int(x_lo), int(x_hi))
+        if os.environ.get("LSK_TUNE", "1") == "0" or not self.val.is_cuda:
+            return True
+        x = y = None
+        redraws = int(os.environ.get("LSK_TUNE_REDRAWS", self.SLICED_REDRAWS))
+        for i, c in enumerate(kernel_partition.colors):
+            rows = range_partition.pieces[c].volume
+            if c not in made or rows < self.TUNE_MIN_ROWS:
+                continue
+            if x is None:
+                x = torch.zeros(x_hi - x_lo + 1, dtype=self.dtype, device=self.val.device)
+            if y is None or y.numel() < rows:
+                y = torch.empty(rows, dtype=self.dtype, device=self.val.device)
+
+            def timed(s, placement):
+                t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                be.csr_sliced_spmv(s, 0, rows, x, y, 0, placement)
+                t0.record()
+                for _ in range(3):
+                    be.csr_sliced_spmv(s, 0, rows, x, y, 0, placement)
+                t1.record()
+                t1.synchronize()
+                return t0.elapsed_time(t1) / 3
+
+            def best_of(s):
+                times = {pl: timed(s, pl) for pl in (0, 16, 64, 256, 1024, 4096)}
+                pl = min(times, key=times.get)
+                if os.environ.get("LSK_TUNE_VERBOSE"):
+                    print(f"[lsk] sliced product, piece {c}: " + ", ".join(f"{k}: {v:.3f} ms" for k, v in times.items()),
+                          file=sys.stderr, flush=True)
+                return pl, times[pl]
+
+            self.sliced_placement[c], best = best_of(self.sliced[c])
+            for _ in range(redraws):
+                other = make(i, c)      # a second copy while the first is alive: another place in HBM
+                if other is None:
+                    break
+                pl, t = best_of(other)
+                if t < best:
+                    self.sliced[c].close()
+                    self.sliced[c], self.sliced_placement[c], best = other, pl, t
+                else:
+                    other.close()
         return True
 
     def _structure(self, x_lo: int, x_hi: int, c: int, r0: int, ra: int, rb: int):
@@ -368,7 +452,8 @@ class CSRMatrix(AbstractMatrix):
         product."""
         range_partition = range_partition or dst.index_partition
         be = self.ctx.backend
-        fused = (dot_with is not None and beta == 0 and split is None
+        sliced = self.sliced if self.sliced_window == (x_lo, x_hi) else {}
+        fused = (dot_with is not None and beta == 0 and split is None and not sliced
                  and getattr(be, "csr_spmv_dot", None) is not None)
         touch = getattr(dst, "_touch", None)
         if touch is not None:
@@ -388,6 +473,9 @@ class CSRMatrix(AbstractMatrix):
                     if run_phase != phase:
                         continue
                     n_run = max(kb - ka + 1, 0)
+                    if c in sliced:
+                        be.csr_sliced_spmv(sliced[c], ra, rb, x, dst.piece(i), beta, self.sliced_placement.get(c, 0))
+                        continue
                     rowf, col = self._structure(x_lo, x_hi, c, r0, ra, rb)
                     if rowf.dtype == torch.int32:   # offsets count from the piece's first entry
                         off, n_arr = (k_lo - self.k_base) if nnz else 0, nnz
@@ -400,6 +488,9 @@ class CSRMatrix(AbstractMatrix):
                 continue
             if split is not None and phase == 0:
                 continue  # a piece without a split entry (no entries) goes with the late phase
+            if c in sliced:
+                be.csr_sliced_spmv(sliced[c], 0, rows, x, dst.piece(i), beta, self.sliced_placement.get(c, 0))
+                continue
             off = (k_lo - self.k_base) if nnz else 0
             rowf, col = self._structure(x_lo, x_hi, c, r0, 0, rows)
             args = (rows, nnz, rowf, k_lo if nnz else self.k_base,

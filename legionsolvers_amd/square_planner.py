@@ -119,8 +119,12 @@ class SquarePlanner:
         compress = getattr(matrix, "compress", None)
         if compress is not None and getattr(matrix, "col32", None) is None:
             compress(window[0], window[1], kernel_partition, range_partition)
+        slicer = getattr(matrix, "slice_structure", None)
+        if slicer is not None and not getattr(matrix, "_slice_tried", False):
+            slicer(window[0], window[1], kernel_partition, range_partition)
+            matrix._slice_tried = True
         tune = getattr(matrix, "tune", None)
-        if tune is not None and not getattr(matrix, "_tuned", False):
+        if tune is not None and not getattr(matrix, "_tuned", False) and not getattr(matrix, "sliced", None):
             tune(window[0], window[1], kernel_partition, range_partition)
             matrix._tuned = True
         split = None

@@ -155,17 +155,22 @@ def test_spmv_properties_at_headline_size(gpu_ctx):
     assert Az.dot(Az).get_value() ** 0.5 <= 1e-12 * (4 * Ax.dot(Ax).get_value() + 9 * Ay.dot(Ay).get_value()) ** 0.5
 
 
-def test_cg_with_tuned_placement(gpu_ctx, monkeypatch):
-    """The planner's set-up-time placement tuning (normally only for pieces of millions of rows)
-    forced on a small problem: same CG history as the oracle, whatever placement it picks."""
+@pytest.mark.parametrize("sliced", ["0", "1"])
+def test_cg_with_tuned_placement(gpu_ctx, monkeypatch, sliced):
+    """The planner's set-up-time placement tuning and array redraws (normally only for pieces of
+    millions of rows) forced on a small problem, for the product on the 32-bit structure and for the
+    one on the sliced-pattern copy: same CG history as the oracle, whatever placement it picks."""
     from legionsolvers_amd import CSRMatrix
     monkeypatch.setattr(CSRMatrix, "TUNE_MIN_ROWS", 1)
+    monkeypatch.setenv("LSK_SLICED", sliced)
     rects, row, col, val, n = hc.stencil_problem(4, (16, 16, 16), np.float64)
     rhs = np.random.default_rng(32).standard_normal(n)
     opl = hc.oracle_planner("csr", rects, row, col, val, n, 2, np.float64, rhs)
     mpl = hc.mirror_planner(gpu_ctx, "csr", rects, row, col, val, n, 2, np.float64, rhs)
     matrix = mpl.row_partitioned_matrices[0].matrix
-    assert sorted(matrix.placement) == [0, 1] and all(v in (0, 16, 64, 256, 1024, 4096) for v in matrix.placement.values())
+    chosen = matrix.sliced_placement if sliced == "1" else matrix.placement
+    assert bool(matrix.sliced) == (sliced == "1")
+    assert sorted(chosen) == [0, 1] and all(v in (0, 16, 64, 256, 1024, 4096) for v in chosen.values())
     so, sm = S.CGSolver(opl), CGSolver(mpl)
     for _ in range(8):
         so.step()
@@ -179,7 +184,9 @@ def test_cg_with_tuned_placement(gpu_ctx, monkeypatch):
 def test_compressed_structure_gives_the_same_history(gpu_ctx, monkeypatch, dtype, solver_name):
     """The planner's set-up-time 32-bit copy of the CSR structure (on by default) and the products
     straight on the reference's int64 columns and rects (LSK_COMPRESS=0) give bit-identical
-    residual histories: same tiles, same order of additions."""
+    residual histories: same tiles, same order of additions.  (The sliced-pattern structure, which a
+    stencil matrix would get on top, is switched off here.)"""
+    monkeypatch.setenv("LSK_SLICED", "0")
     rects, row, col, val, n = hc.stencil_problem(4, (20, 12, 16), dtype)
     rhs = np.random.default_rng(33).standard_normal(n).astype(dtype)
     histories = []
@@ -350,3 +357,29 @@ def test_transposed_product_of_a_rectangular_window(gpu_ctx):
         m.rmatvec(out, w_lo, w_hi, hc.to_dev(gpu_ctx, x), row_lo, beta)
         oracle.csr_rmatvec(rects, k_base, col, val, x, row_lo, want, w_lo, w_hi, beta=beta)
         np.testing.assert_allclose(out.cpu().numpy(), want, rtol=1e-12, atol=1e-13)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("pieces", [1, 3])
+def test_sliced_pattern_structure_is_used_and_bit_exact(gpu_ctx, monkeypatch, dtype, pieces):
+    """A stencil matrix gets the sliced-pattern structure at registration; the planner's product on
+    it equals the oracle's ascending-k loop bit for bit, and CG follows the oracle's history."""
+    rects, row, col, val, n = hc.stencil_problem(4, (11, 9, 21), dtype)
+    val = np.random.default_rng(40).standard_normal(val.size).astype(dtype)
+    rhs = np.random.default_rng(41).standard_normal(n).astype(dtype)
+    print(f"case sliced planner {np.dtype(dtype).name} pieces={pieces}", flush=True)
+    mpl = hc.mirror_planner(gpu_ctx, "csr", rects, row, col, val, n, pieces, dtype, rhs)
+    matrix = mpl.row_partitioned_matrices[0].matrix
+    assert sorted(matrix.sliced) == list(range(pieces)) and not matrix.fuses_dot()
+    mpl.allocate_workspace(1)
+    mpl.matvec(2, 1)
+    want = np.zeros(n, dtype)
+    oracle.csr_matvec(rects, 0, col, val, rhs, 0, n - 1, want)
+    assert np.array_equal(mpl.get_vector(2, 0).to_host().numpy(), want)
+    monkeypatch.setenv("LSK_SLICED", "0")
+    mpl0 = hc.mirror_planner(gpu_ctx, "csr", rects, row, col, val, n, pieces, dtype, rhs)
+    assert not mpl0.row_partitioned_matrices[0].matrix.sliced
+    mpl0.allocate_workspace(1)
+    mpl0.matvec(2, 1)
+    tol = 1e-12 if dtype == np.float64 else 1e-4
+    np.testing.assert_allclose(mpl0.get_vector(2, 0).to_host().numpy(), want, rtol=tol, atol=tol)

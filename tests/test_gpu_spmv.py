@@ -666,3 +666,117 @@ def test_device_stencil_generator_bit_exact(gpu_ctx, suf, flag, extent):
             assert gp.intervals[i] == part.bounds(part.image(col, want_k, (0, n - 1)))
         kc = c.create_kernel_partition_from_range_partition(ip)
         assert kc.intervals == kp.intervals  # preimage of rows == image-range of rects here
+
+
+# ------------------------------------------------------------------ sliced row patterns -----
+
+def sliced_case(suf, rects, k_base, col, val, x, x_lo, x_hi, row_first, tag, expect=True):
+    """lsk_csr_sliced_create_* + lsk_csr_sliced_spmv_* on a piece: bit-exact against the oracle's
+    ascending-k loop (separate multiply and add), for beta = 0 and 1 and for a range of rows."""
+    npdt, tdt, _ = DT[suf]
+    rows = rects.shape[0]
+    print(f"case csr_sliced_{suf} {tag} rows={rows} nnz={val.size} k_base={k_base} x=[{x_lo},{x_hi}] "
+          f"row_first={row_first}", flush=True)
+    rd, cd, vd, xd = dev(rects), dev(col), dev(val), dev(x)
+    handle = ctypes.c_void_p(0)
+    code = getattr(_lib.lib(), f"lsk_csr_sliced_create_{suf}")(rows, val.size, P(rd), k_base, P(cd), P(vd), row_first,
+                                                             x_lo, x_hi, stream(), ctypes.byref(handle))
+    if not expect:
+        assert code == _lib.LSK_ERR_UNSUPPORTED and not handle.value, f"{tag}: create said {code}"
+        return None
+    assert code == _lib.LSK_OK, f"{tag}: create said {code}: {_lib.lib().lsk_last_error().decode()}"
+    info = (ctypes.c_int64 * 5)()
+    _lib.call("lsk_csr_sliced_info", handle, info)
+    lens = np.maximum(rects[:, 1] - rects[:, 0] + 1, 0)
+    padded = sum(64 * int(lens[s:s + 64].max()) for s in range(0, rows, 64))
+    assert info[0] == padded and info[1] == -(-rows // 64), f"{tag}: info {list(info)}"
+    try:
+        rng = np.random.default_rng(rows)
+        y0 = rng.standard_normal(rows).astype(npdt)
+        for beta, (ra, rb) in ((0, (0, rows)), (1, (0, rows)), (0, (rows // 3, rows - rows // 5)), (1, (1, min(rows, 66)))):
+            want = y0.copy()
+            part = want[ra:rb].copy()
+            oracle.csr_matvec(rects[ra:rb], k_base, col, val, x, x_lo, x_hi, part, beta=beta)
+            want[ra:rb] = part
+            yd = dev(y0)
+            _lib.call(f"lsk_csr_sliced_spmv_{suf}", handle, ra, rb, P(xd), P(yd), beta, stream())
+            got = yd.cpu().numpy()
+            assert np.array_equal(got.view(np.uint8), want.view(np.uint8)), \
+                f"{tag}: beta={beta} rows {ra}..{rb}: {int((got != want).sum())} rows differ"
+    finally:
+        _lib.call("lsk_csr_sliced_destroy", handle)
+    return list(info)
+
+
+@pytest.mark.parametrize("suf", ["f64", "f32"])
+def test_csr_sliced_patterns_bit_exact(suf):
+    npdt = DT[suf][0]
+    rng = np.random.default_rng(17)
+    for flag, extent in ((1, (1000,)), (2, (37, 41)), (3, (9, 11, 13)), (4, (7, 12, 70)), (4, (3, 3, 3))):
+        offs, cfs = oracle.benchmark_stencil_offsets(flag)
+        rects, _, col, val = oracle.linearized_stencil(extent, offs, cfs, dtype=npdt, coo=True)
+        n = int(np.prod(extent))
+        val = rng.standard_normal(val.size).astype(npdt)  # no two entries alike
+        x = rng.standard_normal(n).astype(npdt)
+        if n < 64:  # one slice, padded from 343 to 64 * 27 entries: not worth it
+            sliced_case(suf, rects, 0, col, val, x, 0, n - 1, 0, f"stencil{flag}{extent}", expect=False)
+            continue
+        info = sliced_case(suf, rects, 0, col, val, x, 0, n - 1, 0, f"stencil{flag}{extent}")
+        assert info[3] <= 27
+        # a piece in the middle: rows a..b of the matrix, entries from k_base, x window = its ghost interval
+        a, b = n // 3, n - n // 4
+        k_lo, k_hi = int(rects[a, 0]), int(rects[b - 1, 1])
+        pc, pv = col[k_lo:k_hi + 1], val[k_lo:k_hi + 1]
+        x_lo, x_hi = int(pc.min()), int(pc.max())
+        sliced_case(suf, rects[a:b], k_lo, pc, pv, x[x_lo:x_hi + 1], x_lo, x_hi, a, f"stencil{flag}{extent} piece")
+        # ... and with a window that misses a column: no structure
+        if x_hi > x_lo + 1:
+            sliced_case(suf, rects[a:b], k_lo, pc, pv, x[x_lo + 1:x_hi + 1], x_lo + 1, x_hi, a,
+                        f"stencil{flag}{extent} short window", expect=False)
+
+
+def test_csr_sliced_patterns_decline():
+    """Matrices without a few repeating row patterns, rows longer than a pattern may be, rects outside
+    the piece: LSK_ERR_UNSUPPORTED, no structure, no abort."""
+    rng = np.random.default_rng(5)
+    rows, per = 4000, 6
+    col = np.sort(rng.integers(0, rows, (rows, per)), axis=1).reshape(-1).astype(np.int64)
+    lo = np.arange(rows, dtype=np.int64) * per
+    rects = np.stack([lo, lo + per - 1], axis=1)
+    val = rng.standard_normal(rows * per)
+    x = rng.standard_normal(rows)
+    sliced_case("f64", rects, 0, col, val, x, 0, rows - 1, 0, "random columns", expect=False)
+    # rows of 40 entries (a band): one pattern, but longer than the table's rows
+    rows, per = 300, 40
+    lo = np.arange(rows, dtype=np.int64) * per
+    rects = np.stack([lo, lo + per - 1], axis=1)
+    col = (np.arange(rows)[:, None] + np.arange(per)[None, :]).reshape(-1).astype(np.int64)
+    sliced_case("f64", rects, 0, col, rng.standard_normal(rows * per), rng.standard_normal(rows + per), 0,
+                rows + per - 1, 0, "long rows", expect=False)
+    # heavy padding: one long row per slice among empty ones
+    rows = 640
+    lens = np.where(np.arange(rows) % 64 == 0, 20, 0)
+    hi = np.cumsum(lens) - 1
+    rects = np.stack([hi - lens + 1, hi], axis=1).astype(np.int64)
+    col = np.concatenate([r + np.arange(20) for r in range(0, rows, 64)]).astype(np.int64)
+    sliced_case("f64", rects, 0, col, rng.standard_normal(col.size), rng.standard_normal(rows + 20), 0, rows + 19, 0,
+                "mostly padding", expect=False)
+    # a rect that points outside the piece's entries
+    rects = np.array([[0, 2], [3, 9]], dtype=np.int64)
+    sliced_case("f64", rects, 0, np.arange(6, dtype=np.int64), rng.standard_normal(6), rng.standard_normal(6), 0, 5, 0,
+                "rect outside", expect=False)
+
+
+def test_csr_sliced_mixed_and_gapped_rows():
+    """Rows with gaps between their rects and empty rows (patterns of length 0) share slices with
+    full rows: the mixed-pattern path."""
+    rng = np.random.default_rng(8)
+    offs, cfs = oracle.benchmark_stencil_offsets(2)
+    rects, _, col, val = oracle.linearized_stencil((30, 9), offs, cfs, dtype=np.float64, coo=True)
+    rects = rects.copy()
+    rects[::7, 1] = rects[::7, 0] - 1        # every 7th row empty
+    rects[1::5, 1] -= 1                      # every 5th row ignores its last entry
+    n = 270
+    info = sliced_case("f64", rects, 0, col, rng.standard_normal(val.size), rng.standard_normal(n), 0, n - 1, 0,
+                       "gapped rects")
+    assert info[2] + info[4] == info[1]  # every slice mixes patterns

@@ -25,23 +25,32 @@ A = sg.create_linearized_csr_stencil_matrix(ctx, (n1, n1, n1), offs, cfs, ip)
 kp = A.create_kernel_partition_from_range_partition(ip)
 A.compress(0, rows - 1, kp, ip)  # the planner's set-up: 32-bit structure (unless LSK_COMPRESS=0) ...
 A.tune(0, rows - 1, kp, ip)      # ... and the tile placement
+A.slice_structure(0, rows - 1, kp, ip)  # ... and the sliced-pattern copy (unless LSK_SLICED=0)
 x = PartitionedVector(ctx, "x", ip)
 y = PartitionedVector(ctx, "y", ip)
 x.owned.copy_(torch.randn(rows, device="cuda", dtype=torch.float64))
 y.zero_fill()
+held_sliced, A.sliced_window = A.sliced_window, None
 if A.col32 is not None:  # the form that reads the 64-bit columns and rects, for comparison
     held, A.col32_window = A.col32_window, None
     for _ in range(3):
         A.matvec(y, x.owned, 0, rows - 1, kp, 0)
     A.col32_window = held
-for _ in range(3):
+for _ in range(3):           # the 32-bit structure
     A.matvec(y, x.owned, 0, rows - 1, kp, 0)
+A.sliced_window = held_sliced
+if A.sliced:
+    for _ in range(3):       # the sliced-pattern copy
+        A.matvec(y, x.owned, 0, rows - 1, kp, 0)
 a = Scalar(ctx, 0.5, torch.float64)
 for _ in range(3):
     x.dot(y)
     y.axpy(a, x)
 ctx.synchronize()
-print(f"tile placement {A.placement}")
+print(f"tile placement {A.placement} sliced {A.sliced_placement}")
+if A.sliced:
+    s = A.sliced[0]
+    print(f"sliced_algorithmic_bytes={s.padded_entries * 8 + rows * 16 + s.slices * 16 + s.masked_slices * 256 + s.mixed_slices * 64}")
 print(f"rows={rows} nnz={A.nnz} spmv_algorithmic_bytes={A.nnz * 16 + rows * 32} "
       f"spmv_c32_algorithmic_bytes={A.nnz * 12 + rows * 20} "
       f"dot_bytes={rows * 16} axpy_read_bytes={rows * 16} axpy_write_bytes={rows * 8}")

@@ -2,7 +2,8 @@
 """HBM-side traffic of one CSR SpMV launch from the two rocprofv3 --pmc passes over
 tools/pmc_spmv.py (FETCH_SIZE and WRITE_SIZE, each its own run):
 
-    python tools/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json>
+    python tools/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json> \
+        [placement text] [sliced_algorithmic_bytes]
 
 FETCH_SIZE is reported in KiB and tallies a 128-byte read request as 64 bytes on gfx950; the dot
 product in the same run (2 * rows * 8 bytes read, nothing else) calibrates that factor."""
@@ -17,7 +18,8 @@ def means(path, counter):
         if r["Counter_Name"] != counter:
             continue
         name = r["Kernel_Name"]
-        key = ("spmv_c32" if "csr_spmv" in name and "unsigned int" in name else
+        key = ("spmv_sliced" if "sliced_spmv" in name else
+               "spmv_c32" if "csr_spmv" in name and "unsigned int" in name else
                "spmv" if "csr_spmv" in name else "dot" if "dot_kernel" in name else None)
         if key:
             acc.setdefault(key, []).append(float(r["Counter_Value"]))
@@ -42,6 +44,12 @@ def main():
         c32 = {"bytes_per_launch_c32": int(round(t32)), "algorithmic_bytes_per_launch_c32": a32,
                "ratio_traffic_over_algorithmic_c32": t32 / a32,
                "FETCH_SIZE_KB_mean_c32": f["spmv_c32"], "WRITE_SIZE_KB_mean_c32": w["spmv_c32"]}
+    if "spmv_sliced" in f:  # the sliced-pattern copy: algorithmic bytes as tools/pmc_spmv.py prints them
+        ts = factor * f["spmv_sliced"] * 1024 + w["spmv_sliced"] * 1024
+        a_s = int(sys.argv[5]) if len(sys.argv) > 5 else None
+        c32.update({"bytes_per_launch_sliced": int(round(ts)), "algorithmic_bytes_per_launch_sliced": a_s,
+                    "ratio_traffic_over_algorithmic_sliced": ts / a_s if a_s else None,
+                    "FETCH_SIZE_KB_mean_sliced": f["spmv_sliced"], "WRITE_SIZE_KB_mean_sliced": w["spmv_sliced"]})
     json.dump({
         "workload": "csr_spmv f64, 27-pt 512^3, 1 GPU",
         "tile_placement": placement,

@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Launch time of the sliced-pattern CSR product beside the 32-bit-structure product on the
+headline matrix (27-point stencil, fp64, one GPU).
+
+    LSK_TUNE_VERBOSE=1 python tools/sliced_rate.py [n]      (grid n^3, default 512)
+"""
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from legionsolvers_amd import Context  # noqa: E402
+from legionsolvers_amd import benchmark_stencil as bs  # noqa: E402
+
+
+def timed(ctx, fn, reps):
+    fn()
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    ctx.synchronize()
+    return (time.perf_counter() - t0) / reps * 1e3
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+    ctx = Context(torch.device("cuda", 0))
+    t0 = time.perf_counter()
+    matrix, planner, solver = bs.build_problem(ctx, 4, n, n, n, 1, 1, torch.float64, num_systems=1)
+    ctx.synchronize()
+    setup = time.perf_counter() - t0
+    planner.get_vector(2, 0).random_fill(1)
+    out = {"grid": n, "rows": matrix.rows, "nnz": matrix.nnz, "setup_s": round(setup, 2)}
+    if matrix.sliced:
+        s = matrix.sliced[0]
+        out["sliced_ms"] = round(timed(ctx, lambda: planner.matvec(3, 2), 20), 3)
+        out["sliced_bytes"] = (s.padded_entries * 8 + matrix.rows * 16 + s.slices * 16 + s.mixed_slices * 64
+                               + s.masked_slices * 256)
+        out["sliced_TBps"] = round(out["sliced_bytes"] / out["sliced_ms"] / 1e9, 3)
+        out.update(patterns=s.patterns, mixed_slices=s.mixed_slices, masked_slices=s.masked_slices, slices=s.slices, padded_entries=s.padded_entries,
+                   placement=matrix.sliced_placement)
+        a = planner.get_vector(3, 0).owned.clone()
+        held, matrix.sliced_window = matrix.sliced_window, None
+        out["c32_ms"] = round(timed(ctx, lambda: planner.matvec(3, 2), 20), 3)
+        matrix.sliced_window = held
+        b = planner.get_vector(3, 0).owned
+        out["max_rel_diff_vs_c32"] = float((a - b).abs().max() / b.abs().max())
+        out["cg_ms_per_step"] = round(timed(ctx, solver.step, 30), 3)
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()
