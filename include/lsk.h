@@ -475,6 +475,17 @@ int lsk_csr_sliced_spmv_f32(const lsk_csr_sliced_t *m, int64_t row_begin, int64_
                             int beta, lsk_stream_t stream);
 int lsk_csr_sliced_spmv_f64(const lsk_csr_sliced_t *m, int64_t row_begin, int64_t row_end, const double *x, double *y,
                             int beta, lsk_stream_t stream);
+/* The same product, and partials[0 .. *count) <- sums over groups of 256 rows of y_new[r] * w[r]
+ * (w[0] pairs with the structure's first row, like y), formed from values still in registers and
+ * added in a fixed order whatever the placement; lsk_sum_partials_* gives the dot product (CG's
+ * p.Ap, src/CGSolver.hpp:46-47, without a pass over y and w).  capacity >= one per 256 rows of
+ * row_begin/64*64 .. row_end, rounded up; *count is written on the host. */
+int lsk_csr_sliced_spmv_dot_f32(const lsk_csr_sliced_t *m, int64_t row_begin, int64_t row_end, const float *x, float *y,
+                                int beta, const float *w, float *partials, int64_t capacity, int64_t *count,
+                                lsk_stream_t stream);
+int lsk_csr_sliced_spmv_dot_f64(const lsk_csr_sliced_t *m, int64_t row_begin, int64_t row_end, const double *x, double *y,
+                                int beta, const double *w, double *partials, int64_t capacity, int64_t *count,
+                                lsk_stream_t stream);
 int lsk_csr_sliced_info(const lsk_csr_sliced_t *m, int64_t *out);
 int lsk_csr_sliced_destroy(lsk_csr_sliced_t *m);
 

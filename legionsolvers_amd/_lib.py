@@ -18,6 +18,7 @@ LIB_PATH = os.environ.get("LSK_LIBRARY") or os.path.join(PKG_DIR, "liblsk.so")  
 HEADER_PATH = os.path.join(os.path.dirname(PKG_DIR), "include", "lsk.h")
 
 LSK_OK = 0
+LSK_ERR_ARG = -2
 LSK_ERR_UNSUPPORTED = -4
 UNIQUE_ID_BYTES = 128
 
@@ -83,6 +84,8 @@ PROTOTYPES = {
     "lsk_csr_sliced_create_f64": (_i, [_i64, _i64, _p, _i64, _p, _p, _i64, _i64, _i64, _p, _p]),
     "lsk_csr_sliced_spmv_f32": (_i, [_p, _i64, _i64, _p, _p, _i, _p]),
     "lsk_csr_sliced_spmv_f64": (_i, [_p, _i64, _i64, _p, _p, _i, _p]),
+    "lsk_csr_sliced_spmv_dot_f32": (_i, [_p, _i64, _i64, _p, _p, _i, _p, _p, _i64, _p, _p]),
+    "lsk_csr_sliced_spmv_dot_f64": (_i, [_p, _i64, _i64, _p, _p, _i, _p, _p, _i64, _p, _p]),
     "lsk_csr_sliced_info": (_i, [_p, _p]),
     "lsk_csr_sliced_destroy": (_i, [_p]),
     "lsk_csr_entry_rows_u32": (_i, [_i64, _i64, _p, _i64, _p, _p]),

@@ -189,6 +189,21 @@ class HipBackend:
         _lib.call(f"lsk_csr_sliced_spmv_{_lib.suffix(sliced.dtype)}", sliced.handle, row_begin, row_end, _ptr(x),
                   _ptr(y), beta, self.stream())
 
+    @staticmethod
+    def csr_sliced_dot_slots(rows: int) -> int:
+        return -(-(-(-rows // 64)) // 4)
+
+    def csr_sliced_spmv_dot(self, sliced: "SlicedStructure", rows: int, x: torch.Tensor, y: torch.Tensor, beta: int,
+                            w: torch.Tensor, partials: torch.Tensor, placement: int = 0) -> int:
+        """The whole piece's product, and partials[:count] <- shares of sum(y_new * w).  Returns count."""
+        if placement != self._placement:
+            _lib.call("lsk_set_option", b"xcd_remap", placement)
+            self._placement = placement
+        count = ctypes.c_int64(0)
+        _lib.call(f"lsk_csr_sliced_spmv_dot_{_lib.suffix(sliced.dtype)}", sliced.handle, 0, rows, _ptr(x), _ptr(y),
+                  beta, _ptr(w), _ptr(partials), partials.numel(), ctypes.byref(count), self.stream())
+        return count.value
+
     def csr_spmv_tune(self, rows: int, nnz: int, rects: torch.Tensor, k_base: int, col: torch.Tensor,
                       val: torch.Tensor, x: torch.Tensor, x_lo: int, x_hi: int,
                       y: torch.Tensor) -> Tuple[int, float]:

@@ -249,15 +249,25 @@ __device__ __forceinline__ T sliced_batch(T acc, const T *vp, const T *xp, const
     return acc;
 }
 
-// The product.  One wave per slice, lane l = row l of the slice.
-template <typename T, int B>
+// The product.  One wave per slice, lane l = row l of the slice.  DOT: workgroup g (of the logical
+// order, whatever its placement) also leaves partials[g] = the sum over its rows of y_new[r] * w[r],
+// added up in a fixed order.
+template <typename T, int B, bool DOT>
 __global__ __launch_bounds__(kBlock) void sliced_spmv_kernel(
     int64_t slice_begin, int64_t slice_count, int64_t row_begin, int64_t row_end, const SliceMeta *__restrict__ meta,
     const T *__restrict__ val, const unsigned char *__restrict__ row_pattern, const unsigned *__restrict__ row_mask,
-    const int *__restrict__ table, const T *__restrict__ x, long long x_shift, T *__restrict__ y, int beta, int remap) {
+    const int *__restrict__ table, const T *__restrict__ x, long long x_shift, T *__restrict__ y, int beta, int remap,
+    const T *__restrict__ w, T *__restrict__ partials) {
+    __shared__ T wave_share[kBlock / kWave];
     const unsigned wg = lsk::xcd_remap(blockIdx.x, gridDim.x, remap);
     const int64_t local = int64_t(wg) * (kBlock / kWave) + threadIdx.x / kWave;
-    if (local >= slice_count) return;
+    if (local >= slice_count) { // (only in the last workgroup)
+        if constexpr (DOT) {
+            wave_share[threadIdx.x / kWave] = T(0);
+            __syncthreads();
+        }
+        return;
+    }
     const int64_t slice = slice_begin + local;
     const int lane = threadIdx.x % kWave;
     const int64_t r = slice * kWave + lane;
@@ -296,6 +306,17 @@ __global__ __launch_bounds__(kBlock) void sliced_spmv_kernel(
         }
     }
     if (live) y[r] = acc;
+    if constexpr (DOT) {
+        const T share = lsk::wave_sum(live ? acc * w[r] : T(0));
+        if (lane == 0) wave_share[threadIdx.x / kWave] = share;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            T total = wave_share[0];
+#pragma unroll
+            for (int i = 1; i < kBlock / kWave; ++i) total = total + wave_share[i];
+            partials[wg] = total;
+        }
+    }
 }
 
 template <typename T>
@@ -427,7 +448,9 @@ int create(const char *name, int64_t rows, int64_t nnz, const int64_t *rects, in
 
 template <typename T>
 int spmv(const char *name, const lsk_csr_sliced *m, int64_t row_begin, int64_t row_end, const T *x, T *y, int beta,
-         lsk_stream_t stream) {
+         const T *w, T *partials, int64_t capacity, int64_t *count, lsk_stream_t stream) {
+    const bool dot = count != nullptr;
+    if (dot) *count = 0;
     if (!m) return lsk::fail(LSK_ERR_ARG, "%s: null structure", name);
     if (m->elem_bytes != static_cast<int>(sizeof(T))) return lsk::fail(LSK_ERR_ARG, "%s: structure of another entry type", name);
     if (row_begin < 0 || row_end > m->rows || row_begin > row_end)
@@ -439,11 +462,21 @@ int spmv(const char *name, const lsk_csr_sliced *m, int64_t row_begin, int64_t r
     const int64_t slice_begin = row_begin / kWave;
     const int64_t slice_count = lsk::ceil_div(row_end, kWave) - slice_begin;
     const unsigned blocks = static_cast<unsigned>(lsk::ceil_div(slice_count, kBlock / kWave));
-    sliced_spmv_kernel<T, 9><<<blocks, kBlock, 0, lsk::as_stream(stream)>>>(
-        slice_begin, slice_count, row_begin, row_end, static_cast<const SliceMeta *>(m->meta),
-        static_cast<const T *>(m->val), m->row_pattern, m->row_mask, m->table, x, m->row_first - m->x_lo, y, beta,
-        lsk::options().xcd_remap);
+    if (dot) {
+        if (!w || !partials) return lsk::fail(LSK_ERR_ARG, "%s: null w or partials", name);
+        if (capacity < static_cast<int64_t>(blocks))
+            return lsk::fail(LSK_ERR_ARG, "%s: room for %lld partial sums, %u needed", name, (long long)capacity, blocks);
+    }
+#define LSK_SLICED_LAUNCH(DOT)                                                                                  \
+    sliced_spmv_kernel<T, 9, DOT><<<blocks, kBlock, 0, lsk::as_stream(stream)>>>(                                \
+        slice_begin, slice_count, row_begin, row_end, static_cast<const SliceMeta *>(m->meta),                   \
+        static_cast<const T *>(m->val), m->row_pattern, m->row_mask, m->table, x, m->row_first - m->x_lo, y, beta, \
+        lsk::options().xcd_remap, w, partials)
+    if (dot) LSK_SLICED_LAUNCH(true);
+    else LSK_SLICED_LAUNCH(false);
+#undef LSK_SLICED_LAUNCH
     LSK_LAUNCH_CHECK();
+    if (dot) *count = blocks;
     return LSK_OK;
 }
 
@@ -464,11 +497,23 @@ int lsk_csr_sliced_create_f64(int64_t rows, int64_t nnz, const int64_t *rects, i
 
 int lsk_csr_sliced_spmv_f32(const lsk_csr_sliced_t *m, int64_t row_begin, int64_t row_end, const float *x, float *y,
                             int beta, lsk_stream_t stream) {
-    return spmv<float>("lsk_csr_sliced_spmv_f32", m, row_begin, row_end, x, y, beta, stream);
+    return spmv<float>("lsk_csr_sliced_spmv_f32", m, row_begin, row_end, x, y, beta, nullptr, nullptr, 0, nullptr, stream);
 }
 int lsk_csr_sliced_spmv_f64(const lsk_csr_sliced_t *m, int64_t row_begin, int64_t row_end, const double *x, double *y,
                             int beta, lsk_stream_t stream) {
-    return spmv<double>("lsk_csr_sliced_spmv_f64", m, row_begin, row_end, x, y, beta, stream);
+    return spmv<double>("lsk_csr_sliced_spmv_f64", m, row_begin, row_end, x, y, beta, nullptr, nullptr, 0, nullptr, stream);
+}
+int lsk_csr_sliced_spmv_dot_f32(const lsk_csr_sliced_t *m, int64_t row_begin, int64_t row_end, const float *x, float *y,
+                                int beta, const float *w, float *partials, int64_t capacity, int64_t *count,
+                                lsk_stream_t stream) {
+    if (!count) return lsk::fail(LSK_ERR_ARG, "lsk_csr_sliced_spmv_dot_f32: null count");
+    return spmv<float>("lsk_csr_sliced_spmv_dot_f32", m, row_begin, row_end, x, y, beta, w, partials, capacity, count, stream);
+}
+int lsk_csr_sliced_spmv_dot_f64(const lsk_csr_sliced_t *m, int64_t row_begin, int64_t row_end, const double *x, double *y,
+                                int beta, const double *w, double *partials, int64_t capacity, int64_t *count,
+                                lsk_stream_t stream) {
+    if (!count) return lsk::fail(LSK_ERR_ARG, "lsk_csr_sliced_spmv_dot_f64: null count");
+    return spmv<double>("lsk_csr_sliced_spmv_dot_f64", m, row_begin, row_end, x, y, beta, w, partials, capacity, count, stream);
 }
 
 int lsk_csr_sliced_info(const lsk_csr_sliced_t *m, int64_t *out) {

@@ -167,7 +167,7 @@ class CSRMatrix(AbstractMatrix):
         if override is not None:
             return override != "0"
         if self.sliced:
-            return False  # the sliced-pattern product saves more bytes than the fused dot does
+            return True   # one lane owns a row there: the shares cost next to nothing
         return self.rows > 0 and self.nnz / self.rows <= self.FUSE_DOT_MAX_ROW_LENGTH
 
     def compress(self, x_lo: int, x_hi: int, kernel_partition, range_partition) -> bool:
@@ -453,7 +453,7 @@ class CSRMatrix(AbstractMatrix):
         range_partition = range_partition or dst.index_partition
         be = self.ctx.backend
         sliced = self.sliced if self.sliced_window == (x_lo, x_hi) else {}
-        fused = (dot_with is not None and beta == 0 and split is None and not sliced
+        fused = (dot_with is not None and beta == 0 and split is None
                  and getattr(be, "csr_spmv_dot", None) is not None)
         touch = getattr(dst, "_touch", None)
         if touch is not None:
@@ -488,6 +488,11 @@ class CSRMatrix(AbstractMatrix):
                 continue
             if split is not None and phase == 0:
                 continue  # a piece without a split entry (no entries) goes with the late phase
+            if c in sliced and fused:
+                buf = dst._partials("mv", i, be.csr_sliced_dot_slots(rows))
+                pieces.append((buf, be.csr_sliced_spmv_dot(sliced[c], rows, x, dst.piece(i), beta, dot_with.piece(i),
+                                                           buf, self.sliced_placement.get(c, 0))))
+                continue
             if c in sliced:
                 be.csr_sliced_spmv(sliced[c], 0, rows, x, dst.piece(i), beta, self.sliced_placement.get(c, 0))
                 continue

@@ -288,7 +288,8 @@ class SquarePlanner:
                 if first:
                     dst.zero_fill()
                 e.matrix.matvec(dst, x, x_lo, x_hi, e.kernel_partition, 1)
-            elif fuse and first and writers[e.range_index] == 1 and e.matrix.fuses_dot():
+            elif (fuse and first and writers[e.range_index] == 1 and e.matrix.fuses_dot()
+                  and not (e.split is not None and handle is not None)):  # (overlapping the halo is worth more)
                 comm.exchange_finish(handle)
                 e.matrix.matvec(dst, x, x_lo, x_hi, e.kernel_partition, 0,
                                 dot_with=self.get_vector(src_idx, e.range_index))

@@ -227,10 +227,12 @@ def test_structure_that_cannot_be_compressed_falls_back(gpu_ctx):
                                [float(v) for v in so.residual_norm_squared], rtol=1e-10)
 
 
-def test_held_back_solution_update(gpu_ctx):
+def test_held_back_solution_update(gpu_ctx, monkeypatch):
     """CG's x += alpha p is held back and shares one pass with p <- r + beta p; reading the solution
-    in between (or at any time) gives the same values as with the fused leaves off, bit for bit."""
+    in between (or at any time) gives the same values as with the fused leaves off, bit for bit.
+    (The fused product + dot is kept out of it: it sums p.Ap in another order.)"""
     from legionsolvers_amd import Context
+    monkeypatch.setenv("LSK_FUSE_SPMV_DOT", "0")
     rects, row, col, val, n = hc.stencil_problem(4, (12, 10, 14), np.float64)
     rhs = np.random.default_rng(35).standard_normal(n)
     runs = []
@@ -370,12 +372,22 @@ def test_sliced_pattern_structure_is_used_and_bit_exact(gpu_ctx, monkeypatch, dt
     print(f"case sliced planner {np.dtype(dtype).name} pieces={pieces}", flush=True)
     mpl = hc.mirror_planner(gpu_ctx, "csr", rects, row, col, val, n, pieces, dtype, rhs)
     matrix = mpl.row_partitioned_matrices[0].matrix
-    assert sorted(matrix.sliced) == list(range(pieces)) and not matrix.fuses_dot()
-    mpl.allocate_workspace(1)
+    assert sorted(matrix.sliced) == list(range(pieces)) and matrix.fuses_dot()
+    mpl.allocate_workspace(2)
     mpl.matvec(2, 1)
     want = np.zeros(n, dtype)
     oracle.csr_matvec(rects, 0, col, val, rhs, 0, n - 1, want)
     assert np.array_equal(mpl.get_vector(2, 0).to_host().numpy(), want)
+    # the fused product + dot between workspace vectors: the same product, and the dot the planner
+    # then takes from its shares
+    mpl.copy(2, 1)
+    mpl.matvec(3, 2)
+    assert np.array_equal(mpl.get_vector(3, 0).to_host().numpy(), want)
+    assert mpl._fused_dot_pending is not None
+    got = mpl.dot(2, 3).get_value()
+    exact = float(np.dot(want.astype(np.float64), rhs.astype(np.float64)))
+    scale = float(np.dot(np.abs(want).astype(np.float64), np.abs(rhs).astype(np.float64)))
+    assert mpl._fused_dot_used == 1 and abs(got - exact) <= (1e-13 if dtype == np.float64 else 1e-5) * scale
     monkeypatch.setenv("LSK_SLICED", "0")
     mpl0 = hc.mirror_planner(gpu_ctx, "csr", rects, row, col, val, n, pieces, dtype, rhs)
     assert not mpl0.row_partitioned_matrices[0].matrix.sliced

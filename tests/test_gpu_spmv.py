@@ -703,6 +703,25 @@ def sliced_case(suf, rects, k_base, col, val, x, x_lo, x_hi, row_first, tag, exp
             got = yd.cpu().numpy()
             assert np.array_equal(got.view(np.uint8), want.view(np.uint8)), \
                 f"{tag}: beta={beta} rows {ra}..{rb}: {int((got != want).sum())} rows differ"
+        # the fused product + dot: the same y bit for bit, and shares that add up to y . w
+        w = rng.standard_normal(rows).astype(npdt)
+        want = np.zeros(rows, dtype=npdt)
+        oracle.csr_matvec(rects, k_base, col, val, x, x_lo, x_hi, want, beta=0)
+        slots = -(-(-(-rows // 64)) // 4)
+        yd, wd = dev(y0), dev(w)
+        partials = torch.full((slots + 3,), 7.0, dtype=tdt, device="cuda")
+        count = ctypes.c_int64(-1)
+        _lib.call(f"lsk_csr_sliced_spmv_dot_{suf}", handle, 0, rows, P(xd), P(yd), 0, P(wd), P(partials), slots + 3,
+                  ctypes.byref(count), stream())
+        assert count.value == slots and np.array_equal(yd.cpu().numpy().view(np.uint8), want.view(np.uint8)), f"{tag}: fused"
+        got = partials.cpu().numpy()
+        assert np.all(got[slots:] == 7.0), f"{tag}: fused form wrote past its shares"
+        exact = float(np.dot(want.astype(np.float64), w.astype(np.float64)))
+        scale = float(np.dot(np.abs(want).astype(np.float64), np.abs(w).astype(np.float64))) + 1e-300
+        assert abs(float(got[:slots].astype(np.float64).sum()) - exact) <= (1e-13 if suf == "f64" else 1e-5) * scale, f"{tag}: fused dot"
+        code = getattr(_lib.lib(), f"lsk_csr_sliced_spmv_dot_{suf}")(handle, 0, rows, P(xd), P(yd), 0, P(wd), P(partials),
+                                                                   slots - 1, ctypes.byref(count), stream())
+        assert code == _lib.LSK_ERR_ARG and count.value == 0, f"{tag}: short partials buffer accepted"
     finally:
         _lib.call("lsk_csr_sliced_destroy", handle)
     return list(info)
