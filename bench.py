@@ -54,25 +54,31 @@ def spmv_kernel_time(ctx, matrix, planner, reps: int, form: str) -> float:
     base = src.own_lo - src.pad_lo
     x = src.data[x_lo - base:x_hi - base + 1]
     held = matrix.sliced_window, matrix.col32_window
+    # the variant the timed CG steps launched: with the shares of p.Ap when the planner fuses them in
+    dot_with = src if (form == "sliced" and planner_fuses_dot(planner)) else None
     try:
         if form in ("c32", "int64"):
             matrix.sliced_window = None
         if form == "int64":
             matrix.col32_window = None
-        return spmv_kernel_time_inner(ctx, matrix, entry, dst, x, x_lo, x_hi, reps)
+        return spmv_kernel_time_inner(ctx, matrix, entry, dst, x, x_lo, x_hi, reps, dot_with)
     finally:
         matrix.sliced_window, matrix.col32_window = held
 
 
-def spmv_kernel_time_inner(ctx, matrix, entry, dst, x, x_lo, x_hi, reps: int) -> float:
+def planner_fuses_dot(planner) -> bool:
+    return planner._fused_dot_used > 0 and planner.row_partitioned_matrices[0].matrix.fuses_dot()
+
+
+def spmv_kernel_time_inner(ctx, matrix, entry, dst, x, x_lo, x_hi, reps: int, dot_with=None) -> float:
     for _ in range(3):
-        matrix.matvec(dst, x, x_lo, x_hi, entry.kernel_partition, 0)
+        matrix.matvec(dst, x, x_lo, x_hi, entry.kernel_partition, 0, dot_with=dot_with)
     start = torch.cuda.Event(enable_timing=True)
     stop = torch.cuda.Event(enable_timing=True)
     ctx.synchronize()
     start.record()
     for _ in range(reps):
-        matrix.matvec(dst, x, x_lo, x_hi, entry.kernel_partition, 0)
+        matrix.matvec(dst, x, x_lo, x_hi, entry.kernel_partition, 0, dot_with=dot_with)
     stop.record()
     stop.synchronize()
     return start.elapsed_time(stop) * 1e-3 / reps
@@ -157,7 +163,7 @@ def main():
         parts = list(matrix.sliced.values())
         algo_bytes = (sum(p.padded_entries for p in parts) * 8 + matrix.rows * 16 + sum(p.slices for p in parts) * 16
                       + sum(p.masked_slices for p in parts) * 64 * 4 + sum(p.mixed_slices for p in parts) * 64)
-        kernel = "sliced_spmv_kernel<double, 9>"
+        kernel = f"sliced_spmv_kernel<double, 9, {'true' if planner_fuses_dot(planner) else 'false'}>"
         layout = ("values copied once at set-up into slices of 64 rows, one column-pattern id per slice (27 "
                   "patterns), no column array and no row offsets; every row summed in entry order, bit for bit "
                   "the reference's CPU loop")
