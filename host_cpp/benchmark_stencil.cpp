@@ -4,8 +4,8 @@
 // three output lines.  Extensions for tests: -systems 1 solves a single system, -coo 1 builds the
 // COO form of the matrix, -f32 1 uses float entries, -restart N sets GMRES's restart length
 // (the reference hard-codes 10), -history 1 prints the solver's scalar history one value per line,
-// -compress 0 / -fuse 0 / -redraws 0 turn the 32-bit structure, the held-back updates and the
-// set-up-time array redraws off, -adjoint N (after the solve) multiplies the solution by the
+// -compress 0 / -sliced 0 / -fuse 0 / -redraws 0 turn the 32-bit structure, the sliced-pattern copy,
+// the held-back updates and the set-up-time array redraws off, -adjoint N (after the solve) multiplies the solution by the
 // transpose and prints it against the product itself (the stencil matrices are symmetric) and both
 // sides of <A x, b> = <x, A^T b>; N > 1 transposes in runs of N entries.
 #include <chrono>
@@ -23,7 +23,7 @@ namespace {
 
 struct Args {
     long dim = 1, solver = 1, nx = 16, ny = 16, nz = 16, vp = 4, it = 20, pt = 1;
-    long systems = 2, coo = 0, f32 = 0, restart = 10, history = 0, compress = 1, fuse = 1, redraws = 4, adjoint = 0;
+    long systems = 2, coo = 0, f32 = 0, restart = 10, history = 0, compress = 1, fuse = 1, redraws = 4, adjoint = 0, sliced = 1;
 };
 
 Args parse(int argc, char **argv) {
@@ -33,7 +33,8 @@ Args parse(int argc, char **argv) {
         {"-nz", &Args::nz}, {"-vp", &Args::vp}, {"-it", &Args::it}, {"-pt", &Args::pt},
         {"-systems", &Args::systems}, {"-coo", &Args::coo}, {"-f32", &Args::f32}, {"-restart", &Args::restart},
         {"-history", &Args::history}, {"-compress", &Args::compress}, {"-fuse", &Args::fuse},
-        {"-redraws", &Args::redraws}, {"-adjoint", &Args::adjoint}};
+        {"-redraws", &Args::redraws}, {"-adjoint", &Args::adjoint},
+        {"-sliced", &Args::sliced}};
     for (int i = 1; i + 1 < argc; i += 2) {
         bool known = false;
         for (const auto &t : table)
@@ -114,7 +115,7 @@ template <typename T> int main_typed(const Args &a) {
         matrix = std::make_unique<COOMatrix<T>>(create_linearized_coo_stencil_matrix<T>(ctx, extent, st, partition));
     else {
         auto csr = std::make_unique<CSRMatrix<T>>(create_linearized_csr_stencil_matrix<T>(
-            ctx, extent, st, partition, a.compress != 0, static_cast<int>(a.redraws)));
+            ctx, extent, st, partition, a.compress != 0, static_cast<int>(a.redraws), a.sliced != 0));
         if (a.adjoint > 1) csr->transpose_chunk = a.adjoint;
         matrix = std::move(csr);
     }

@@ -48,6 +48,10 @@ template <typename T> struct Abi;
         static constexpr auto csr_spmv_tune = lsk_csr_spmv_tune_##SUF;                             \
         static constexpr auto coo_spmv = lsk_coo_spmv_##SUF;                                       \
         static constexpr auto gather = lsk_gather_##SUF;                                           \
+        static constexpr auto csr_sliced_create = lsk_csr_sliced_create_##SUF;                     \
+        static constexpr auto csr_sliced_spmv = lsk_csr_sliced_spmv_##SUF;                         \
+        static constexpr auto csr_sliced_spmv_dot = lsk_csr_sliced_spmv_dot_##SUF;                 \
+        static constexpr auto csr_sliced_tune = lsk_csr_sliced_tune_##SUF;                         \
         static constexpr auto stencil_fill_csr = lsk_stencil_fill_csr_##SUF;                       \
         static constexpr auto stencil_fill_coo = lsk_stencil_fill_coo_##SUF;                       \
     }
@@ -441,7 +445,7 @@ private:
 template <typename T> class CSRMatrix : public AbstractMatrix<T> {
 public:
     CSRMatrix(const Context &ctx, const EqualPartition &range, int64_t domain_size, DeviceArray<int64_t> rects,
-              DeviceArray<int64_t> col, DeviceArray<T> val, bool compress = true, int redraws = 4)
+              DeviceArray<int64_t> col, DeviceArray<T> val, bool compress = true, int redraws = 4, bool slice = true)
         : ctx_(&ctx), range_(range), domain_(domain_size), rects_(std::move(rects)), col_(std::move(col)),
           val_(std::move(val)) {
         for (int c = 0; c < range_.colors(); ++c) {
@@ -455,6 +459,7 @@ public:
             pieces_.push_back(std::move(p));
         }
         if (compress && col_.size() > 0 && domain_ > 0) try_compress();
+        if (slice && col_.size() > 0 && domain_ > 0 && try_slice(redraws)) return;
         float best = tune();
         // Where the driver puts the arrays in HBM moves the product's time by several per cent, and
         // user code cannot steer it; so the arrays are copied into fresh allocations a few times
@@ -494,6 +499,7 @@ public:
         }
     }
     bool compressed() const { return col32_.size() > 0; }
+    bool sliced() const { return !sliced_.empty(); }
     bool accumulates_only() const override { return false; }
     void matvec(PartitionedVector<T> &dst, const PartitionedVector<T> &src, int beta) const override {
         if (!(dst.partition() == range_) || src.partition().n != domain_)
@@ -502,6 +508,11 @@ public:
             const int64_t rows = range_.volume(c);
             if (rows <= 0) continue;
             const Piece &p = pieces_[c];
+            if (sliced() && sliced_[c].handle) {
+                check(lsk_set_option("xcd_remap", sliced_[c].placement));
+                check(Abi<T>::csr_sliced_spmv(sliced_[c].handle, 0, rows, src.data(), dst.piece(c), beta, ctx_->stream()));
+                continue;
+            }
             check(lsk_set_option("xcd_remap", p.placement));
             if (compressed())
                 check(Abi<T>::csr_spmv_c32(rows, p.nnz, p.rowoff.get(), col32_.get() + p.k_lo, val_.get() + p.k_lo,
@@ -559,6 +570,74 @@ private:
         }
         return total;
     }
+    // The sliced-pattern copy of a piece (lsk_csr_sliced_*): for matrices whose rows repeat a few
+    // column patterns, the product then reads no column array at all and sums every row in entry
+    // order, bit for bit the loop of src/CSRMatrixTasks.cpp:73-91.
+    struct Sliced {
+        lsk_csr_sliced_t *handle = nullptr;
+        int placement = 0;
+        Sliced() = default;
+        Sliced(Sliced &&o) noexcept : handle(o.handle), placement(o.placement) { o.handle = nullptr; }
+        Sliced &operator=(Sliced &&o) noexcept {
+            if (this != &o) {
+                lsk_csr_sliced_destroy(handle);
+                handle = o.handle;
+                placement = o.placement;
+                o.handle = nullptr;
+            }
+            return *this;
+        }
+        Sliced(const Sliced &) = delete;
+        Sliced &operator=(const Sliced &) = delete;
+        ~Sliced() { lsk_csr_sliced_destroy(handle); }
+    };
+    bool make_slice(int c, Sliced &out) const { // false: the library declined
+        const Piece &p = pieces_[c];
+        const int rc = Abi<T>::csr_sliced_create(range_.volume(c), p.nnz, rects_.get() + 2 * range_.piece[c].first, p.k_lo,
+                                                 col_.get() + p.k_lo, val_.get() + p.k_lo, range_.piece[c].first, 0,
+                                                 domain_ - 1, ctx_->stream(), &out.handle);
+        if (rc == LSK_ERR_UNSUPPORTED) return false;
+        check(rc);
+        return true;
+    }
+    // All pieces or none.  Large pieces then get their placement by timing, and up to `redraws` more
+    // copies are made, the fastest kept (where the driver puts the copy in HBM moves the product's
+    // time by several per cent).
+    bool try_slice(int redraws) {
+        std::vector<Sliced> made(range_.colors());
+        int64_t most = 0;
+        for (int c = 0; c < range_.colors(); ++c) {
+            if (range_.volume(c) <= 0 || pieces_[c].nnz <= 0) continue;
+            if (!make_slice(c, made[c])) return false;
+            most = std::max(most, range_.volume(c));
+        }
+        if (most == 0) return false;
+        if (most >= kTuneMinRows) {
+            DeviceArray<T> x(domain_), y(most);
+            check(Abi<T>::fill(domain_, T(0), x.get(), ctx_->stream()));
+            for (int c = 0; c < range_.colors(); ++c) {
+                if (!made[c].handle || range_.volume(c) < kTuneMinRows) continue;
+                float best = 0.0f;
+                check(Abi<T>::csr_sliced_tune(made[c].handle, x.get(), y.get(), ctx_->stream(), &made[c].placement, &best));
+                for (int i = 0; i < redraws; ++i) {
+                    Sliced other;
+                    float ms = 0.0f;
+                    try {
+                        if (!make_slice(c, other)) break;
+                    } catch (const std::runtime_error &) {
+                        break; // no room for a second copy
+                    }
+                    check(Abi<T>::csr_sliced_tune(other.handle, x.get(), y.get(), ctx_->stream(), &other.placement, &ms));
+                    if (ms < best) {
+                        best = ms;
+                        made[c] = std::move(other);
+                    }
+                }
+            }
+        }
+        sliced_ = std::move(made);
+        return true;
+    }
     void try_compress() {
         DeviceArray<uint32_t> col32(col_.size());
         if (lsk_csr_compress_cols_u32(col_.size(), col_.get(), 0, domain_ - 1, col32.get(), ctx_->stream()) != LSK_OK)
@@ -585,6 +664,7 @@ private:
     DeviceArray<T> val_;
     DeviceArray<uint32_t> col32_;
     std::vector<Piece> pieces_;
+    std::vector<Sliced> sliced_;
     mutable std::unique_ptr<Transposed<T>> transposed_;
 };
 

@@ -103,11 +103,11 @@ Generated<T> generate(const Context &ctx, const std::vector<int64_t> &extent, St
 template <typename T>
 CSRMatrix<T> create_linearized_csr_stencil_matrix(const Context &ctx, const std::vector<int64_t> &extent,
                                                   const Stencil &stencil, const EqualPartition &partition,
-                                                  bool compress = true, int redraws = 4) {
+                                                  bool compress = true, int redraws = 4, bool slice = true) {
     auto g = detail::generate<T>(ctx, extent, stencil, false);
     if (partition.n != g.rows) throw std::invalid_argument("the partition must colour the linearised grid");
     return CSRMatrix<T>(ctx, partition, g.rows, std::move(g.rects), std::move(g.col), std::move(g.val), compress,
-                        redraws);
+                        redraws, slice);
 }
 
 // create_linearized_coo_stencil_matrix (fill task src/StencilGenerator.cpp:129-242).

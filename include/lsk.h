@@ -486,6 +486,14 @@ int lsk_csr_sliced_spmv_dot_f32(const lsk_csr_sliced_t *m, int64_t row_begin, in
 int lsk_csr_sliced_spmv_dot_f64(const lsk_csr_sliced_t *m, int64_t row_begin, int64_t row_end, const double *x, double *y,
                                 int beta, const double *w, double *partials, int64_t capacity, int64_t *count,
                                 lsk_stream_t stream);
+/* Times the whole product (x: the window, y: rows values, overwritten) for a few values of option
+ * "xcd_remap" and reports the fastest and its milliseconds per launch, as lsk_csr_spmv_tune_* does.
+ * Callers that remake the structure a few times and keep the fastest copy (where the driver puts an
+ * array in HBM moves the product's time by several per cent) compare these milliseconds. */
+int lsk_csr_sliced_tune_f32(const lsk_csr_sliced_t *m, const float *x, float *y, lsk_stream_t stream, int *xcd_remap,
+                            float *ms);
+int lsk_csr_sliced_tune_f64(const lsk_csr_sliced_t *m, const double *x, double *y, lsk_stream_t stream, int *xcd_remap,
+                            float *ms);
 int lsk_csr_sliced_info(const lsk_csr_sliced_t *m, int64_t *out);
 int lsk_csr_sliced_destroy(lsk_csr_sliced_t *m);
 

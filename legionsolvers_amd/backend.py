@@ -189,6 +189,14 @@ class HipBackend:
         _lib.call(f"lsk_csr_sliced_spmv_{_lib.suffix(sliced.dtype)}", sliced.handle, row_begin, row_end, _ptr(x),
                   _ptr(y), beta, self.stream())
 
+    def csr_sliced_tune(self, sliced: "SlicedStructure", x: torch.Tensor, y: torch.Tensor) -> Tuple[int, float]:
+        """(placement, milliseconds per launch) of the fastest workgroup -> XCD placement; y is
+        overwritten.  Synchronises."""
+        remap, ms = ctypes.c_int(0), ctypes.c_float(0.0)
+        _lib.call(f"lsk_csr_sliced_tune_{_lib.suffix(sliced.dtype)}", sliced.handle, _ptr(x), _ptr(y), self.stream(),
+                  ctypes.byref(remap), ctypes.byref(ms))
+        return remap.value, ms.value
+
     @staticmethod
     def csr_sliced_dot_slots(rows: int) -> int:
         return -(-(-(-rows // 64)) // 4)

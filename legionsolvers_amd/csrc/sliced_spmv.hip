@@ -21,6 +21,7 @@
 // slice + 4 per row of a masked slice (+ 1 per row of a slice that fits no common list).
 #include <algorithm>
 #include <climits>
+#include <cstdlib>
 #include <new>
 
 #include <hipcub/hipcub.hpp>
@@ -480,9 +481,64 @@ int spmv(const char *name, const lsk_csr_sliced *m, int64_t row_begin, int64_t r
     return LSK_OK;
 }
 
+// Times the candidates of the workgroup -> XCD placement on this structure and reports the fastest.
+template <typename T>
+int tune(const char *name, const lsk_csr_sliced *m, const T *x, T *y, lsk_stream_t stream, int *remap_out, float *ms_out) {
+    static const int candidates[] = {0, 16, 64, 256, 1024, 4096};
+    constexpr int kWarm = 1, kTimed = 3;
+    if (!m) return lsk::fail(LSK_ERR_ARG, "%s: null structure", name);
+    lsk::Options &opt = lsk::options();
+    const int saved = opt.xcd_remap;
+    hipStream_t s = lsk::as_stream(stream);
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    LSK_HIP(hipEventCreate(&t0));
+    LSK_HIP(hipEventCreate(&t1));
+    int best = saved, status = LSK_OK;
+    float best_ms = -1.0f;
+    for (int c : candidates) {
+        opt.xcd_remap = c;
+        for (int i = 0; i < kWarm && status == LSK_OK; ++i)
+            status = spmv<T>(name, m, 0, m->rows, x, y, 0, nullptr, nullptr, 0, nullptr, stream);
+        if (status != LSK_OK) break;
+        if (hipEventRecord(t0, s) != hipSuccess) { status = lsk::fail(LSK_ERR_HIP, "%s: event record", name); break; }
+        for (int i = 0; i < kTimed && status == LSK_OK; ++i)
+            status = spmv<T>(name, m, 0, m->rows, x, y, 0, nullptr, nullptr, 0, nullptr, stream);
+        if (status != LSK_OK) break;
+        float ms = 0.0f;
+        if (hipEventRecord(t1, s) != hipSuccess || hipEventSynchronize(t1) != hipSuccess ||
+            hipEventElapsedTime(&ms, t0, t1) != hipSuccess) {
+            status = lsk::fail(LSK_ERR_HIP, "%s: event timing", name);
+            break;
+        }
+        ms /= kTimed;
+        if (std::getenv("LSK_TUNE_VERBOSE"))
+            std::fprintf(stderr, "[lsk] %s: xcd_remap %d -> %.3f ms per launch\n", name, c, ms);
+        if (best_ms < 0.0f || ms < best_ms) {
+            best_ms = ms;
+            best = c;
+        }
+    }
+    opt.xcd_remap = saved;
+    (void)hipEventDestroy(t0);
+    (void)hipEventDestroy(t1);
+    if (status != LSK_OK) return status;
+    if (remap_out) *remap_out = best;
+    if (ms_out) *ms_out = best_ms;
+    return LSK_OK;
+}
+
 } // namespace
 
 extern "C" {
+
+int lsk_csr_sliced_tune_f32(const lsk_csr_sliced_t *m, const float *x, float *y, lsk_stream_t stream, int *xcd_remap,
+                            float *ms) {
+    return tune<float>("lsk_csr_sliced_tune_f32", m, x, y, stream, xcd_remap, ms);
+}
+int lsk_csr_sliced_tune_f64(const lsk_csr_sliced_t *m, const double *x, double *y, lsk_stream_t stream, int *xcd_remap,
+                            float *ms) {
+    return tune<double>("lsk_csr_sliced_tune_f64", m, x, y, stream, xcd_remap, ms);
+}
 
 int lsk_csr_sliced_create_f32(int64_t rows, int64_t nnz, const int64_t *rects, int64_t k_base, const int64_t *col,
                               const float *val, int64_t row_first, int64_t x_lo, int64_t x_hi, lsk_stream_t stream,

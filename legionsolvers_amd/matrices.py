@@ -249,23 +249,8 @@ class CSRMatrix(AbstractMatrix):
             if y is None or y.numel() < rows:
                 y = torch.empty(rows, dtype=self.dtype, device=self.val.device)
 
-            def timed(s, placement):
-                t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                be.csr_sliced_spmv(s, 0, rows, x, y, 0, placement)
-                t0.record()
-                for _ in range(3):
-                    be.csr_sliced_spmv(s, 0, rows, x, y, 0, placement)
-                t1.record()
-                t1.synchronize()
-                return t0.elapsed_time(t1) / 3
-
             def best_of(s):
-                times = {pl: timed(s, pl) for pl in (0, 16, 64, 256, 1024, 4096)}
-                pl = min(times, key=times.get)
-                if os.environ.get("LSK_TUNE_VERBOSE"):
-                    print(f"[lsk] sliced product, piece {c}: " + ", ".join(f"{k}: {v:.3f} ms" for k, v in times.items()),
-                          file=sys.stderr, flush=True)
-                return pl, times[pl]
+                return be.csr_sliced_tune(s, x, y)
 
             self.sliced_placement[c], best = best_of(self.sliced[c])
             for _ in range(redraws):
