@@ -13,6 +13,7 @@
 // reference's `cuda_task_body`, because that is the name TaskTDI::preregister and
 // HasCUDAVariantMixin look for (src/TaskBaseClasses.hpp:211-223, src/MetaprogrammingUtilities.hpp:
 // 123-145).
+#include <cstdlib>
 #include <map>
 #include <utility>
 
@@ -58,6 +59,8 @@ template <> struct Abi<float> {
     static constexpr auto dot_host = lsk_dot_host_f32;
     static constexpr auto csr_spmv = lsk_csr_spmv_f32;
     static constexpr auto csr_spmv_c32 = lsk_csr_spmv_c32_f32;
+    static constexpr auto csr_sliced_create = lsk_csr_sliced_create_f32;
+    static constexpr auto csr_sliced_spmv = lsk_csr_sliced_spmv_f32;
     static constexpr auto coo_spmv = lsk_coo_spmv_f32;
 };
 template <> struct Abi<double> {
@@ -68,6 +71,8 @@ template <> struct Abi<double> {
     static constexpr auto dot_host = lsk_dot_host_f64;
     static constexpr auto csr_spmv = lsk_csr_spmv_f64;
     static constexpr auto csr_spmv_c32 = lsk_csr_spmv_c32_f64;
+    static constexpr auto csr_sliced_create = lsk_csr_sliced_create_f64;
+    static constexpr auto csr_sliced_spmv = lsk_csr_sliced_spmv_f64;
     static constexpr auto coo_spmv = lsk_coo_spmv_f64;
 };
 
@@ -108,6 +113,35 @@ const Structure32 &structure32(const int64_t *rects, int64_t rows, int64_t k_bas
         check(lsk_free(col32));
     }
     return s;
+}
+
+// The sliced-pattern copy of a CSR piece (values in slices of 64 rows, no column array; made for
+// matrices whose rows repeat a few column patterns, i.e. every stencil), tried first and cached the
+// same way.  It holds a COPY of the entry values: an application that rewrites a matrix's entries in
+// place sets LSK_SLICED=0 (or drops the table entry) so that products keep reading the region.
+struct Sliced {
+    const void *rects = nullptr, *val = nullptr;
+    int64_t rows = 0, nnz = 0, x_lo = 0, x_hi = -1;
+    bool tried = false;
+    lsk_csr_sliced_t *handle = nullptr; // null after a refusal
+};
+std::map<std::pair<unsigned long long, const void *>, Sliced> sliced_table;
+
+template <typename T>
+const lsk_csr_sliced_t *sliced_structure(const int64_t *rects, int64_t rows, int64_t k_base, const int64_t *col,
+                                         const T *val, int64_t nnz, int64_t row_first, int64_t x_lo, int64_t x_hi,
+                                         lsk_stream_t stream) {
+    static const bool off = std::getenv("LSK_SLICED") && std::getenv("LSK_SLICED")[0] == '0';
+    if (off) return nullptr;
+    const auto key = std::make_pair(Legion::Processor::get_executing_processor().id, static_cast<const void *>(col));
+    Sliced &s = sliced_table[key];
+    if (s.tried && s.rects == rects && s.val == val && s.rows == rows && s.nnz == nnz && s.x_lo == x_lo && s.x_hi == x_hi)
+        return s.handle;
+    if (s.handle) check(lsk_csr_sliced_destroy(s.handle));
+    s = Sliced{rects, val, rows, nnz, x_lo, x_hi, true, nullptr};
+    const int rc = Abi<T>::csr_sliced_create(rows, nnz, rects, k_base, col, val, row_first, x_lo, x_hi, stream, &s.handle);
+    if (rc != LSK_OK && rc != LSK_ERR_UNSUPPORTED) check(rc);
+    return s.handle;
 }
 
 // One vector argument of a BLAS-1 task: base pointer of the dense piece and its volume.
@@ -185,6 +219,15 @@ void CSRMatvecTask<LEGION_SOLVERS_KDR_TEMPLATE_ARGS>::cuda_task_body(LEGION_SOLV
     const AffineReader<ENTRY_T, 1, DOMAIN_COORD_T> x(regions[3], *task->regions[3].privilege_fields.begin());
     const bool no_x = in_bounds.empty(), no_k = ker_bounds.empty();
     if (!no_x && !no_k) {
+        if (const lsk_csr_sliced_t *sl = sliced_structure<ENTRY_T>(
+                reinterpret_cast<const int64_t *>(rowptr.ptr(out_bounds.lo)), static_cast<int64_t>(out_bounds.volume()),
+                ker_bounds.lo[0], reinterpret_cast<const int64_t *>(col.ptr(ker_bounds.lo)), val.ptr(ker_bounds.lo),
+                static_cast<int64_t>(ker_bounds.volume()), out_bounds.lo[0], in_bounds.lo[0], in_bounds.hi[0],
+                task_stream())) {
+            check(Abi<ENTRY_T>::csr_sliced_spmv(sl, 0, static_cast<int64_t>(out_bounds.volume()), x.ptr(in_bounds.lo),
+                                                const_cast<ENTRY_T *>(y.ptr(out_bounds.lo)), /*beta=*/0, task_stream()));
+            return;
+        }
         const Structure32 &s32 = structure32(
             reinterpret_cast<const int64_t *>(rowptr.ptr(out_bounds.lo)), static_cast<int64_t>(out_bounds.volume()),
             ker_bounds.lo[0], reinterpret_cast<const int64_t *>(col.ptr(ker_bounds.lo)),
