@@ -12,9 +12,12 @@ on the device and resident in HBM before the timed region.  Rank 0 prints ONE JS
 
 Besides the contract's fields the line carries:
   roofline      the CSR SpMV kernel of the timed steps against the HBM roof: algorithmic bytes of
-                one launch in the layout it reads (nnz*12 + rows*20 on this rank with the set-up-time
-                32-bit structure, nnz*16 + rows*32 without) / its mean duration from HIP events
-  roofline_int64_columns   the same for the kernel that reads the reference's 64-bit column field
+                one launch in the layout it reads (the sliced-pattern copy: padded entries * 8 +
+                rows * 16 + 16 per slice + 4 per row of a masked slice; else nnz*12 + rows*20 on the
+                set-up-time 32-bit structure, nnz*16 + rows*32 on the arrays as handed over) / its
+                mean duration from HIP events
+  roofline_32bit_structure, roofline_int64_columns   the same for the kernels that read the
+                32-bit copy of the structure and the reference's 64-bit column field
   cpu_baseline  the CPU oracle's CG step (OpenMP over row blocks) on a bounded 27-point sample,
                 rank 0 at N = 1 only
 """

@@ -254,7 +254,10 @@ class CSRMatrix(AbstractMatrix):
 
             self.sliced_placement[c], best = best_of(self.sliced[c])
             for _ in range(redraws):
-                other = make(i, c)      # a second copy while the first is alive: another place in HBM
+                try:
+                    other = make(i, c)  # a second copy while the first is alive: another place in HBM
+                except RuntimeError:    # no room for it
+                    break
                 if other is None:
                     break
                 pl, t = best_of(other)
@@ -264,6 +267,20 @@ class CSRMatrix(AbstractMatrix):
                 else:
                     other.close()
         return True
+
+    def time_piece(self, i: int, c: int, x: torch.Tensor, y: torch.Tensor, reps: int = 3) -> float:
+        """Milliseconds of the sliced-pattern product of local piece i (colour c) with the window x
+        and the output piece y."""
+        be = self.ctx.backend
+        rows = y.numel()
+        t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        be.csr_sliced_spmv(self.sliced[c], 0, rows, x, y, 0, self.sliced_placement.get(c, 0))
+        t0.record()
+        for _ in range(reps):
+            be.csr_sliced_spmv(self.sliced[c], 0, rows, x, y, 0, self.sliced_placement.get(c, 0))
+        t1.record()
+        t1.synchronize()
+        return t0.elapsed_time(t1) / reps
 
     def _structure(self, x_lo: int, x_hi: int, c: int, r0: int, ra: int, rb: int):
         """(row field, column array) a product of rows [ra, rb) of piece c (whose first row is
