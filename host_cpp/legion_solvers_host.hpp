@@ -11,6 +11,7 @@
 #pragma once
 
 #include <algorithm>
+#include <chrono>
 #include <cstdint>
 #include <memory>
 #include <stdexcept>
@@ -632,6 +633,16 @@ private:
                         best = ms;
                         made[c] = std::move(other);
                     }
+                }
+                // The driver scrubs the memory of the copies just freed in the background, and a
+                // product that runs meanwhile loses a few per cent: leave once this one is back at
+                // the time it was chosen for, three probes in a row (or after 10 s).
+                const auto deadline = std::chrono::steady_clock::now() + std::chrono::seconds(10);
+                for (int good = 0; redraws > 0 && good < 3 && std::chrono::steady_clock::now() < deadline;) {
+                    float ms = 0.0f;
+                    int placement = 0;
+                    check(Abi<T>::csr_sliced_tune(made[c].handle, x.get(), y.get(), ctx_->stream(), &placement, &ms));
+                    good = ms <= 1.01f * best ? good + 1 : 0;
                 }
             }
         }

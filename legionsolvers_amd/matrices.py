@@ -447,6 +447,11 @@ class CSRMatrix(AbstractMatrix):
                 self.rects, self.col, self.val = old
             del old
             torch.cuda.empty_cache()  # hand the losing set back to the driver before the next draw
+        # the driver scrubs what was just freed in the background, which slows whatever runs
+        # meanwhile (see _wait_until_steady): leave once the product is back at its time
+        deadline, good = time.monotonic() + self.SETTLE_SECONDS, 0
+        while need >= (1 << 30) and good < 4 and time.monotonic() < deadline:
+            good = good + 1 if time_current() <= 1.01 * best else 0
 
     def create_kernel_partition_from_range_partition(self, range_partition):
         """Image-range of the rowptr rects over each piece's rows (src/CSRMatrix.cpp:89-109)."""
