@@ -198,18 +198,20 @@ class HipBackend:
         return remap.value, ms.value
 
     @staticmethod
-    def csr_sliced_dot_slots(rows: int) -> int:
-        return -(-(-(-rows // 64)) // 4)
+    def csr_sliced_dot_slots(row_end: int, row_begin: int = 0) -> int:
+        """Partial sums lsk_csr_sliced_spmv_dot_* leaves for rows row_begin..row_end-1."""
+        return -(-(-(-row_end // 64) - row_begin // 64) // 4)
 
-    def csr_sliced_spmv_dot(self, sliced: "SlicedStructure", rows: int, x: torch.Tensor, y: torch.Tensor, beta: int,
-                            w: torch.Tensor, partials: torch.Tensor, placement: int = 0) -> int:
-        """The whole piece's product, and partials[:count] <- shares of sum(y_new * w).  Returns count."""
+    def csr_sliced_spmv_dot(self, sliced: "SlicedStructure", row_end: int, x: torch.Tensor, y: torch.Tensor, beta: int,
+                            w: torch.Tensor, partials: torch.Tensor, placement: int = 0, row_begin: int = 0) -> int:
+        """Rows row_begin..row_end-1 of the piece's product, and partials[:count] <- shares of the sum
+        of y_new * w over those rows.  Returns count."""
         if placement != self._placement:
             _lib.call("lsk_set_option", b"xcd_remap", placement)
             self._placement = placement
         count = ctypes.c_int64(0)
-        _lib.call(f"lsk_csr_sliced_spmv_dot_{_lib.suffix(sliced.dtype)}", sliced.handle, 0, rows, _ptr(x), _ptr(y),
-                  beta, _ptr(w), _ptr(partials), partials.numel(), ctypes.byref(count), self.stream())
+        _lib.call(f"lsk_csr_sliced_spmv_dot_{_lib.suffix(sliced.dtype)}", sliced.handle, row_begin, row_end, _ptr(x),
+                  _ptr(y), beta, _ptr(w), _ptr(partials), partials.numel(), ctypes.byref(count), self.stream())
         return count.value
 
     def csr_spmv_tune(self, rows: int, nnz: int, rects: torch.Tensor, k_base: int, col: torch.Tensor,

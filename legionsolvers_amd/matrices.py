@@ -481,12 +481,13 @@ class CSRMatrix(AbstractMatrix):
         Krylov step takes next; only with beta = 0).
         split, phase: with the result of halo_split, launch only the runs of rows of that phase
         (0: those that need no ghost cell, 1: the others); both phases together are the whole
-        product."""
+        product (and, on the sliced-pattern copy, leave all the shares of the dot)."""
         range_partition = range_partition or dst.index_partition
         be = self.ctx.backend
         sliced = self.sliced if self.sliced_window == (x_lo, x_hi) else {}
-        fused = (dot_with is not None and beta == 0 and split is None
+        fused = (dot_with is not None and beta == 0 and (split is None or bool(sliced))
                  and getattr(be, "csr_spmv_dot", None) is not None)
+        last_phase = split is None or phase == 1
         touch = getattr(dst, "_touch", None)
         if touch is not None:
             touch()
@@ -501,10 +502,19 @@ class CSRMatrix(AbstractMatrix):
             k_lo, k_hi = kernel_partition.intervals[i]
             nnz = max(k_hi - k_lo + 1, 0)
             if split is not None and i in split:
-                for run_phase, ra, rb, ka, kb in split[i]:
+                if fused:  # every run's shares side by side in one buffer, whichever phase launches it
+                    slots = [be.csr_sliced_dot_slots(rb, ra) for _, ra, rb, _, _ in split[i]]
+                    buf = dst._partials("mv", i, sum(slots))
+                    if last_phase:
+                        pieces.append((buf, sum(slots)))
+                for k, (run_phase, ra, rb, ka, kb) in enumerate(split[i]):
                     if run_phase != phase:
                         continue
                     n_run = max(kb - ka + 1, 0)
+                    if c in sliced and fused:
+                        be.csr_sliced_spmv_dot(sliced[c], rb, x, dst.piece(i), beta, dot_with.piece(i),
+                                               buf[sum(slots[:k]):], self.sliced_placement.get(c, 0), row_begin=ra)
+                        continue
                     if c in sliced:
                         be.csr_sliced_spmv(sliced[c], ra, rb, x, dst.piece(i), beta, self.sliced_placement.get(c, 0))
                         continue
@@ -537,7 +547,7 @@ class CSRMatrix(AbstractMatrix):
                 pieces.append((buf, be.csr_spmv_dot(*args, dot_with.piece(i), buf, self.placement.get(c, 0))))
             else:
                 be.csr_spmv(*args, self.placement.get(c, 0))
-        if fused:
+        if fused and last_phase:
             dst._note_ready(dot_with, pieces)
 
 

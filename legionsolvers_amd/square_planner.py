@@ -289,17 +289,24 @@ class SquarePlanner:
                     dst.zero_fill()
                 e.matrix.matvec(dst, x, x_lo, x_hi, e.kernel_partition, 1)
             elif (fuse and first and writers[e.range_index] == 1 and e.matrix.fuses_dot()
-                  and not (e.split is not None and handle is not None)):  # (overlapping the halo is worth more)
+                  and not (e.split is not None and handle is not None)):
                 comm.exchange_finish(handle)
                 e.matrix.matvec(dst, x, x_lo, x_hi, e.kernel_partition, 0,
                                 dot_with=self.get_vector(src_idx, e.range_index))
                 fused_any = True
             elif e.split is not None and handle is not None:
-                # rows that read no ghost cell are multiplied while the halo is in flight
+                # rows that read no ghost cell are multiplied while the halo is in flight (and on the
+                # sliced-pattern copy both phases can still leave the shares of the dot)
                 beta = 0 if first else 1
-                e.matrix.matvec(dst, x, x_lo, x_hi, e.kernel_partition, beta, split=e.split, phase=0)
+                with_dot = (fuse and first and writers[e.range_index] == 1 and e.matrix.fuses_dot()
+                            and bool(getattr(e.matrix, "sliced", None)))
+                dot_with = self.get_vector(src_idx, e.range_index) if with_dot else None
+                e.matrix.matvec(dst, x, x_lo, x_hi, e.kernel_partition, beta, split=e.split, phase=0,
+                                dot_with=dot_with)
                 comm.exchange_finish(handle)
-                e.matrix.matvec(dst, x, x_lo, x_hi, e.kernel_partition, beta, split=e.split, phase=1)
+                e.matrix.matvec(dst, x, x_lo, x_hi, e.kernel_partition, beta, split=e.split, phase=1,
+                                dot_with=dot_with)
+                fused_any = fused_any or with_dot
             else:
                 comm.exchange_finish(handle)
                 e.matrix.matvec(dst, x, x_lo, x_hi, e.kernel_partition, 0 if first else 1)

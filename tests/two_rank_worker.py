@@ -30,8 +30,9 @@ def main():
         spaces = 2 if solver_name == "cg" else 1
         opl = hc.oracle_planner(kind, rects, row, col, val, n, pieces, np.float64, rhs, spaces)
         mpl = hc.mirror_planner(ctx, kind, rects, row, col, val, n, pieces, np.float64, rhs, spaces)
-        if kind == "csr":  # 27-point rows: not fused, so the halo overlap path is the one that runs
+        if kind == "csr":  # the halo overlap path is the one that runs, on the sliced-pattern copy
             assert mpl.row_partitioned_matrices[0].split is not None
+            assert mpl.row_partitioned_matrices[0].matrix.sliced
         if solver_name == "cg":
             so, sm, steps = S.CGSolver(opl), CGSolver(mpl), 8
         elif solver_name == "bicgstab":
@@ -41,6 +42,8 @@ def main():
         for _ in range(steps):
             so.step()
             sm.step()
+        if solver_name == "cg" and kind == "csr":  # both phases of the split product left the shares of p.Ap
+            assert mpl._fused_dot_used >= steps - 1, (mpl._fused_dot_issued, mpl._fused_dot_used)
         if solver_name == "cg":
             np.testing.assert_allclose([s.get_value() for s in sm.residual_norm_squared],
                                        [float(v) for v in so.residual_norm_squared], rtol=1e-10)
