@@ -31,7 +31,7 @@
 struct lsk_csr_sliced {
     int elem_bytes = 0;
     int64_t rows = 0, row_first = 0, x_lo = 0, x_hi = -1;
-    int64_t slices = 0, padded_entries = 0, entries = 0, mixed_slices = 0, masked_slices = 0;
+    int64_t slices = 0, padded_entries = 0, mixed_slices = 0, masked_slices = 0;
     int patterns = 0;
     void *val = nullptr;           // padded_entries values, slice by slice, entry-major inside a slice
     void *meta = nullptr;          // per slice {int64 base; int32 maxlen; int32 pattern (| kSliceMasked) or -1}
@@ -341,7 +341,6 @@ int create(const char *name, int64_t rows, int64_t nnz, const int64_t *rects, in
     m->x_lo = x_lo;
     m->x_hi = x_hi;
     m->slices = slices;
-    m->entries = nnz;
     unsigned long long *keys = nullptr;
     long long *rep = nullptr, *slice_entries = nullptr, *inclusive = nullptr, *mixed = nullptr;
     int *flags = nullptr;
