@@ -206,7 +206,7 @@ def test_gmres30_7pt_fp32_scaled(gpu_ctx):
     assert np.abs(got - want).max() <= 1e-3 * np.abs(want).max()
 
 
-def test_spmv_properties_7pt_fp32_768(gpu_ctx):
+def test_spmv_properties_7pt_fp32_768(gpu_ctx, monkeypatch):
     """The GMRES configuration's matrix at full size (7-point, 768^3, fp32 entries, int64
     indices: 453M rows, 3.17G entries, 45 GB): entry count, zero interior row sums,
     symmetry and linearity of the fp32 SpMV."""
@@ -250,6 +250,16 @@ def test_spmv_properties_7pt_fp32_768(gpu_ctx):
     Az = matvec(z, "Az")
     err = float((Az.owned.double() - Ax.owned.double() - Ay.owned.double()).abs().max())
     assert err <= 4e-6 * float(Ax.owned.abs().max() + Ay.owned.abs().max())
+    # the planner's two set-up-time layouts of this matrix against the product on the int64 arrays
+    del Az, Ay, z, y
+    monkeypatch.setenv("LSK_TUNE_REDRAWS", "0")
+    assert A.compress(0, n - 1, kp, ip)
+    assert torch.equal(matvec(x, "Ax32").owned, Ax.owned)
+    assert A.slice_structure(0, n - 1, kp, ip)
+    s = A.sliced[0]
+    assert (s.patterns, s.mixed_slices) == (27, 0) and s.padded_entries == A.nnz + 2 * n1 * n1  # 6 -> 7 at line ends
+    diff = float((matvec(x, "Axs").owned - Ax.owned).abs().max())
+    assert diff <= 2e-6 * float(Ax.owned.abs().max())
 
 
 @pytest.mark.parametrize("solver", [1, 2, 3])

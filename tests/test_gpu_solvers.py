@@ -101,7 +101,7 @@ def test_solvers_match_oracle(gpu_ctx, dtype, solver_name, kind):
     assert np.abs(got - want).max() <= rtol * 10 * scale
 
 
-def test_spmv_properties_at_headline_size(gpu_ctx):
+def test_spmv_properties_at_headline_size(gpu_ctx, monkeypatch):
     """BenchmarkStencil's headline matrix (3-D 27-point, 512^3, fp64: 134M rows, 3.6G entries,
     58 GB of col+val) is far beyond what the CPU oracle can check; these properties are
     size-independent: interior row sums are 0 (88 - 6*6 - 12*3 - 8*2 = 0), boundary row sums
@@ -153,6 +153,20 @@ def test_spmv_properties_at_headline_size(gpu_ctx):
     Az.axpy(-2.0, Ax)
     Az.axpy(3.0, Ay)
     assert Az.dot(Az).get_value() ** 0.5 <= 1e-12 * (4 * Ax.dot(Ax).get_value() + 9 * Ay.dot(Ay).get_value()) ** 0.5
+    # the two set-up-time layouts the planner puts this matrix in, against the product above (which
+    # read the int64 arrays): the 32-bit structure bit for bit, the sliced-pattern copy (27 patterns,
+    # a quarter of the slices masked, rows summed in entry order) to rounding
+    del Az, Ay, z, y
+    monkeypatch.setenv("LSK_TUNE_REDRAWS", "0")
+    assert A.compress(0, n - 1, kp, ip)
+    assert torch.equal(matvec(x).owned, Ax.owned)
+    assert A.slice_structure(0, n - 1, kp, ip)
+    s = A.sliced[0]
+    assert (s.patterns, s.mixed_slices, s.masked_slices * 4) == (27, 0, s.slices) and s.slices * 64 == n
+    # padding: the two end rows of every grid line have 2/3 of the line's row length (27, 18 or 12)
+    assert s.padded_entries == A.nnz + 2 * (9 * (n1 - 2) ** 2 + 6 * 4 * (n1 - 2) + 4 * 4)
+    diff = float((matvec(x).owned - Ax.owned).abs().max())
+    assert 0.0 < diff <= 1e-13 * float(Ax.owned.abs().max())
 
 
 @pytest.mark.parametrize("sliced", ["0", "1"])
