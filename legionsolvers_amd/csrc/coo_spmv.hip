@@ -160,9 +160,10 @@ __global__ __launch_bounds__(kBlock) void coo_spmv_scan_kernel(
     for (int j = 0; j < K; ++j) { // entries past the end re-read the last one and are dropped below
         const int64_t e = base + j * lsk::kWave + lane;
         const int64_t ec = e < last ? e : last;
-        rr[j] = row[ec];
-        cc[j] = col[ec];
-        vv[j] = val[ec];
+        // streamed past the caches (nothing reads an entry twice), so that x and y keep L2 to themselves
+        rr[j] = __builtin_nontemporal_load(row + ec);
+        cc[j] = __builtin_nontemporal_load(col + ec);
+        vv[j] = __builtin_nontemporal_load(val + ec);
     }
     T pp[K];
 #pragma unroll
