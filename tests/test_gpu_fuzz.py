@@ -151,3 +151,71 @@ def test_spmv_random_structures(gpu_ctx, suf, kind):
                 err = np.abs(yd.cpu().numpy().astype(np.float64) - want_c.astype(np.float64))
                 assert np.all(err <= lim * 4), ("coo 32-bit", float(err.max()))
             _lib.call("lsk_set_option", b"coo.variant", 1)
+
+
+@pytest.mark.parametrize("seed", range(8))
+@pytest.mark.parametrize("suf", ["f64", "f32"])
+def test_sliced_pattern_products_fuzz(seed, suf):
+    """Random matrices made of a few row patterns (lists of column distances with repeats, in any
+    order, some of them ordered parts of others, some unrelated, some empty), laid out in runs of
+    random length so that slices of 64 rows come out uniform, masked and mixed: the sliced-pattern
+    product equals the oracle's ascending-k loop bit for bit, whole and by ranges of rows."""
+    npdt, tdt, _ = DT[suf]
+    rng = np.random.default_rng(1000 + seed)
+    rows = int(rng.integers(65, 3000))
+    n_patterns = int(rng.integers(1, 9))
+    base = rng.integers(-40, 41, size=int(rng.integers(8, 33)))      # one long list ...
+    patterns = [base]
+    for _ in range(n_patterns - 1):
+        kind = rng.integers(0, 8)
+        if kind < 4:       # ... ordered parts of it, a few entries short (masked slices)
+            keep = np.sort(rng.choice(base.size, size=base.size - int(rng.integers(1, 4)), replace=False))
+            patterns.append(base[keep])
+        elif kind < 7:     # ... unrelated lists of about the same length (mixed slices)
+            patterns.append(rng.integers(-40, 41, size=max(base.size - int(rng.integers(0, 3)), 1)))
+        else:              # ... the empty row
+            patterns.append(np.zeros(0, dtype=np.int64))
+    run = int(rng.choice([1, 7, 64, 200]))
+    which = np.repeat(rng.integers(0, len(patterns), size=rows // run + 1), run)[:rows]
+    lens = np.array([patterns[p].size for p in which])
+    row_first = int(rng.integers(0, 500))
+    k_base = int(rng.integers(0, 100))
+    hi = k_base + np.cumsum(lens) - 1
+    rects = np.stack([hi - lens + 1, hi], axis=1).astype(np.int64)
+    col = np.concatenate([row_first + r + patterns[p] for r, p in enumerate(which)] + [np.zeros(0, dtype=np.int64)])
+    col = col.astype(np.int64)
+    nnz = col.size
+    if nnz == 0:
+        pytest.skip("drew an empty matrix")
+    val = rng.standard_normal(nnz).astype(npdt)
+    x_lo, x_hi = int(col.min()), int(col.max())
+    x = rng.standard_normal(x_hi - x_lo + 1).astype(npdt)
+    print(f"case sliced fuzz seed={seed} {suf} rows={rows} nnz={nnz} patterns={len(patterns)} run={run}", flush=True)
+    rd, cd, vd, xd = dev(rects), dev(col), dev(val), dev(x)
+    handle = ctypes.c_void_p(0)
+    code = getattr(_lib.lib(), f"lsk_csr_sliced_create_{suf}")(rows, nnz, P(rd), k_base, P(cd), P(vd), row_first, x_lo,
+                                                             x_hi, stream(), ctypes.byref(handle))
+    if code == _lib.LSK_ERR_UNSUPPORTED:   # too much padding for this draw: a legitimate answer
+        padded = sum(64 * int(lens[s:s + 64].max()) for s in range(0, rows, 64))
+        assert padded * np.dtype(npdt).itemsize > nnz * (np.dtype(npdt).itemsize + 3)
+        return
+    assert code == _lib.LSK_OK, _lib.lib().lsk_last_error().decode()
+    try:
+        info = (ctypes.c_int64 * 5)()
+        _lib.call("lsk_csr_sliced_info", handle, info)
+        assert info[3] <= len(patterns) and info[2] + info[4] <= info[1]
+        print(f"  slices {info[1]}: {info[2]} mixed, {info[4]} masked; {info[3]} patterns", flush=True)
+        y0 = rng.standard_normal(rows).astype(npdt)
+        for beta, (ra, rb) in ((0, (0, rows)), (1, (0, rows)), (1, (rows // 4, rows - rows // 3)), (0, (63, 130))):
+            rb = min(rb, rows)
+            want = y0.copy()
+            part = want[ra:rb].copy()
+            oracle.csr_matvec(rects[ra:rb], k_base, col, val, x, x_lo, x_hi, part, beta=beta)
+            want[ra:rb] = part
+            yd = dev(y0)
+            _lib.call(f"lsk_csr_sliced_spmv_{suf}", handle, ra, rb, P(xd), P(yd), beta, stream())
+            got = yd.cpu().numpy()
+            assert np.array_equal(got.view(np.uint8), want.view(np.uint8)), \
+                f"seed {seed}: beta={beta} rows {ra}..{rb}: {int((got != want).sum())} rows differ (info {list(info)})"
+    finally:
+        _lib.call("lsk_csr_sliced_destroy", handle)
