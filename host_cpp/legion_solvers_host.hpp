@@ -14,6 +14,7 @@
 #include <chrono>
 #include <cstdint>
 #include <memory>
+#include <optional>
 #include <stdexcept>
 #include <string>
 #include <utility>
@@ -378,6 +379,12 @@ public:
     // transpose, built on the first call.
     virtual void rmatvec(PartitionedVector<T> &dst, const PartitionedVector<T> &src, int beta) const = 0;
     virtual bool accumulates_only() const = 0;
+    // Optional fused form: dst <- A src and, in `shares` (room for dot_shares() values), partial sums
+    // that add up to dot(dst, w).  dot_shares() == 0: the matrix has no such form.
+    virtual int64_t dot_shares() const { return 0; }
+    virtual void matvec_dot(PartitionedVector<T> &, const PartitionedVector<T> &, const PartitionedVector<T> &, T *) const {
+        throw std::logic_error("this matrix has no fused product + dot");
+    }
 };
 
 // The CSR form of the transpose of a matrix, in the library's 32-bit structure: one row per element
@@ -524,6 +531,31 @@ public:
                                        dst.piece(c), beta, ctx_->stream()));
         }
     }
+    // On the sliced-pattern copy one lane owns a row, so the product can leave the shares of
+    // dot(dst, w) for a wave reduction per slice: one share per 256 rows of every piece.
+    int64_t dot_shares() const override {
+        if (!sliced()) return 0;
+        int64_t total = 0;
+        for (int c = 0; c < range_.colors(); ++c) {
+            if (range_.volume(c) > 0 && !sliced_[c].handle) return 0; // a piece without entries: no fused form
+            total += shares_of(range_.volume(c));
+        }
+        return total;
+    }
+    void matvec_dot(PartitionedVector<T> &dst, const PartitionedVector<T> &src, const PartitionedVector<T> &w,
+                    T *shares) const override {
+        if (!(dst.partition() == range_) || !(w.partition() == range_) || src.partition().n != domain_ || !dot_shares())
+            throw std::invalid_argument("matrix and vectors do not fit");
+        for (int c = 0; c < range_.colors(); ++c) {
+            const int64_t rows = range_.volume(c);
+            if (rows <= 0) continue;
+            int64_t count = 0;
+            check(lsk_set_option("xcd_remap", sliced_[c].placement));
+            check(Abi<T>::csr_sliced_spmv_dot(sliced_[c].handle, 0, rows, src.data(), dst.piece(c), 0, w.piece(c), shares,
+                                              shares_of(rows), &count, ctx_->stream()));
+            shares += count;
+        }
+    }
     void rmatvec(PartitionedVector<T> &dst, const PartitionedVector<T> &src, int beta) const override {
         if (!(src.partition() == range_) || dst.partition().n != domain_)
             throw std::invalid_argument("matrix and vectors do not fit");
@@ -592,6 +624,7 @@ private:
         Sliced &operator=(const Sliced &) = delete;
         ~Sliced() { lsk_csr_sliced_destroy(handle); }
     };
+    static int64_t shares_of(int64_t rows) { return ((rows + 63) / 64 + 3) / 4; }
     bool make_slice(int c, Sliced &out) const { // false: the library declined
         const Piece &p = pieces_[c];
         const int rc = Abi<T>::csr_sliced_create(range_.volume(c), p.nnz, rects_.get() + 2 * range_.piece[c].first, p.k_lo,
@@ -758,40 +791,86 @@ public:
             vectors_.push_back(std::move(row));
         }
     }
-    PartitionedVector<T> &get_vector(int index, int space) const { return *vectors_.at(index).at(space); }
-    void zero_fill(int dst) { for (auto *v : vectors_.at(dst)) v->zero_fill(); }
-    void copy(int dst, int src) { for (size_t s = 0; s < vectors_.at(dst).size(); ++s) *vectors_[dst][s] = *vectors_.at(src)[s]; }
-    void scal(int dst, const std::vector<Scalar<T>> &alpha) { for (auto *v : vectors_.at(dst)) v->scal(alpha); }
+    PartitionedVector<T> &get_vector(int index, int space) const {
+        pending_.reset(); // the caller may write through the reference
+        return *vectors_.at(index).at(space);
+    }
+    void zero_fill(int dst) {
+        pending_.reset();
+        for (auto *v : vectors_.at(dst)) v->zero_fill();
+    }
+    void copy(int dst, int src) {
+        pending_.reset();
+        for (size_t s = 0; s < vectors_.at(dst).size(); ++s) *vectors_[dst][s] = *vectors_.at(src)[s];
+    }
+    void scal(int dst, const std::vector<Scalar<T>> &alpha) {
+        pending_.reset();
+        for (auto *v : vectors_.at(dst)) v->scal(alpha);
+    }
     // An update by a workspace vector is held back (see PartitionedVector): into the solution it may
     // share a pass with that vector's own update, into a workspace vector it may serve the dot
-    // product that follows.  set_fusion(false) launches every leaf as it is asked for.
+    // product that follows.  A product between workspace vectors may leave the shares of the dot
+    // product of its result with its input (CG's p.Ap), which a dot(dst, src) that comes next, before
+    // any other operation of the planner, only adds up.  set_fusion(false) launches every leaf as it
+    // is asked for.
     void set_fusion(bool on) { fuse_ = on; }
     void axpy(int dst, const std::vector<Scalar<T>> &alpha, int src) {
+        pending_.reset();
         const bool defer = fuse_ && src >= 2 && dst != RHS && dst != src;
         for (size_t s = 0; s < vectors_.at(dst).size(); ++s) vectors_[dst][s]->axpy(alpha, *vectors_.at(src)[s], defer);
     }
     void xpay(int dst, const std::vector<Scalar<T>> &alpha, int src) {
+        pending_.reset();
         for (size_t s = 0; s < vectors_.at(dst).size(); ++s) vectors_[dst][s]->xpay(alpha, *vectors_.at(src)[s]);
     }
     Scalar<T> dot(int v, int w) const {
-        Scalar<T> acc = vectors_.at(v)[0]->dot(*vectors_.at(w)[0]);
-        for (size_t s = 1; s < vectors_[v].size(); ++s) acc = acc + vectors_[v][s]->dot(*vectors_[w][s]);
+        const std::optional<Pending> pending = std::move(pending_);
+        pending_.reset();
+        const bool ready = pending && ((pending->dst == v && pending->src == w) || (pending->dst == w && pending->src == v));
+        auto one = [&](size_t s) {
+            if (ready && pending->shares[s] > 0) {
+                Scalar<T> out = Scalar<T>::uninitialised(*ctx_);
+                check(Abi<T>::sum_partials(pending->shares[s], share_buffers_[s].get(), out.writable(), nullptr, 0,
+                                           ctx_->stream()));
+                return out;
+            }
+            return vectors_.at(v)[s]->dot(*vectors_.at(w)[s]);
+        };
+        Scalar<T> acc = one(0);
+        for (size_t s = 1; s < vectors_[v].size(); ++s) acc = acc + one(s);
         return acc;
     }
     void matvec(int dst, int src) {
-        std::vector<bool> touched(vectors_.at(dst).size(), false);
+        pending_.reset();
+        const size_t spaces = vectors_.at(dst).size();
+        std::vector<bool> touched(spaces, false);
+        std::vector<int> writers(spaces, 0);
+        for (const auto &e : matrices_) ++writers[e.range];
+        Pending pending{dst, src, std::vector<int64_t>(spaces, 0)};
+        bool any = false;
         for (const auto &e : matrices_) {
             PartitionedVector<T> &y = *vectors_[dst][e.range];
-            if (!touched[e.range] && e.matrix->accumulates_only()) y.zero_fill();
-            e.matrix->matvec(y, *vectors_.at(src)[e.domain], touched[e.range] || e.matrix->accumulates_only() ? 1 : 0);
+            const int64_t shares = e.matrix->dot_shares();
+            if (fuse_ && dst >= 2 && src >= 2 && dst != src && writers[e.range] == 1 && e.domain == e.range && shares > 0) {
+                if (share_buffers_.size() < spaces) share_buffers_.resize(spaces);
+                if (share_buffers_[e.range].size() < shares) share_buffers_[e.range] = DeviceArray<T>(shares);
+                e.matrix->matvec_dot(y, *vectors_.at(src)[e.domain], *vectors_[src][e.range], share_buffers_[e.range].get());
+                pending.shares[e.range] = shares;
+                any = true;
+            } else {
+                if (!touched[e.range] && e.matrix->accumulates_only()) y.zero_fill();
+                e.matrix->matvec(y, *vectors_.at(src)[e.domain], touched[e.range] || e.matrix->accumulates_only() ? 1 : 0);
+            }
             touched[e.range] = true;
         }
         for (size_t s = 0; s < touched.size(); ++s)
             if (!touched[s]) vectors_[dst][s]->zero_fill();
+        if (any) pending_ = std::move(pending);
     }
     // dst <- A^T src over all matrices: `src` is read in every matrix's range space, `dst` written in
     // its domain space (the reference's planner has no such method).
     void rmatvec(int dst, int src) {
+        pending_.reset();
         std::vector<bool> touched(vectors_.at(dst).size(), false);
         for (const auto &e : matrices_) {
             e.matrix->rmatvec(*vectors_[dst][e.domain], *vectors_.at(src)[e.range], touched[e.domain] ? 1 : 0);
@@ -806,6 +885,10 @@ private:
         const AbstractMatrix<T> *matrix;
         int domain, range;
     };
+    struct Pending { // shares of dot(vector dst, vector src) left by the last matvec, per space (0: none)
+        int dst, src;
+        std::vector<int64_t> shares;
+    };
     int add(PartitionedVector<T> &v, int index) {
         vectors_[index].push_back(&v);
         return static_cast<int>(vectors_[index].size()) - 1;
@@ -815,6 +898,8 @@ private:
     std::vector<std::vector<PartitionedVector<T> *>> vectors_;
     std::vector<std::unique_ptr<PartitionedVector<T>>> owned_;
     std::vector<Entry> matrices_;
+    mutable std::optional<Pending> pending_;
+    mutable std::vector<DeviceArray<T>> share_buffers_;
 };
 
 // CGSolver<T> (src/CGSolver.hpp:13-57).
