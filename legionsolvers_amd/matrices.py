@@ -273,7 +273,7 @@ class CSRMatrix(AbstractMatrix):
                 self._wait_until_steady(c, rows, x, y, best)
         return True
 
-    SETTLE_SECONDS = 10.0
+    SETTLE_SECONDS = 12.0
 
     def _wait_until_steady(self, c: int, rows: int, x: torch.Tensor, y: torch.Tensor, best: float) -> None:
         """The driver scrubs memory a process has freed in the background, at some 33 GB/s
@@ -281,13 +281,14 @@ class CSRMatrix(AbstractMatrix):
         which free ~29 GB each at the headline size, the product's time wanders between its best
         and +7 % for 5 s and then stays at the best for good).  So that whatever is timed next is
         not judged in that shadow, set-up ends by re-timing the product until it is back at the
-        time it had when it was chosen, eight probes in a row (0.6 s), or SETTLE_SECONDS have passed."""
+        time it had when it was chosen, sixteen probes in a row (1.2 s; quiet spells of half a second
+        occur inside the shadow), or SETTLE_SECONDS have passed."""
         deadline = time.monotonic() + self.SETTLE_SECONDS
         good = 0
-        while good < 8 and time.monotonic() < deadline:
+        while good < 16 and time.monotonic() < deadline:
             t = self.time_piece(0, c, x, y[:rows])
             good = good + 1 if t <= 1.01 * best else 0
-            if good < 8:
+            if good < 16:
                 time.sleep(0.05)
         if os.environ.get("LSK_TUNE_VERBOSE"):
             print(f"[lsk] sliced product steady again {self.SETTLE_SECONDS - (deadline - time.monotonic()):.1f} s "

@@ -2,7 +2,8 @@
 """Launch time of the sliced-pattern CSR product beside the 32-bit-structure product on the
 headline matrix (27-point stencil, fp64, one GPU).
 
-    LSK_TUNE_VERBOSE=1 python tools/sliced_rate.py [n]      (grid n^3, default 512)
+    LSK_TUNE_VERBOSE=1 python tools/sliced_rate.py [n] [dim-flag] [f32|f64]
+    (grid n^3, default 512; BenchmarkStencil's -dim flag, default 4 = 27-point, 3 = 7-point)
 """
 import json
 import os
@@ -28,17 +29,21 @@ def timed(ctx, fn, reps):
 
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+    flag = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+    dtype = torch.float32 if (len(sys.argv) > 3 and sys.argv[3] == "f32") else torch.float64
+    esz = 4 if dtype == torch.float32 else 8
     ctx = Context(torch.device("cuda", 0))
     t0 = time.perf_counter()
-    matrix, planner, solver = bs.build_problem(ctx, 4, n, n, n, 1, 1, torch.float64, num_systems=1)
+    matrix, planner, solver = bs.build_problem(ctx, flag, n, n, n, 1, 1, dtype, num_systems=1)
     ctx.synchronize()
     setup = time.perf_counter() - t0
     planner.get_vector(2, 0).random_fill(1)
-    out = {"grid": n, "rows": matrix.rows, "nnz": matrix.nnz, "setup_s": round(setup, 2)}
+    out = {"grid": n, "dim_flag": flag, "entry_bytes": esz, "rows": matrix.rows, "nnz": matrix.nnz,
+           "setup_s": round(setup, 2)}
     if matrix.sliced:
         s = matrix.sliced[0]
         out["sliced_ms"] = round(timed(ctx, lambda: planner.matvec(3, 2), 20), 3)
-        out["sliced_bytes"] = (s.padded_entries * 8 + matrix.rows * 16 + s.slices * 16 + s.mixed_slices * 64
+        out["sliced_bytes"] = (s.padded_entries * esz + matrix.rows * 2 * esz + s.slices * 16 + s.mixed_slices * 64
                                + s.masked_slices * 256)
         out["sliced_TBps"] = round(out["sliced_bytes"] / out["sliced_ms"] / 1e9, 3)
         out.update(patterns=s.patterns, mixed_slices=s.mixed_slices, masked_slices=s.masked_slices, slices=s.slices, padded_entries=s.padded_entries,
