@@ -270,20 +270,23 @@ class CSRMatrix(AbstractMatrix):
                 else:
                     other.close()
             if freed >= (1 << 30):  # (smaller amounts are scrubbed before anyone could notice)
-                self._wait_until_steady(c, rows, x, y, best)
+                self._wait_until_steady(c, rows, x, y, best, freed)
         return True
 
     SETTLE_SECONDS = 12.0
 
-    def _wait_until_steady(self, c: int, rows: int, x: torch.Tensor, y: torch.Tensor, best: float) -> None:
+    def _wait_until_steady(self, c: int, rows: int, x: torch.Tensor, y: torch.Tensor, best: float,
+                           freed: int) -> None:
         """The driver scrubs memory a process has freed in the background, at some 33 GB/s
         (measured: freeing 30 GB slows a running product by 2 % for 0.9 s; after the redraws above,
         which free ~29 GB each at the headline size, the product's time wanders between its best
         and +7 % for 5 s and then stays at the best for good).  So that whatever is timed next is
         not judged in that shadow, set-up ends by re-timing the product until it is back at the
         time it had when it was chosen, sixteen probes in a row (1.2 s; quiet spells of half a second
-        occur inside the shadow), or SETTLE_SECONDS have passed."""
-        deadline = time.monotonic() + self.SETTLE_SECONDS
+        occur inside the shadow), or twice the time the scrub should take (at most SETTLE_SECONDS) has
+        passed."""
+        limit = min(self.SETTLE_SECONDS, 1.5 + 2.0 * freed / 33e9)  # twice what the scrub should take
+        deadline = time.monotonic() + limit
         good = 0
         while good < 16 and time.monotonic() < deadline:
             t = self.time_piece(0, c, x, y[:rows])
@@ -291,7 +294,7 @@ class CSRMatrix(AbstractMatrix):
             if good < 16:
                 time.sleep(0.05)
         if os.environ.get("LSK_TUNE_VERBOSE"):
-            print(f"[lsk] sliced product steady again {self.SETTLE_SECONDS - (deadline - time.monotonic()):.1f} s "
+            print(f"[lsk] sliced product steady again {limit - (deadline - time.monotonic()):.1f} s "
                   f"after the redraws", file=sys.stderr, flush=True)
 
     def time_piece(self, i: int, c: int, x: torch.Tensor, y: torch.Tensor, reps: int = 3) -> float:
