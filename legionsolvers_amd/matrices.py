@@ -120,112 +120,23 @@ def _transposed_for(matrix, out_lo: int, out_hi: int, src: torch.Tensor, src_lo:
     return t
 
 
-class CSRMatrix(AbstractMatrix):
-    def __init__(self, ctx, rects: torch.Tensor, k_base: int, col: torch.Tensor, val: torch.Tensor,
-                 range_space: IndexSpace, row_lo: int):
-        """rects: this rank's rows row_lo .. row_lo+rows-1; col/val: the kernel entries
-        k_base .. k_base+nnz-1 those rects point into."""
-        if rects.dtype != torch.int64 or col.dtype != torch.int64:
-            raise TypeError("rects and col must be int64 (the reference's long long coordinates)")
-        if rects.dim() != 2 or rects.shape[1] != 2 or not rects.is_contiguous():
-            raise ValueError("rects must be a contiguous (rows, 2) tensor")
-        if col.numel() != val.numel():
-            raise ValueError("col and val differ in length")
-        self.ctx = ctx
-        self.rects, self.k_base, self.col, self.val = rects, int(k_base), col, val
-        self.dtype = val.dtype
-        self.range_space = range_space
-        self.row_lo = int(row_lo)
-        self.rows = rects.shape[0]
-        self.nnz = col.numel()
-        self.placement = {}  # piece colour -> tile placement found by tune()
-        self.col32 = None         # compress(): the column field as 32-bit offsets into ...
-        self.col32_window = None  # ... this window (x_lo, x_hi)
-        self.rowoff = {}          # ... and per piece colour rows + 1 32-bit offsets of the rows' entries
+class _SlicedCopies:
+    """What CSRMatrix and COOMatrix share around the sliced-pattern copies of their pieces
+    (lsk_csr_sliced_*): making them for all pieces or none, choosing the placement of large ones by
+    timing, re-making them a few times and keeping the fastest, and waiting until the driver is done
+    scrubbing what that freed."""
+
+    SLICED_REDRAWS = 6
+    TUNE_MIN_ROWS = 1 << 21  # pieces below this are not worth the trial launches
+
+    def _init_sliced(self) -> None:
         self.sliced = {}          # slice_structure(): piece colour -> sliced-pattern copy of the piece ...
         self.sliced_window = None # ... for products against this window
         self.sliced_placement = {}
 
-    def transpose(self, x_lo: int, x_hi: int, row_lo: int, rows: int) -> TransposedBlock:
-        """The transpose of this rank's rows against the window x_lo..x_hi of the domain."""
-        if row_lo != self.row_lo or rows != self.rows:
-            raise ValueError("rmatvec: the source vector does not hold exactly this rank's rows")
+    def _make_sliced_copies(self, make, x_lo: int, x_hi: int, kernel_partition, range_partition) -> bool:
+        """make(i, c): the copy of local piece i (colour c), None when the library declines."""
         be = self.ctx.backend
-        return TransposedBlock(be, self.col, be.csr_entry_rows(self.rects, self.k_base, self.nnz), self.val,
-                               x_lo, x_hi, rows)
-
-    def rmatvec(self, out, out_lo, out_hi, src, src_lo, beta):
-        _transposed_for(self, out_lo, out_hi, src, src_lo).apply(self.ctx.backend, out, src, beta)
-
-    TUNE_MIN_ROWS = 1 << 21  # pieces below this are not worth the ~30 trial launches
-    FUSE_DOT_MAX_ROW_LENGTH = 16.0
-
-    def fuses_dot(self) -> bool:
-        """Whether the fused product + dot leaf pays on this matrix.  It costs 3-4 % of the
-        product (measured: +0.4 ms on the 27-point 512^3 matrix, as much as the dot it saves)
-        and saves a pass over two vectors, which is 10 % of a 5-/7-point product."""
-        override = os.environ.get("LSK_FUSE_SPMV_DOT")
-        if override is not None:
-            return override != "0"
-        if self.sliced:
-            return True   # one lane owns a row there: the shares cost next to nothing
-        return self.rows > 0 and self.nnz / self.rows <= self.FUSE_DOT_MAX_ROW_LENGTH
-
-    def compress(self, x_lo: int, x_hi: int, kernel_partition, range_partition) -> bool:
-        """Set-up-time copy of the matrix structure in 32 bits: the column field as offsets into
-        the window x_lo..x_hi of the input vector (the ghost interval the planner found for this
-        rank) and, per piece, the rects as rows + 1 offsets into the piece's entries.  Products
-        against exactly that window then read 4 instead of 8 bytes of column and 4 instead of 16
-        of row structure and give bit-identical results.  What the reference redoes on every
-        call for cuSPARSE (src/CuSPARSEHelpers.hpp:9-31,71-80), done once.  LSK_COMPRESS=0 turns
-        it off.  Returns whether the copy was made (not for windows of 2^32 - 1 columns or more,
-        pieces of 2^32 entries or more, or rects that are not back to back)."""
-        be = self.ctx.backend
-        cols, rows_of = getattr(be, "csr_compress_cols", None), getattr(be, "csr_compress_rows", None)
-        if (cols is None or rows_of is None or os.environ.get("LSK_COMPRESS", "1") == "0" or x_hi < x_lo
-                or self.nnz == 0 or x_hi - x_lo + 1 > be.COMPRESS_MAX_EXTENT):
-            return False
-        rowoff = {}
-        for i, c in enumerate(kernel_partition.colors):
-            p = range_partition.pieces[c]
-            k_lo, k_hi = kernel_partition.intervals[i]
-            nnz = max(k_hi - k_lo + 1, 0)
-            if p.volume == 0:
-                continue
-            r0 = p.lo[0] - self.row_lo
-            off = rows_of(self.rects[r0:r0 + p.volume], k_lo if nnz else self.k_base, nnz)
-            if off is None:
-                return False
-            rowoff[c] = off
-        self.rowoff = rowoff
-        self.col32 = cols(self.col, x_lo, x_hi)
-        self.col32_window = (int(x_lo), int(x_hi))
-        return True
-
-    SLICED_REDRAWS = 6
-
-    def slice_structure(self, x_lo: int, x_hi: int, kernel_partition, range_partition) -> bool:
-        """Set-up-time re-layout for matrices whose rows repeat a few column patterns (every
-        linearised stencil): per piece a copy of the values in slices of 64 rows plus one pattern id
-        per row; products against the window x_lo..x_hi then read no column array and no row
-        structure, and sum every row in entry order with separate multiply and add -- bit for bit
-        the loop of src/CSRMatrixTasks.cpp:73-91.  All pieces or none.  LSK_SLICED=0 turns it off.
-        For large pieces the tile placement is then chosen by timing, and the copy is made up to
-        SLICED_REDRAWS more times, keeping the fastest (where the driver puts an array in HBM
-        moves the product's time by several per cent)."""
-        be = self.ctx.backend
-        maker = getattr(be, "csr_sliced_create", None)
-        if maker is None or os.environ.get("LSK_SLICED", "1") == "0" or x_hi < x_lo or self.nnz == 0:
-            return False
-
-        def make(i, c):
-            p = range_partition.pieces[c]
-            k_lo, k_hi = kernel_partition.intervals[i]
-            nnz = max(k_hi - k_lo + 1, 0)
-            r0, off = p.lo[0] - self.row_lo, k_lo - self.k_base
-            return maker(p.volume, nnz, self.rects[r0:r0 + p.volume], k_lo, self.col[off:off + nnz],
-                         self.val[off:off + nnz], p.lo[0], x_lo, x_hi)
-
         made = {}
         for i, c in enumerate(kernel_partition.colors):
             k_lo, k_hi = kernel_partition.intervals[i]
@@ -310,6 +221,110 @@ class CSRMatrix(AbstractMatrix):
         t1.record()
         t1.synchronize()
         return t0.elapsed_time(t1) / reps
+
+
+
+class CSRMatrix(AbstractMatrix, _SlicedCopies):
+    def __init__(self, ctx, rects: torch.Tensor, k_base: int, col: torch.Tensor, val: torch.Tensor,
+                 range_space: IndexSpace, row_lo: int):
+        """rects: this rank's rows row_lo .. row_lo+rows-1; col/val: the kernel entries
+        k_base .. k_base+nnz-1 those rects point into."""
+        if rects.dtype != torch.int64 or col.dtype != torch.int64:
+            raise TypeError("rects and col must be int64 (the reference's long long coordinates)")
+        if rects.dim() != 2 or rects.shape[1] != 2 or not rects.is_contiguous():
+            raise ValueError("rects must be a contiguous (rows, 2) tensor")
+        if col.numel() != val.numel():
+            raise ValueError("col and val differ in length")
+        self.ctx = ctx
+        self.rects, self.k_base, self.col, self.val = rects, int(k_base), col, val
+        self.dtype = val.dtype
+        self.range_space = range_space
+        self.row_lo = int(row_lo)
+        self.rows = rects.shape[0]
+        self.nnz = col.numel()
+        self.placement = {}  # piece colour -> tile placement found by tune()
+        self.col32 = None         # compress(): the column field as 32-bit offsets into ...
+        self.col32_window = None  # ... this window (x_lo, x_hi)
+        self.rowoff = {}          # ... and per piece colour rows + 1 32-bit offsets of the rows' entries
+        self._init_sliced()
+
+    def transpose(self, x_lo: int, x_hi: int, row_lo: int, rows: int) -> TransposedBlock:
+        """The transpose of this rank's rows against the window x_lo..x_hi of the domain."""
+        if row_lo != self.row_lo or rows != self.rows:
+            raise ValueError("rmatvec: the source vector does not hold exactly this rank's rows")
+        be = self.ctx.backend
+        return TransposedBlock(be, self.col, be.csr_entry_rows(self.rects, self.k_base, self.nnz), self.val,
+                               x_lo, x_hi, rows)
+
+    def rmatvec(self, out, out_lo, out_hi, src, src_lo, beta):
+        _transposed_for(self, out_lo, out_hi, src, src_lo).apply(self.ctx.backend, out, src, beta)
+
+    FUSE_DOT_MAX_ROW_LENGTH = 16.0
+
+    def fuses_dot(self) -> bool:
+        """Whether the fused product + dot leaf pays on this matrix.  It costs 3-4 % of the
+        product (measured: +0.4 ms on the 27-point 512^3 matrix, as much as the dot it saves)
+        and saves a pass over two vectors, which is 10 % of a 5-/7-point product."""
+        override = os.environ.get("LSK_FUSE_SPMV_DOT")
+        if override is not None:
+            return override != "0"
+        if self.sliced:
+            return True   # one lane owns a row there: the shares cost next to nothing
+        return self.rows > 0 and self.nnz / self.rows <= self.FUSE_DOT_MAX_ROW_LENGTH
+
+    def compress(self, x_lo: int, x_hi: int, kernel_partition, range_partition) -> bool:
+        """Set-up-time copy of the matrix structure in 32 bits: the column field as offsets into
+        the window x_lo..x_hi of the input vector (the ghost interval the planner found for this
+        rank) and, per piece, the rects as rows + 1 offsets into the piece's entries.  Products
+        against exactly that window then read 4 instead of 8 bytes of column and 4 instead of 16
+        of row structure and give bit-identical results.  What the reference redoes on every
+        call for cuSPARSE (src/CuSPARSEHelpers.hpp:9-31,71-80), done once.  LSK_COMPRESS=0 turns
+        it off.  Returns whether the copy was made (not for windows of 2^32 - 1 columns or more,
+        pieces of 2^32 entries or more, or rects that are not back to back)."""
+        be = self.ctx.backend
+        cols, rows_of = getattr(be, "csr_compress_cols", None), getattr(be, "csr_compress_rows", None)
+        if (cols is None or rows_of is None or os.environ.get("LSK_COMPRESS", "1") == "0" or x_hi < x_lo
+                or self.nnz == 0 or x_hi - x_lo + 1 > be.COMPRESS_MAX_EXTENT):
+            return False
+        rowoff = {}
+        for i, c in enumerate(kernel_partition.colors):
+            p = range_partition.pieces[c]
+            k_lo, k_hi = kernel_partition.intervals[i]
+            nnz = max(k_hi - k_lo + 1, 0)
+            if p.volume == 0:
+                continue
+            r0 = p.lo[0] - self.row_lo
+            off = rows_of(self.rects[r0:r0 + p.volume], k_lo if nnz else self.k_base, nnz)
+            if off is None:
+                return False
+            rowoff[c] = off
+        self.rowoff = rowoff
+        self.col32 = cols(self.col, x_lo, x_hi)
+        self.col32_window = (int(x_lo), int(x_hi))
+        return True
+
+    def slice_structure(self, x_lo: int, x_hi: int, kernel_partition, range_partition) -> bool:
+        """Set-up-time re-layout for matrices whose rows repeat a few column patterns (every
+        linearised stencil): per piece a copy of the values in slices of 64 rows plus one pattern id
+        per row; products against the window x_lo..x_hi then read no column array and no row
+        structure, and sum every row in entry order with separate multiply and add -- bit for bit
+        the loop of src/CSRMatrixTasks.cpp:73-91.  All pieces or none.  LSK_SLICED=0 turns it off.
+        For large pieces the tile placement is then chosen by timing, and the copy is made up to
+        SLICED_REDRAWS more times, keeping the fastest (where the driver puts an array in HBM
+        moves the product's time by several per cent)."""
+        be = self.ctx.backend
+        maker = getattr(be, "csr_sliced_create", None)
+        if maker is None or os.environ.get("LSK_SLICED", "1") == "0" or x_hi < x_lo or self.nnz == 0:
+            return False
+
+        def make(i, c):
+            p = range_partition.pieces[c]
+            k_lo, k_hi = kernel_partition.intervals[i]
+            nnz = max(k_hi - k_lo + 1, 0)
+            r0, off = p.lo[0] - self.row_lo, k_lo - self.k_base
+            return maker(p.volume, nnz, self.rects[r0:r0 + p.volume], k_lo, self.col[off:off + nnz],
+                         self.val[off:off + nnz], p.lo[0], x_lo, x_hi)
+        return self._make_sliced_copies(make, x_lo, x_hi, kernel_partition, range_partition)
 
     def _structure(self, x_lo: int, x_hi: int, c: int, r0: int, ra: int, rb: int):
         """(row field, column array) a product of rows [ra, rb) of piece c (whose first row is
@@ -555,7 +570,7 @@ class CSRMatrix(AbstractMatrix):
             dst._note_ready(dot_with, pieces)
 
 
-class COOMatrix(AbstractMatrix):
+class COOMatrix(AbstractMatrix, _SlicedCopies):
     def __init__(self, ctx, row: torch.Tensor, col: torch.Tensor, val: torch.Tensor,
                  range_space: IndexSpace):
         """This rank's entries: every entry whose row this rank owns (the preimage of its
@@ -575,6 +590,7 @@ class COOMatrix(AbstractMatrix):
         self.row32 = self.col32 = None  # compress(): 32-bit copies of the index fields ...
         self.col32_window = None        # ... for this x window (x_lo, x_hi) ...
         self.row_origin = 0             # ... and rows counted from this global row
+        self._init_sliced()
 
     def compress(self, x_lo: int, x_hi: int, kernel_partition, range_partition) -> bool:
         """Set-up-time 32-bit copies of the index fields: columns as offsets into the window
@@ -607,6 +623,31 @@ class COOMatrix(AbstractMatrix):
 
     def rmatvec(self, out, out_lo, out_hi, src, src_lo, beta):
         _transposed_for(self, out_lo, out_hi, src, src_lo).apply(self.ctx.backend, out, src, beta)
+
+    def slice_structure(self, x_lo: int, x_hi: int, kernel_partition, range_partition) -> bool:
+        """The sliced-pattern copy (see CSRMatrix.slice_structure) for row-sorted COO matrices whose
+        rows repeat a few column patterns: the rows' runs of entries are what a CSR matrix calls its
+        rects.  One lane then sums a row's entries in entry order onto what y holds, which for
+        row-sorted entries is bit for bit the loop of src/COOMatrixTasks.cpp:67-74.  A matrix with
+        a column outside the window, unsorted rows or no such structure keeps the forms above."""
+        be = self.ctx.backend
+        maker = getattr(be, "csr_sliced_create", None)
+        if (maker is None or os.environ.get("LSK_SLICED", "1") == "0" or x_hi < x_lo or self.nnz == 0
+                or not self.row_sorted):
+            return False
+
+        def make(i, c):
+            p = range_partition.pieces[c]
+            k_lo, k_hi = kernel_partition.intervals[i]
+            nnz = k_hi - k_lo + 1
+            bounds = torch.arange(p.lo[0], p.hi[0] + 2, dtype=torch.int64, device=self.row.device)
+            first = torch.searchsorted(self.row[k_lo:k_lo + nnz], bounds) + k_lo   # rows + 1 entry offsets
+            rects = torch.stack((first[:-1], first[1:] - 1), dim=1).contiguous()
+            del bounds, first
+            return maker(p.volume, nnz, rects, k_lo, self.col[k_lo:k_lo + nnz], self.val[k_lo:k_lo + nnz],
+                         p.lo[0], x_lo, x_hi)
+
+        return self._make_sliced_copies(make, x_lo, x_hi, kernel_partition, range_partition)
 
     BLOCK_BYTES = 4 << 20        # of x per column block: what one XCD's L2 holds beside the stream
     BLOCK_MIN_WINDOW = 16 << 20  # smaller x windows are not worth re-ordering for
@@ -683,12 +724,19 @@ class COOMatrix(AbstractMatrix):
     def create_domain_partition_from_kernel_partition(self, domain_space, kernel_partition):
         return _ghost_from_kernel(self.ctx, self.col, 0, domain_space, kernel_partition)
 
+    def overwrites(self, x_lo, x_hi, kernel_partition, range_partition) -> bool:
+        """Whether matvec(beta = 0) is available: every local piece that has rows is multiplied
+        through its sliced-pattern copy, which can start a row's sum from zero (the zero fill the
+        reference does before an accumulating product, src/SquarePlanner.hpp:341, then falls away)."""
+        return self.sliced_window == (x_lo, x_hi) and all(
+            c in self.sliced for c in kernel_partition.colors if range_partition.pieces[c].volume > 0)
+
     def matvec(self, dst, x, x_lo, x_hi, kernel_partition, beta=1, range_partition=None):
         """COOMatrix::matvec (src/COOMatrix.cpp:144-191): accumulates; dst must hold the
-        values to add to (the planner zero-fills it)."""
-        if beta != 1:
-            raise ValueError("COO matvec accumulates (beta = 1)")
+        values to add to (the planner zero-fills it).  beta = 0 where overwrites() says so."""
         range_partition = range_partition or dst.index_partition
+        if beta != 1 and not (beta == 0 and self.overwrites(x_lo, x_hi, kernel_partition, range_partition)):
+            raise ValueError("COO matvec accumulates (beta = 1)")
         touch = getattr(dst, "_touch", None)
         if touch is not None:
             touch()
@@ -697,6 +745,10 @@ class COOMatrix(AbstractMatrix):
             k_lo, k_hi = kernel_partition.intervals[i]
             nnz = max(k_hi - k_lo + 1, 0)
             if p.volume == 0 or nnz == 0:
+                continue
+            if c in self.sliced and self.sliced_window == (x_lo, x_hi):
+                self.ctx.backend.csr_sliced_spmv(self.sliced[c], 0, p.volume, x, dst.piece(i), beta,
+                                                 self.sliced_placement.get(c, 0))
                 continue
             if self.blocked and self.col32_window == (x_lo, x_hi):
                 # (one local piece) every entry is visited; the row window selects, as always

@@ -285,6 +285,9 @@ class SquarePlanner:
             comm = self.ctx.comm
             if isinstance(e.matrix, COOMatrix):
                 comm.exchange_finish(handle)
+                if first and e.matrix.overwrites(x_lo, x_hi, e.kernel_partition, dst.index_partition):
+                    e.matrix.matvec(dst, x, x_lo, x_hi, e.kernel_partition, 0)
+                    continue
                 if first:
                     dst.zero_fill()
                 e.matrix.matvec(dst, x, x_lo, x_hi, e.kernel_partition, 1)
