@@ -150,7 +150,8 @@ class _SlicedCopies:
         self.sliced, self.sliced_window = made, (int(x_lo), int(x_hi))
         if os.environ.get("LSK_TUNE", "1") == "0" or not self.val.is_cuda:
             return True
-        x = y = None
+        x = y = last = None
+        freed_total = 0
         redraws = int(os.environ.get("LSK_TUNE_REDRAWS", self.SLICED_REDRAWS))
         for i, c in enumerate(kernel_partition.colors):
             rows = range_partition.pieces[c].volume
@@ -180,8 +181,10 @@ class _SlicedCopies:
                     self.sliced[c], self.sliced_placement[c], best = other, pl, t
                 else:
                     other.close()
-            if freed >= (1 << 30):  # (smaller amounts are scrubbed before anyone could notice)
-                self._wait_until_steady(c, rows, x, y, best, freed)
+            freed_total += freed
+            last = (c, rows, best)
+        if freed_total >= (1 << 30):  # (smaller amounts are scrubbed before anyone could notice)
+            self._wait_until_steady(last[0], last[1], x, y, last[2], freed_total)
         return True
 
     SETTLE_SECONDS = 12.0
