@@ -40,7 +40,9 @@ int allreduce_sum(lsk_comm_t c, T *buf, int count, lsk_stream_t stream) {
     if (count < 0) return lsk::fail(LSK_ERR_ARG, "lsk_allreduce_sum: negative count");
     if (count == 0) return LSK_OK;
     if (!buf) return lsk::fail(LSK_ERR_ARG, "lsk_allreduce_sum: null buffer");
-    if (c->nranks == 1) return LSK_OK; // sum over one rank
+    // A sum over one rank changes nothing; option "comm.skip_single_rank" = 0 enqueues the RCCL
+    // call all the same (what a one-GPU machine can exercise of this path).
+    if (c->nranks == 1 && lsk::options().comm_skip_single_rank) return LSK_OK;
     LSK_NCCL(ncclAllReduce(buf, buf, size_t(count), NcclType<T>::value, ncclSum, c->comm,
                            lsk::as_stream(stream)));
     return LSK_OK;
@@ -65,15 +67,24 @@ int halo_exchange(lsk_comm_t c, int nsend, const int *send_peer, const T *const 
             return lsk::fail(LSK_ERR_ARG, "lsk_halo_exchange: bad recv entry %d", i);
     hipStream_t s = lsk::as_stream(stream);
     LSK_NCCL(ncclGroupStart());
-    for (int i = 0; i < nsend; ++i)
-        if (send_count[i] > 0)
-            LSK_NCCL(ncclSend(send_ptr[i], size_t(send_count[i]), NcclType<T>::value, send_peer[i],
-                              c->comm, s));
-    for (int i = 0; i < nrecv; ++i)
-        if (recv_count[i] > 0)
-            LSK_NCCL(ncclRecv(recv_ptr[i], size_t(recv_count[i]), NcclType<T>::value, recv_peer[i],
-                              c->comm, s));
-    LSK_NCCL(ncclGroupEnd());
+    // From here on the group is open: a failing call is remembered, the group is closed whatever
+    // happened (a group left open would swallow every later RCCL call of this thread), and the
+    // first failure is what the caller gets.
+    ncclResult_t first = ncclSuccess;
+    const char *what = "";
+    for (int i = 0; i < nsend && first == ncclSuccess; ++i)
+        if (send_count[i] > 0) {
+            first = ncclSend(send_ptr[i], size_t(send_count[i]), NcclType<T>::value, send_peer[i], c->comm, s);
+            what = "ncclSend";
+        }
+    for (int i = 0; i < nrecv && first == ncclSuccess; ++i)
+        if (recv_count[i] > 0) {
+            first = ncclRecv(recv_ptr[i], size_t(recv_count[i]), NcclType<T>::value, recv_peer[i], c->comm, s);
+            what = "ncclRecv";
+        }
+    const ncclResult_t closed = ncclGroupEnd();
+    if (first != ncclSuccess) return nccl_fail(first, what, __FILE__, __LINE__);
+    if (closed != ncclSuccess) return nccl_fail(closed, "ncclGroupEnd", __FILE__, __LINE__);
     return LSK_OK;
 }
 
@@ -83,6 +94,12 @@ int allgather(lsk_comm_t c, const T *send, T *recv, int64_t count, lsk_stream_t 
     if (count < 0) return lsk::fail(LSK_ERR_ARG, "lsk_allgather: negative count");
     if (count == 0) return LSK_OK;
     if (!send || !recv) return lsk::fail(LSK_ERR_ARG, "lsk_allgather: null buffer");
+    if (c->nranks == 1 && lsk::options().comm_skip_single_rank) { // one rank: recv <- send
+        if (send != recv)
+            LSK_HIP(hipMemcpyAsync(recv, send, size_t(count) * sizeof(T), hipMemcpyDeviceToDevice,
+                                   lsk::as_stream(stream)));
+        return LSK_OK;
+    }
     LSK_NCCL(ncclAllGather(send, recv, size_t(count), NcclType<T>::value, c->comm,
                            lsk::as_stream(stream)));
     return LSK_OK;

@@ -61,6 +61,7 @@ struct Options {
     int csr_max_units = 0;   // 16-byte units per lane in flight in the wave-tile form: 0 = by tile size, 4 or 8
     int blas1_form = 1;      // 0: grid-strided accesses, 1: contiguous chunk per workgroup
     int coo_variant = 1;     // 0: workgroup chunks through LDS, 1: wave-wide segmented scan
+    int comm_skip_single_rank = 1; // one-rank communicators: answer without calling RCCL
 };
 Options &options();
 

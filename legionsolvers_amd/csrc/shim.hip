@@ -109,6 +109,8 @@ int lsk_set_option(const char *key, int value) {
     } else if (!std::strcmp(key, "coo.variant")) {
         if (value != 0 && value != 1) return lsk::fail(LSK_ERR_ARG, "coo.variant must be 0 or 1");
         o.coo_variant = value;
+    } else if (!std::strcmp(key, "comm.skip_single_rank")) {
+        o.comm_skip_single_rank = value != 0;
     } else {
         return lsk::fail(LSK_ERR_ARG, "lsk_set_option: unknown key '%s'", key);
     }
@@ -125,6 +127,7 @@ int lsk_get_option(const char *key, int *value) {
     else if (!std::strcmp(key, "csr.max_units")) *value = o.csr_max_units;
     else if (!std::strcmp(key, "blas1.form")) *value = o.blas1_form;
     else if (!std::strcmp(key, "coo.variant")) *value = o.coo_variant;
+    else if (!std::strcmp(key, "comm.skip_single_rank")) *value = o.comm_skip_single_rank;
     else return lsk::fail(LSK_ERR_ARG, "lsk_get_option: unknown key '%s'", key);
     return LSK_OK;
 }

@@ -248,7 +248,10 @@ def test_shim_memory_and_streams():
 
 
 def test_rccl_layer_single_rank():
-    """The RCCL entry points with a one-rank communicator (all a 1-GPU box can run)."""
+    """The RCCL entry points with a one-rank communicator (all a 1-GPU box can run).  With option
+    comm.skip_single_rank = 0 the collectives are really enqueued on the stream (ncclAllReduce,
+    ncclAllGather over one rank), between kernels that produce and consume their operands, as a dot
+    product's all-reduce sits between the fold kernel and the next axpy."""
     lib = _lib.lib()
     uid = ctypes.create_string_buffer(_lib.UNIQUE_ID_BYTES)
     _lib.check(lib.lsk_comm_unique_id(uid))
@@ -257,17 +260,42 @@ def test_rccl_layer_single_rank():
     r, w = ctypes.c_int(-1), ctypes.c_int(-1)
     _lib.check(lib.lsk_comm_rank(comm, ctypes.byref(r), ctypes.byref(w)))
     assert (r.value, w.value) == (0, 1)
-    buf = dev(np.array([1.5, 2.5]))
-    _lib.check(lib.lsk_allreduce_sum_f64(comm, P(buf), 2, stream()))
-    out = torch.zeros(2, dtype=torch.float64, device="cuda")
-    _lib.check(lib.lsk_allgather_f64(comm, P(buf), P(out), 2, stream()))
+    for skip in (1, 0):
+        print(f"case rccl single rank, comm.skip_single_rank={skip}", flush=True)
+        _lib.check(lib.lsk_set_option(b"comm.skip_single_rank", skip))
+        try:
+            for suf, tdt in (("f64", torch.float64), ("f32", torch.float32)):
+                v = torch.arange(1, 65, dtype=tdt, device="cuda")  # every partial sum exact in fp32
+                buf = torch.zeros(2, dtype=tdt, device="cuda")
+                # dot -> all-reduce -> scal by the reduced value, all stream-ordered
+                _lib.call(f"lsk_dot_{suf}", 64, P(v), P(v), P(buf[0:1]), None, 0, stream())
+                _lib.call(f"lsk_nrm2_{suf}", 64, P(v), P(buf[1:2]), None, 0, stream())
+                _lib.check(getattr(lib, f"lsk_allreduce_sum_{suf}")(comm, P(buf), 2, stream()))
+                y = torch.ones(8, dtype=tdt, device="cuda")
+                _lib.call(f"lsk_scal_dev_{suf}", 8, 1, P(buf[0:1]), None, None, None, P(y), stream())
+                out = torch.zeros(2, dtype=tdt, device="cuda")
+                _lib.check(getattr(lib, f"lsk_allgather_{suf}")(comm, P(buf), P(out), 2, stream()))
+                torch.cuda.synchronize()
+                want = float(sum(i * i for i in range(1, 65)))
+                assert buf[0].item() == want and abs(buf[1].item() - want ** 0.5) < 1e-4
+                assert out.tolist() == buf.tolist()
+                assert y.tolist() == [want] * 8
+        finally:
+            _lib.check(lib.lsk_set_option(b"comm.skip_single_rank", 1))
     _lib.check(lib.lsk_halo_exchange_f64(comm, 0, None, None, None, 0, None, None, None, stream()))
-    torch.cuda.synchronize()
-    assert buf.tolist() == [1.5, 2.5] and out.tolist() == [1.5, 2.5]
+    buf = dev(np.array([1.5, 2.5]))
     bad_peer = (ctypes.c_int * 1)(0)
     ptrs = (ctypes.c_void_p * 1)(buf.data_ptr())
     cnt = (ctypes.c_int64 * 1)(1)
     assert lib.lsk_halo_exchange_f64(comm, 1, bad_peer, ptrs, cnt, 0, None, None, None, stream()) == -2
+    # after a refused exchange the communicator still works (no RCCL group was left open)
+    _lib.check(lib.lsk_set_option(b"comm.skip_single_rank", 0))
+    try:
+        _lib.check(lib.lsk_allreduce_sum_f64(comm, P(buf), 2, stream()))
+    finally:
+        _lib.check(lib.lsk_set_option(b"comm.skip_single_rank", 1))
+    torch.cuda.synchronize()
+    assert buf.tolist() == [1.5, 2.5]
     _lib.check(lib.lsk_comm_destroy(comm))
 
 
