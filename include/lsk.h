@@ -56,16 +56,17 @@ void lsk_set_abort_on_error(int enable);
  * result.  Keys: "csr.variant" (0 workgroup tiles | 1 wave tiles, default 1),
  * "csr.nontemporal" (0 | 1: stream col/val past the caches, default 0), "xcd_remap" (c > 0:
  * each XCD takes runs of c consecutive tiles; c < 0: one contiguous eighth of the tiles per
- * XCD; 0: workgroup id = tile id, the default), "csr.log_rows_per_wave" (-1 = from
+ * XCD; 0: workgroup id = tile id, the default; kept PER HOST THREAD, so that the value a thread
+ * sets before its launch, or a tuner flips while it times candidates, never reaches launches made
+ * from another thread), "csr.log_rows_per_wave" (-1 = from
  * the mean row length, else 0..8), "csr.max_units" (16-byte units per lane the wave-tile form
  * keeps in flight: 0 = chosen from the mean tile size, 4 or 8), "blas1.form" (0 grid-strided | 1 contiguous chunk per
  * workgroup, default 1), "coo.variant" (0 workgroup chunks through LDS | 1 wave-wide segmented
  * scan, default 1), "comm.skip_single_rank" (1, the default: lsk_allreduce_sum_* / lsk_allgather_* on a
  * one-rank communicator answer without calling RCCL | 0: they enqueue the RCCL collective all the
  * same).  No counterpart in the reference
- * (cuSPARSE picks its own algorithm behind CUSPARSE_SPMV_ALG_DEFAULT).  Options are
- * process-wide and read at launch time without synchronisation: set them from the thread that
- * launches, between launches. */
+ * (cuSPARSE picks its own algorithm behind CUSPARSE_SPMV_ALG_DEFAULT).  All other options
+ * are process-wide and read at launch time without synchronisation: set them between launches. */
 int lsk_set_option(const char *key, int value);
 int lsk_get_option(const char *key, int *value);
 
@@ -457,7 +458,8 @@ int lsk_sorted_key_offsets_u32(int64_t n, const uint32_t *keys, int64_t nkeys, u
  *
  * rows, nnz, rects, k_base, col, val as lsk_csr_spmv_*; row_first = global index of rects' first
  * row; x_lo..x_hi = the window of the input vector every product will be given (x[0] = element
- * x_lo); y[0] = the first row.  The structure holds a COPY of the values: remake it when they change.
+ * x_lo); y[0] = the first row.  The structure holds a COPY of the values: lsk_csr_sliced_update_values_*
+ * brings it up to date when they change.
  * create answers LSK_ERR_UNSUPPORTED (never an abort) when the matrix has no such structure
  * (more patterns, longer rows, a column outside the window, rects outside the piece, or padding
  * that would cost more than the column array saves): stay with lsk_csr_spmv_c32_* / lsk_csr_spmv_*.
@@ -473,6 +475,16 @@ int lsk_csr_sliced_create_f32(int64_t rows, int64_t nnz, const int64_t *rects, i
 int lsk_csr_sliced_create_f64(int64_t rows, int64_t nnz, const int64_t *rects, int64_t k_base, const int64_t *col,
                               const double *val, int64_t row_first, int64_t x_lo, int64_t x_hi, lsk_stream_t stream,
                               lsk_csr_sliced_t **out);
+/* The structure holds a copy of the entry values, whereas the reference's task reads the region on
+ * every call (src/CSRMatrixTasks.cu:88-118).  A caller that rewrites the entries in place (same rects,
+ * same columns, new values) calls this before its next product: it copies `val` into the slices again
+ * (the last set-up kernel alone: one read of val, one write of the slices, stream-ordered, no
+ * allocation, no synchronisation).  rows, nnz, rects, k_base as given to create; a change of the
+ * STRUCTURE needs destroy + create. */
+int lsk_csr_sliced_update_values_f32(lsk_csr_sliced_t *m, int64_t rows, int64_t nnz, const int64_t *rects,
+                                     int64_t k_base, const float *val, lsk_stream_t stream);
+int lsk_csr_sliced_update_values_f64(lsk_csr_sliced_t *m, int64_t rows, int64_t nnz, const int64_t *rects,
+                                     int64_t k_base, const double *val, lsk_stream_t stream);
 int lsk_csr_sliced_spmv_f32(const lsk_csr_sliced_t *m, int64_t row_begin, int64_t row_end, const float *x, float *y,
                             int beta, lsk_stream_t stream);
 int lsk_csr_sliced_spmv_f64(const lsk_csr_sliced_t *m, int64_t row_begin, int64_t row_end, const double *x, double *y,

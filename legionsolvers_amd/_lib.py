@@ -82,6 +82,8 @@ PROTOTYPES = {
     "lsk_gather_f64": (_i, [_i64, _p, _p, _p, _p]),
     "lsk_csr_sliced_create_f32": (_i, [_i64, _i64, _p, _i64, _p, _p, _i64, _i64, _i64, _p, _p]),
     "lsk_csr_sliced_create_f64": (_i, [_i64, _i64, _p, _i64, _p, _p, _i64, _i64, _i64, _p, _p]),
+    "lsk_csr_sliced_update_values_f32": (_i, [_p, _i64, _i64, _p, _i64, _p, _p]),
+    "lsk_csr_sliced_update_values_f64": (_i, [_p, _i64, _i64, _p, _i64, _p, _p]),
     "lsk_csr_sliced_spmv_f32": (_i, [_p, _i64, _i64, _p, _p, _i, _p]),
     "lsk_csr_sliced_spmv_f64": (_i, [_p, _i64, _i64, _p, _p, _i, _p]),
     "lsk_csr_sliced_spmv_dot_f32": (_i, [_p, _i64, _i64, _p, _p, _i, _p, _p, _i64, _p, _p]),

@@ -8,6 +8,7 @@ and the built library: there is no CPU fallback in the product path.
 from __future__ import annotations
 
 import ctypes
+import threading
 from typing import Sequence, Tuple
 
 import torch
@@ -37,12 +38,14 @@ class HipBackend:
         # Partial sums of dot/nrm2: private to this backend so that other users of the
         # library's per-device scratch cannot race with it.
         self._ws_bytes = int(self.lib.lsk_dot_workspace_bytes(0))
-        self._placement = 0  # value of the library's xcd_remap option as last set from here
+        self._placed = threading.local()  # the library's xcd_remap option (kept per host thread) as last set
         self._ws = torch.empty(self._ws_bytes, dtype=torch.uint8, device=self.device)
 
     # -- plumbing ------------------------------------------------------------------------
     def stream(self) -> ctypes.c_void_p:
-        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        """torch's current stream on this device, as the raw hipStream_t (asked for on every launch,
+        so through the one-call accessor rather than a torch.cuda.Stream object)."""
+        return ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(self.device.index))
 
     def empty(self, n: int, dtype: torch.dtype) -> torch.Tensor:
         return torch.empty(int(n), dtype=dtype, device=self.device)
@@ -52,6 +55,12 @@ class HipBackend:
 
     def synchronize(self) -> None:
         torch.cuda.current_stream(self.device).synchronize()
+
+    def _place(self, placement: int) -> None:
+        """Sets the tile -> XCD placement for this thread's next launches."""
+        if getattr(self._placed, "value", None) != placement:
+            _lib.call("lsk_set_option", b"xcd_remap", placement)
+            self._placed.value = placement
 
     # -- BLAS-1 ----------------------------------------------------------------------------
     @staticmethod
@@ -119,9 +128,7 @@ class HipBackend:
                      val: torch.Tensor, x: torch.Tensor, x_lo: int, x_hi: int, y: torch.Tensor,
                      beta: int, w: torch.Tensor, partials: torch.Tensor, placement: int = 0) -> int:
         """y as csr_spmv; partials[:count] <- shares of sum(y_new * w).  Returns count."""
-        if placement != self._placement:
-            _lib.call("lsk_set_option", b"xcd_remap", placement)
-            self._placement = placement
+        self._place(placement)
         count = ctypes.c_int64(0)
         if col.dtype == torch.int32:
             _lib.call(f"lsk_csr_spmv_c32_dot_{_lib.suffix(val.dtype)}", rows, nnz, _ptr(rects), _ptr(col),
@@ -156,9 +163,7 @@ class HipBackend:
         `rects`, `col`: the (rows, 2) int64 rects and int64 global column ids, or the int32-typed
         arrays of csr_compress_rows (rows + 1 offsets) and csr_compress_cols (made for the window
         x_lo..x_hi; x[0] is the window's first element either way; k_base is then unused)."""
-        if placement != self._placement:
-            _lib.call("lsk_set_option", b"xcd_remap", placement)
-            self._placement = placement
+        self._place(placement)
         if col.dtype == torch.int32:
             _lib.call(f"lsk_csr_spmv_c32_{_lib.suffix(val.dtype)}", rows, nnz, _ptr(rects), _ptr(col),
                       _ptr(val), _ptr(x), x_hi - x_lo + 1, _ptr(y), beta, self.stream())
@@ -179,13 +184,17 @@ class HipBackend:
         _lib.check(code)
         return SlicedStructure(self.lib, handle, val.dtype)
 
+    def csr_sliced_update_values(self, sliced: "SlicedStructure", rows: int, nnz: int, rects: torch.Tensor,
+                                 k_base: int, val: torch.Tensor) -> None:
+        """Copies the entry values into the sliced-pattern copy again (same structure, new values)."""
+        _lib.call(f"lsk_csr_sliced_update_values_{_lib.suffix(sliced.dtype)}", sliced.handle, rows, nnz, _ptr(rects),
+                  k_base, _ptr(val), self.stream())
+
     def csr_sliced_spmv(self, sliced: "SlicedStructure", row_begin: int, row_end: int, x: torch.Tensor,
                         y: torch.Tensor, beta: int, placement: int = 0) -> None:
         """Rows row_begin..row_end-1 of y <- A x + beta y; x[0] is the window's first element, y[0] the
         piece's first row."""
-        if placement != self._placement:
-            _lib.call("lsk_set_option", b"xcd_remap", placement)
-            self._placement = placement
+        self._place(placement)
         _lib.call(f"lsk_csr_sliced_spmv_{_lib.suffix(sliced.dtype)}", sliced.handle, row_begin, row_end, _ptr(x),
                   _ptr(y), beta, self.stream())
 
@@ -206,9 +215,7 @@ class HipBackend:
                             w: torch.Tensor, partials: torch.Tensor, placement: int = 0, row_begin: int = 0) -> int:
         """Rows row_begin..row_end-1 of the piece's product, and partials[:count] <- shares of the sum
         of y_new * w over those rows.  Returns count."""
-        if placement != self._placement:
-            _lib.call("lsk_set_option", b"xcd_remap", placement)
-            self._placement = placement
+        self._place(placement)
         count = ctypes.c_int64(0)
         _lib.call(f"lsk_csr_sliced_spmv_dot_{_lib.suffix(sliced.dtype)}", sliced.handle, row_begin, row_end, _ptr(x),
                   _ptr(y), beta, _ptr(w), _ptr(partials), partials.numel(), ctypes.byref(count), self.stream())

@@ -15,11 +15,13 @@ from .comm import Communicator
 
 class Context:
     def __init__(self, device: Optional[torch.device] = None, group=None, backend=None,
-                 fuse: Optional[bool] = None):
+                 fuse: Optional[bool] = None, comm=None):
         """fuse: let the planner use the fused leaf forms (product + dot, axpy + squared norm)
         where a solver's next dot product can reuse them; default on, LSK_FUSE=0 turns it off.
-        Results change only in the order of the additions inside the dot products."""
-        self.comm = Communicator(group)
+        Results change only in the order of the additions inside the dot products.
+        comm: an object with the interface of comm.Communicator in place of the torch.distributed
+        one (ranks that are threads of one process, for instance)."""
+        self.comm = comm if comm is not None else Communicator(group)
         self.fuse = (os.environ.get("LSK_FUSE", "1") != "0") if fuse is None else bool(fuse)
         if backend is None:
             from .backend import HipBackend

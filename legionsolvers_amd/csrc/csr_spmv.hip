@@ -764,10 +764,10 @@ int launch_csr_spmv(const char *name, int64_t rows, int64_t nnz, const void *rec
         const bool wide = tune.csr_max_units == 0 ? units > 4.0 : tune.csr_max_units == 8;
 #define LSK_CSRW_LAUNCH(L, NT, KMAX)                                                              \
     csr_spmv_wave_kernel<T, CT, L, NT, KMAX, false><<<unsigned(blocks_w), kBlock, 0, s>>>(        \
-        rows, rc, k_base, nnz, col, val, x, x_lo, x_hi, y, beta, tune.xcd_remap, nullptr, nullptr)
+        rows, rc, k_base, nnz, col, val, x, x_lo, x_hi, y, beta, lsk::xcd_remap_option(), nullptr, nullptr)
 #define LSK_CSRW_LAUNCH_DOT(L, KMAX)                                                              \
     csr_spmv_wave_kernel<T, CT, L, false, KMAX, true><<<unsigned(blocks_w), kBlock, 0, s>>>(      \
-        rows, rc, k_base, nnz, col, val, x, x_lo, x_hi, y, beta, tune.xcd_remap, w, partials)
+        rows, rc, k_base, nnz, col, val, x, x_lo, x_hi, y, beta, lsk::xcd_remap_option(), w, partials)
 #define LSK_CSRW_CASE(L)                                                                          \
     case L:                                                                                       \
         if (fused) {                                                                              \
@@ -816,7 +816,7 @@ int launch_csr_spmv(const char *name, int64_t rows, int64_t nnz, const void *rec
 #define LSK_CSR_CASE(L)                                                                       \
     case L:                                                                                   \
         csr_spmv_kernel<T, L><<<blocks, kBlock, 0, s>>>(rows, rc, k_base, nnz, col, val, x,   \
-                                                        x_lo, x_hi, y, beta, tune.xcd_remap); \
+                                                        x_lo, x_hi, y, beta, lsk::xcd_remap_option()); \
         break;
     switch (log_r) {
         LSK_CSR_CASE(2)
@@ -884,8 +884,8 @@ int tune_csr_spmv(const char *name, int64_t rows, int64_t nnz, const void *rects
                   lsk_stream_t stream, int *remap_out, float *ms_out) {
     static const int candidates[] = {0, 16, 64, 256, 1024, 4096};
     constexpr int kWarm = 2, kTimed = 5;
-    lsk::Options &tune = lsk::options();
-    const int saved = tune.xcd_remap;
+    int &placement = lsk::xcd_remap_option();
+    const int saved = placement;
     hipStream_t s = lsk::as_stream(stream);
     hipEvent_t t0 = nullptr, t1 = nullptr;
     LSK_HIP(hipEventCreate(&t0));
@@ -893,7 +893,7 @@ int tune_csr_spmv(const char *name, int64_t rows, int64_t nnz, const void *rects
     int best = saved, status = LSK_OK;
     float best_ms = -1.0f;
     for (int c : candidates) {
-        tune.xcd_remap = c;
+        placement = c;
         for (int i = 0; i < kWarm && status == LSK_OK; ++i)
             status = launch_csr_spmv<T, CT>(name, rows, nnz, rects, k_base, col, val, x, x_lo, x_hi, y, 0, stream);
         if (status != LSK_OK) break;
@@ -915,7 +915,7 @@ int tune_csr_spmv(const char *name, int64_t rows, int64_t nnz, const void *rects
             best = c;
         }
     }
-    tune.xcd_remap = saved;
+    placement = saved;
     (void)hipEventDestroy(t0);
     (void)hipEventDestroy(t1);
     if (status != LSK_OK) return status;

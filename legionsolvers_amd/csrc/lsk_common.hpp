@@ -56,7 +56,6 @@ int device_state(DeviceState **out);
 struct Options {
     int csr_variant = 1;     // 0: workgroup tiles, 1: wave tiles
     int csr_nontemporal = 0; // stream col/val with nontemporal loads
-    int xcd_remap = 0;       // tiles per XCD chunk (0 off, < 0 one contiguous eighth per XCD)
     int csr_log_rw = -1;     // log2 rows per wave for the wave-tile form; -1 = from the mean row length
     int csr_max_units = 0;   // 16-byte units per lane in flight in the wave-tile form: 0 = by tile size, 4 or 8
     int blas1_form = 1;      // 0: grid-strided accesses, 1: contiguous chunk per workgroup
@@ -64,6 +63,12 @@ struct Options {
     int comm_skip_single_rank = 1; // one-rank communicators: answer without calling RCCL
 };
 Options &options();
+
+// Option "xcd_remap" (tiles per XCD chunk; 0 off, < 0 one contiguous eighth per XCD) is kept per
+// HOST THREAD: a caller sets it right before its launch and the tuners flip it while they time
+// candidates, neither of which may leak into launches made from other threads (Legion runs one
+// thread per GPU processor).  A thread's first value is LSK_XCD_REMAP from the environment, or 0.
+int &xcd_remap_option();
 
 // Workgroup -> logical tile remap for XCD-local reuse of the input-vector window.  Workgroups
 // are dealt round-robin over the 8 XCDs (block b shares an XCD with b+8, b+16, ...).  With

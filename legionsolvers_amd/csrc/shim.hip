@@ -52,7 +52,6 @@ Options &options() {
         Options o;
         if (const char *e = std::getenv("LSK_CSR_VARIANT")) o.csr_variant = std::atoi(e);
         if (const char *e = std::getenv("LSK_CSR_NT")) o.csr_nontemporal = std::atoi(e);
-        if (const char *e = std::getenv("LSK_XCD_REMAP")) o.xcd_remap = std::atoi(e);
         if (const char *e = std::getenv("LSK_CSR_MAX_UNITS")) {
             const int v = std::atoi(e);
             if (v == 0 || v == 4 || v == 8) o.csr_max_units = v;
@@ -61,6 +60,15 @@ Options &options() {
         return o;
     }();
     return opts;
+}
+
+int &xcd_remap_option() {
+    static const int initial = [] {
+        const char *e = std::getenv("LSK_XCD_REMAP");
+        return e ? std::atoi(e) : 0;
+    }();
+    thread_local int value = initial;
+    return value;
 }
 
 int device_state(DeviceState **out) {
@@ -97,7 +105,7 @@ int lsk_set_option(const char *key, int value) {
     } else if (!std::strcmp(key, "csr.nontemporal")) {
         o.csr_nontemporal = value != 0;
     } else if (!std::strcmp(key, "xcd_remap")) {
-        o.xcd_remap = value;
+        lsk::xcd_remap_option() = value;
     } else if (!std::strcmp(key, "csr.log_rows_per_wave")) {
         if (value < -1 || value > 8) return lsk::fail(LSK_ERR_ARG, "csr.log_rows_per_wave must be -1..8");
         o.csr_log_rw = value;
@@ -122,7 +130,7 @@ int lsk_get_option(const char *key, int *value) {
     const lsk::Options &o = lsk::options();
     if (!std::strcmp(key, "csr.variant")) *value = o.csr_variant;
     else if (!std::strcmp(key, "csr.nontemporal")) *value = o.csr_nontemporal;
-    else if (!std::strcmp(key, "xcd_remap")) *value = o.xcd_remap;
+    else if (!std::strcmp(key, "xcd_remap")) *value = lsk::xcd_remap_option();
     else if (!std::strcmp(key, "csr.log_rows_per_wave")) *value = o.csr_log_rw;
     else if (!std::strcmp(key, "csr.max_units")) *value = o.csr_max_units;
     else if (!std::strcmp(key, "blas1.form")) *value = o.blas1_form;

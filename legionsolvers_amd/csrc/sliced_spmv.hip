@@ -30,7 +30,7 @@
 
 struct lsk_csr_sliced {
     int elem_bytes = 0;
-    int64_t rows = 0, row_first = 0, x_lo = 0, x_hi = -1;
+    int64_t rows = 0, nnz = 0, k_base = 0, row_first = 0, x_lo = 0, x_hi = -1;
     int64_t slices = 0, padded_entries = 0, mixed_slices = 0, masked_slices = 0;
     int patterns = 0;
     void *val = nullptr;           // padded_entries values, slice by slice, entry-major inside a slice
@@ -337,6 +337,8 @@ int create(const char *name, int64_t rows, int64_t nnz, const int64_t *rects, in
     if (!m) return lsk::fail(LSK_ERR_ARG, "%s: out of host memory", name);
     m->elem_bytes = sizeof(T);
     m->rows = rows;
+    m->nnz = nnz;
+    m->k_base = k_base;
     m->row_first = row_first;
     m->x_lo = x_lo;
     m->x_hi = x_hi;
@@ -446,6 +448,26 @@ int create(const char *name, int64_t rows, int64_t nnz, const int64_t *rects, in
     return LSK_OK;
 }
 
+// The values again, from the caller's array into the slices (pass 4 alone): for a caller that has
+// rewritten the entries of the matrix in place.  The structure (rects, columns) must be the one the
+// copy was made from; that is the caller's promise, only the sizes can be checked here.
+template <typename T>
+int update_values(const char *name, lsk_csr_sliced *m, int64_t rows, int64_t nnz, const int64_t *rects, int64_t k_base,
+                  const T *val, lsk_stream_t stream) {
+    if (!m) return lsk::fail(LSK_ERR_ARG, "%s: null structure", name);
+    if (m->elem_bytes != static_cast<int>(sizeof(T))) return lsk::fail(LSK_ERR_ARG, "%s: structure of another entry type", name);
+    if (rows != m->rows || nnz != m->nnz || k_base != m->k_base)
+        return lsk::fail(LSK_ERR_ARG, "%s: %lld rows, %lld entries from %lld; the structure was made for %lld, %lld from %lld",
+                         name, (long long)rows, (long long)nnz, (long long)k_base, (long long)m->rows, (long long)m->nnz,
+                         (long long)m->k_base);
+    if (!rects || !val) return lsk::fail(LSK_ERR_ARG, "%s: null pointer", name);
+    sliced_fill_kernel<T><<<static_cast<unsigned>(lsk::ceil_div(m->slices * kWave, kBlock)), kBlock, 0, lsk::as_stream(stream)>>>(
+        rows, reinterpret_cast<const long long *>(rects), k_base, val, static_cast<const SliceMeta *>(m->meta), m->row_mask,
+        static_cast<T *>(m->val));
+    LSK_LAUNCH_CHECK();
+    return LSK_OK;
+}
+
 template <typename T>
 int spmv(const char *name, const lsk_csr_sliced *m, int64_t row_begin, int64_t row_end, const T *x, T *y, int beta,
          const T *w, T *partials, int64_t capacity, int64_t *count, lsk_stream_t stream) {
@@ -471,7 +493,7 @@ int spmv(const char *name, const lsk_csr_sliced *m, int64_t row_begin, int64_t r
     sliced_spmv_kernel<T, 9, DOT><<<blocks, kBlock, 0, lsk::as_stream(stream)>>>(                                \
         slice_begin, slice_count, row_begin, row_end, static_cast<const SliceMeta *>(m->meta),                   \
         static_cast<const T *>(m->val), m->row_pattern, m->row_mask, m->table, x, m->row_first - m->x_lo, y, beta, \
-        lsk::options().xcd_remap, w, partials)
+        lsk::xcd_remap_option(), w, partials)
     if (dot) LSK_SLICED_LAUNCH(true);
     else LSK_SLICED_LAUNCH(false);
 #undef LSK_SLICED_LAUNCH
@@ -486,8 +508,8 @@ int tune(const char *name, const lsk_csr_sliced *m, const T *x, T *y, lsk_stream
     static const int candidates[] = {0, 16, 64, 256, 1024, 4096};
     constexpr int kWarm = 1, kTimed = 3;
     if (!m) return lsk::fail(LSK_ERR_ARG, "%s: null structure", name);
-    lsk::Options &opt = lsk::options();
-    const int saved = opt.xcd_remap;
+    int &placement = lsk::xcd_remap_option();
+    const int saved = placement;
     hipStream_t s = lsk::as_stream(stream);
     hipEvent_t t0 = nullptr, t1 = nullptr;
     LSK_HIP(hipEventCreate(&t0));
@@ -495,7 +517,7 @@ int tune(const char *name, const lsk_csr_sliced *m, const T *x, T *y, lsk_stream
     int best = saved, status = LSK_OK;
     float best_ms = -1.0f;
     for (int c : candidates) {
-        opt.xcd_remap = c;
+        placement = c;
         for (int i = 0; i < kWarm && status == LSK_OK; ++i)
             status = spmv<T>(name, m, 0, m->rows, x, y, 0, nullptr, nullptr, 0, nullptr, stream);
         if (status != LSK_OK) break;
@@ -517,7 +539,7 @@ int tune(const char *name, const lsk_csr_sliced *m, const T *x, T *y, lsk_stream
             best = c;
         }
     }
-    opt.xcd_remap = saved;
+    placement = saved;
     (void)hipEventDestroy(t0);
     (void)hipEventDestroy(t1);
     if (status != LSK_OK) return status;
@@ -548,6 +570,15 @@ int lsk_csr_sliced_create_f64(int64_t rows, int64_t nnz, const int64_t *rects, i
                               const double *val, int64_t row_first, int64_t x_lo, int64_t x_hi, lsk_stream_t stream,
                               lsk_csr_sliced_t **out) {
     return create<double>("lsk_csr_sliced_create_f64", rows, nnz, rects, k_base, col, val, row_first, x_lo, x_hi, stream, out);
+}
+
+int lsk_csr_sliced_update_values_f32(lsk_csr_sliced_t *m, int64_t rows, int64_t nnz, const int64_t *rects, int64_t k_base,
+                                     const float *val, lsk_stream_t stream) {
+    return update_values<float>("lsk_csr_sliced_update_values_f32", m, rows, nnz, rects, k_base, val, stream);
+}
+int lsk_csr_sliced_update_values_f64(lsk_csr_sliced_t *m, int64_t rows, int64_t nnz, const int64_t *rects, int64_t k_base,
+                                     const double *val, lsk_stream_t stream) {
+    return update_values<double>("lsk_csr_sliced_update_values_f64", m, rows, nnz, rects, k_base, val, stream);
 }
 
 int lsk_csr_sliced_spmv_f32(const lsk_csr_sliced_t *m, int64_t row_begin, int64_t row_end, const float *x, float *y,

@@ -133,6 +133,12 @@ class _SlicedCopies:
         self.sliced = {}          # slice_structure(): piece colour -> sliced-pattern copy of the piece ...
         self.sliced_window = None # ... for products against this window
         self.sliced_placement = {}
+        self._sliced_refill = {}  # piece colour -> refill(copy): the piece's current values into that copy
+
+    def _refill_sliced_copies(self) -> None:
+        """The sliced-pattern copies hold a copy of the entry values: bring them up to date."""
+        for c, s in self.sliced.items():
+            self._sliced_refill[c](s)
 
     def _make_sliced_copies(self, make, x_lo: int, x_hi: int, kernel_partition, range_partition) -> bool:
         """make(i, c): the copy of local piece i (colour c), None when the library declines."""
@@ -240,6 +246,7 @@ class CSRMatrix(AbstractMatrix, _SlicedCopies):
             raise ValueError("col and val differ in length")
         self.ctx = ctx
         self.rects, self.k_base, self.col, self.val = rects, int(k_base), col, val
+        self._val_given = val  # set-up may move the arrays (tune): values_changed() reads this one
         self.dtype = val.dtype
         self.range_space = range_space
         self.row_lo = int(row_lo)
@@ -250,6 +257,18 @@ class CSRMatrix(AbstractMatrix, _SlicedCopies):
         self.col32_window = None  # ... this window (x_lo, x_hi)
         self.rowoff = {}          # ... and per piece colour rows + 1 32-bit offsets of the rows' entries
         self._init_sliced()
+
+    def values_changed(self) -> None:
+        """To be called after the entries were rewritten in place, in the `val` tensor the matrix was
+        made from (same structure, new values), before the next product.  The reference's task reads
+        the region on every call (src/CSRMatrixTasks.cu:88-118); here set-up may have moved the arrays
+        to another place in HBM (tune) and made copies of the values (slice_structure, the transpose
+        behind rmatvec), all of which this brings up to date: one pass over the values per copy,
+        stream-ordered."""
+        if self.val is not self._val_given:
+            self.ctx.backend.copy(self.val, self._val_given)
+        self._refill_sliced_copies()
+        self._transposed = None  # rebuilt by the next rmatvec
 
     def transpose(self, x_lo: int, x_hi: int, row_lo: int, rows: int) -> TransposedBlock:
         """The transpose of this rank's rows against the window x_lo..x_hi of the domain."""
@@ -325,6 +344,8 @@ class CSRMatrix(AbstractMatrix, _SlicedCopies):
             k_lo, k_hi = kernel_partition.intervals[i]
             nnz = max(k_hi - k_lo + 1, 0)
             r0, off = p.lo[0] - self.row_lo, k_lo - self.k_base
+            self._sliced_refill[c] = lambda s, rows=p.volume: be.csr_sliced_update_values(
+                s, rows, nnz, self.rects[r0:r0 + rows], k_lo, self.val[off:off + nnz])
             return maker(p.volume, nnz, self.rects[r0:r0 + p.volume], k_lo, self.col[off:off + nnz],
                          self.val[off:off + nnz], p.lo[0], x_lo, x_hi)
         return self._make_sliced_copies(make, x_lo, x_hi, kernel_partition, range_partition)
@@ -534,11 +555,11 @@ class CSRMatrix(AbstractMatrix, _SlicedCopies):
                         continue
                     n_run = max(kb - ka + 1, 0)
                     if c in sliced and fused:
-                        be.csr_sliced_spmv_dot(sliced[c], rb, x, dst.piece(i), beta, dot_with.piece(i),
+                        be.csr_sliced_spmv_dot(sliced[c], rb, x, dst._piece(i), beta, dot_with._piece(i),
                                                buf[sum(slots[:k]):], self.sliced_placement.get(c, 0), row_begin=ra)
                         continue
                     if c in sliced:
-                        be.csr_sliced_spmv(sliced[c], ra, rb, x, dst.piece(i), beta, self.sliced_placement.get(c, 0))
+                        be.csr_sliced_spmv(sliced[c], ra, rb, x, dst._piece(i), beta, self.sliced_placement.get(c, 0))
                         continue
                     rowf, col = self._structure(x_lo, x_hi, c, r0, ra, rb)
                     if rowf.dtype == torch.int32:   # offsets count from the piece's first entry
@@ -548,25 +569,25 @@ class CSRMatrix(AbstractMatrix, _SlicedCopies):
                     # (nnz = the entries of THESE rows: the kernel sizes its tiles by nnz / rows)
                     be.csr_spmv(rb - ra, n_run, rowf, ka if n_run else self.k_base,
                                 col[off:off + n_arr], self.val[off:off + n_arr], x, x_lo, x_hi,
-                                dst.piece(i)[ra:rb], beta, self.placement.get(c, 0))
+                                dst._piece(i)[ra:rb], beta, self.placement.get(c, 0))
                 continue
             if split is not None and phase == 0:
                 continue  # a piece without a split entry (no entries) goes with the late phase
             if c in sliced and fused:
                 buf = dst._partials("mv", i, be.csr_sliced_dot_slots(rows))
-                pieces.append((buf, be.csr_sliced_spmv_dot(sliced[c], rows, x, dst.piece(i), beta, dot_with.piece(i),
+                pieces.append((buf, be.csr_sliced_spmv_dot(sliced[c], rows, x, dst._piece(i), beta, dot_with._piece(i),
                                                            buf, self.sliced_placement.get(c, 0))))
                 continue
             if c in sliced:
-                be.csr_sliced_spmv(sliced[c], 0, rows, x, dst.piece(i), beta, self.sliced_placement.get(c, 0))
+                be.csr_sliced_spmv(sliced[c], 0, rows, x, dst._piece(i), beta, self.sliced_placement.get(c, 0))
                 continue
             off = (k_lo - self.k_base) if nnz else 0
             rowf, col = self._structure(x_lo, x_hi, c, r0, 0, rows)
             args = (rows, nnz, rowf, k_lo if nnz else self.k_base,
-                    col[off:off + nnz], self.val[off:off + nnz], x, x_lo, x_hi, dst.piece(i), beta)
+                    col[off:off + nnz], self.val[off:off + nnz], x, x_lo, x_hi, dst._piece(i), beta)
             if fused:
                 buf = dst._partials("mv", i, be.csr_spmv_dot_slots(rows, nnz, self.dtype))
-                pieces.append((buf, be.csr_spmv_dot(*args, dot_with.piece(i), buf, self.placement.get(c, 0))))
+                pieces.append((buf, be.csr_spmv_dot(*args, dot_with._piece(i), buf, self.placement.get(c, 0))))
             else:
                 be.csr_spmv(*args, self.placement.get(c, 0))
         if fused and last_phase:
@@ -590,6 +611,7 @@ class COOMatrix(AbstractMatrix, _SlicedCopies):
         self.row_sorted = bool((row[1:] >= row[:-1]).all()) if self.nnz > 1 else True
         self.blocked = False            # entries of the 32-bit copies re-ordered by column blocks
         self.val_blocked = None         # ... with the values in that order
+        self._block_order = None        # ... which is val[_block_order]
         self.row32 = self.col32 = None  # compress(): 32-bit copies of the index fields ...
         self.col32_window = None        # ... for this x window (x_lo, x_hi) ...
         self.row_origin = 0             # ... and rows counted from this global row
@@ -643,11 +665,14 @@ class COOMatrix(AbstractMatrix, _SlicedCopies):
             p = range_partition.pieces[c]
             k_lo, k_hi = kernel_partition.intervals[i]
             nnz = k_hi - k_lo + 1
-            bounds = torch.arange(p.lo[0], p.hi[0] + 2, dtype=torch.int64, device=self.row.device)
-            first = torch.searchsorted(self.row[k_lo:k_lo + nnz], bounds) + k_lo   # rows + 1 entry offsets
-            rects = torch.stack((first[:-1], first[1:] - 1), dim=1).contiguous()
-            del bounds, first
-            return maker(p.volume, nnz, rects, k_lo, self.col[k_lo:k_lo + nnz], self.val[k_lo:k_lo + nnz],
+            def row_rects():
+                bounds = torch.arange(p.lo[0], p.hi[0] + 2, dtype=torch.int64, device=self.row.device)
+                first = torch.searchsorted(self.row[k_lo:k_lo + nnz], bounds) + k_lo   # rows + 1 entry offsets
+                return torch.stack((first[:-1], first[1:] - 1), dim=1).contiguous()
+
+            self._sliced_refill[c] = lambda s: be.csr_sliced_update_values(
+                s, p.volume, nnz, row_rects(), k_lo, self.val[k_lo:k_lo + nnz])
+            return maker(p.volume, nnz, row_rects(), k_lo, self.col[k_lo:k_lo + nnz], self.val[k_lo:k_lo + nnz],
                          p.lo[0], x_lo, x_hi)
 
         return self._make_sliced_copies(make, x_lo, x_hi, kernel_partition, range_partition)
@@ -680,7 +705,6 @@ class COOMatrix(AbstractMatrix, _SlicedCopies):
         if order is None:
             return
         blocked = tuple(be.gather(t, order) for t in (self.row32, self.col32, self.val))
-        del order
         c = kernel_partition.colors[0]
         p = range_partition.pieces[c]
         y_lo, y_hi = p.lo[0] - self.row_origin, p.hi[0] - self.row_origin
@@ -705,6 +729,17 @@ class COOMatrix(AbstractMatrix, _SlicedCopies):
         if t_blocked < t_rows:
             self.row32, self.col32, self.val_blocked = blocked
             self.blocked = True
+            self._block_order = order  # kept for values_changed(): 4 bytes per entry
+
+    def values_changed(self) -> None:
+        """To be called after the entries were rewritten in place in the `val` tensor (same rows and
+        columns, new values), before the next product: brings the set-up-time copies of the values up
+        to date (the column-blocked order, the sliced-pattern copies, the transpose behind rmatvec).
+        The reference's task reads the region on every call (src/COOMatrixTasks.cu:86-145)."""
+        if self.blocked:
+            self.val_blocked = self.ctx.backend.gather(self.val, self._block_order)
+        self._refill_sliced_copies()
+        self._transposed = None
 
     def create_kernel_partition_from_range_partition(self, range_partition):
         """Preimage of the row field (src/COOMatrix.cpp:77-95).  For row-sorted entries each
@@ -750,21 +785,21 @@ class COOMatrix(AbstractMatrix, _SlicedCopies):
             if p.volume == 0 or nnz == 0:
                 continue
             if c in self.sliced and self.sliced_window == (x_lo, x_hi):
-                self.ctx.backend.csr_sliced_spmv(self.sliced[c], 0, p.volume, x, dst.piece(i), beta,
+                self.ctx.backend.csr_sliced_spmv(self.sliced[c], 0, p.volume, x, dst._piece(i), beta,
                                                  self.sliced_placement.get(c, 0))
                 continue
             if self.blocked and self.col32_window == (x_lo, x_hi):
                 # (one local piece) every entry is visited; the row window selects, as always
                 self.ctx.backend.coo_spmv(self.nnz, self.row32, self.col32, self.val_blocked, x, x_lo, x_hi,
-                                          dst.piece(i), p.lo[0] - self.row_origin, p.hi[0] - self.row_origin)
+                                          dst._piece(i), p.lo[0] - self.row_origin, p.hi[0] - self.row_origin)
                 continue
             if self.col32 is not None and self.col32_window == (x_lo, x_hi):
                 self.ctx.backend.coo_spmv(nnz, self.row32[k_lo:k_lo + nnz], self.col32[k_lo:k_lo + nnz],
-                                          self.val[k_lo:k_lo + nnz], x, x_lo, x_hi, dst.piece(i),
+                                          self.val[k_lo:k_lo + nnz], x, x_lo, x_hi, dst._piece(i),
                                           p.lo[0] - self.row_origin, p.hi[0] - self.row_origin)
                 continue
             self.ctx.backend.coo_spmv(nnz, self.row[k_lo:k_lo + nnz], self.col[k_lo:k_lo + nnz],
-                                      self.val[k_lo:k_lo + nnz], x, x_lo, x_hi, dst.piece(i),
+                                      self.val[k_lo:k_lo + nnz], x, x_lo, x_hi, dst._piece(i),
                                       p.lo[0], p.hi[0])
 
 

@@ -39,7 +39,11 @@ class _DeferredAxpy:
 class PartitionedVector:
     """Views of the storage (`data`, `owned`, `piece(i)`) are to be fetched again after an operation
     on the vector rather than kept across it, as a Legion accessor is valid for one mapping only:
-    reading them is what makes an update that is being held back (axpy(defer=True)) happen."""
+    fetching one makes an update that is being held back (axpy(defer=True)) happen, and, because the
+    views are writable, counts as a write: whatever a fused leaf had left behind about the vector's
+    contents (partial sums of a dot product) is forgotten, so a write through the view can never be
+    followed by a stale dot.  The package's own leaf calls use the `_own` / `_buf` / `_piece`
+    forms, which settle but do not count as writes."""
 
     def __init__(self, ctx, name: str, index_partition: IndexPartition,
                  dtype: torch.dtype = torch.float64, pad: Tuple[int, int] = (0, 0)):
@@ -86,15 +90,37 @@ class PartitionedVector:
 
     @property
     def data(self) -> torch.Tensor:
-        """The whole buffer, halo room included."""
+        """The whole buffer, halo room included (writable: see the class note)."""
         self._settle()
+        self._touch()
         return self._data
 
     @property
     def owned(self) -> torch.Tensor:
-        """This rank's elements, pieces in colour order."""
+        """This rank's elements, pieces in colour order (writable: see the class note)."""
+        self._settle()
+        self._touch()
+        return self._owned
+
+    def mark_written(self) -> None:
+        """For a caller that kept a view and wrote through it later: the vector's contents changed."""
+        self._settle()
+        self._touch()
+
+    # the same views for the package's own leaf calls, which do their own bookkeeping
+    @property
+    def _buf(self) -> torch.Tensor:
+        self._settle()
+        return self._data
+
+    @property
+    def _own(self) -> torch.Tensor:
         self._settle()
         return self._owned
+
+    def _piece(self, i: int) -> torch.Tensor:
+        off = self.piece_offsets[i]
+        return self._own[off:off + self.piece_sizes[i]]
 
     # -- accessors (src/PartitionedVector.hpp:52-72) ------------------------------------
     def get_name(self) -> str:
@@ -113,7 +139,7 @@ class PartitionedVector:
         return self.index_partition
 
     def piece(self, i: int) -> torch.Tensor:
-        """View of the i-th local piece (colour self.colors[i])."""
+        """View of the i-th local piece (colour self.colors[i]); writable: see the class note."""
         off = self.piece_offsets[i]
         return self.owned[off:off + self.piece_sizes[i]]
 
@@ -164,7 +190,7 @@ class PartitionedVector:
         self._touch()
         for i in range(len(self.piece_sizes)):
             if self.piece_sizes[i]:
-                self.ctx.backend.fill(self.piece(i), value)
+                self.ctx.backend.fill(self._piece(i), value)
 
     def zero_fill(self) -> None:
         self.constant_fill(0.0)
@@ -179,7 +205,7 @@ class PartitionedVector:
         self._touch()
         for i, c in enumerate(self.colors):
             if self.piece_sizes[i]:
-                self.ctx.backend.random_fill(self.piece(i), seed, self.index_partition.pieces[c].lo[0])
+                self.ctx.backend.random_fill(self._piece(i), seed, self.index_partition.pieces[c].lo[0])
 
     def assign(self, x: "PartitionedVector") -> "PartitionedVector":
         """operator=(const PartitionedVector &): index copy, piece by piece."""
@@ -187,7 +213,7 @@ class PartitionedVector:
         self._touch()
         for i in range(len(self.piece_sizes)):
             if self.piece_sizes[i]:
-                self.ctx.backend.copy(self.piece(i), x.piece(i))
+                self.ctx.backend.copy(self._piece(i), x._piece(i))
         return x
 
     # -- BLAS-1 (src/PartitionedVector.cpp:195-358) ---------------------------------------
@@ -196,7 +222,7 @@ class PartitionedVector:
         self._touch()
         for i in range(len(self.piece_sizes)):
             if self.piece_sizes[i]:
-                self.ctx.backend.scal(self.piece(i), futs)
+                self.ctx.backend.scal(self._piece(i), futs)
 
     def axpy(self, *args, speculate: bool = False, defer: bool = False, on_outcome=None) -> None:
         """axpy(alpha, x) | axpy(numer, denom, x) | axpy(numer1, numer2, denom, x):
@@ -231,9 +257,9 @@ class PartitionedVector:
                 pieces.append((None, 0))
             elif fused:
                 buf = self._partials("sq", i, be.SQNORM_SLOTS)
-                pieces.append((buf, be.axpy_sqnorm(self.piece(i), futs, x.piece(i), buf)))
+                pieces.append((buf, be.axpy_sqnorm(self._piece(i), futs, x._piece(i), buf)))
             else:
-                be.axpy(self.piece(i), futs, x.piece(i))
+                be.axpy(self._piece(i), futs, x._piece(i))
         if fused:
             self._note_ready(self, pieces)
 
@@ -254,12 +280,12 @@ class PartitionedVector:
             z._touch()
             for i in range(len(self.piece_sizes)):
                 if self.piece_sizes[i]:
-                    self.ctx.backend.axpy_xpay(z.piece(i), futs_a, self.piece(i), futs, x.piece(i))
+                    self.ctx.backend.axpy_xpay(z._piece(i), futs_a, self._piece(i), futs, x._piece(i))
             return
         self._touch()
         for i in range(len(self.piece_sizes)):
             if self.piece_sizes[i]:
-                self.ctx.backend.xpay(self.piece(i), futs, x.piece(i))
+                self.ctx.backend.xpay(self._piece(i), futs, x._piece(i))
 
     def dot_local(self, x: "PartitionedVector", out: torch.Tensor) -> None:
         """out[0] <- this rank's share of the dot product: its pieces' results folded in
@@ -283,7 +309,7 @@ class PartitionedVector:
                         be.sum_partials(0, None, dst)
                         continue
                     buf = z._partials("ad", i, be.SQNORM_SLOTS)
-                    count = be.axpy_dot(z.piece(i), futs, d.p.piece(i), None if other is z else other.piece(i), buf)
+                    count = be.axpy_dot(z._piece(i), futs, d.p._piece(i), None if other is z else other._piece(i), buf)
                     be.sum_partials(count, buf, dst)
                 if n > 1:
                     be.sum_scalars(slots, out)
@@ -294,7 +320,7 @@ class PartitionedVector:
             if ready is not None:
                 be.sum_partials(ready[i][1], ready[i][0], dst)
             else:
-                be.dot(self.piece(i), x.piece(i), dst)
+                be.dot(self._piece(i), x._piece(i), dst)
 
         if n == 1:
             piece_dot(0, out)
@@ -315,4 +341,4 @@ class PartitionedVector:
     # -- test / debug helpers ---------------------------------------------------------------
     def to_host(self) -> torch.Tensor:
         """This rank's owned elements, in colour order, on the host."""
-        return self.owned.detach().cpu()
+        return self._own.detach().cpu()

@@ -243,17 +243,17 @@ class SquarePlanner:
         plan = e.plan
         own_lo, own_hi = src.own_lo, src.own_hi
         if not plan.recvs and not plan.sends:
-            return src.owned, own_lo, own_hi, None
+            return src._own, own_lo, own_hi, None
         if src.pad_lo >= plan.pad_lo and src.pad_hi >= plan.pad_hi:
-            buf, base = src.data, own_lo - src.pad_lo      # gather in place
+            buf, base = src._buf, own_lo - src.pad_lo      # gather in place
         else:
             need = plan.pad_lo + src.local_size + plan.pad_hi
             if e.staging is None or e.staging.numel() != need:
                 e.staging = self.ctx.backend.empty(need, self.dtype)
             buf, base = e.staging, own_lo - plan.pad_lo
             if src.local_size:
-                self.ctx.backend.copy(buf[plan.pad_lo:plan.pad_lo + src.local_size], src.owned)
-        sends = [(t.peer, src.owned[t.start - own_lo:t.start - own_lo + t.count]) for t in plan.sends]
+                self.ctx.backend.copy(buf[plan.pad_lo:plan.pad_lo + src.local_size], src._own)
+        sends = [(t.peer, src._own[t.start - own_lo:t.start - own_lo + t.count]) for t in plan.sends]
         recvs = [(t.peer, buf[t.start - base:t.start - base + t.count]) for t in plan.recvs]
         handle = self.ctx.comm.exchange_start(sends, recvs)
         x_lo = own_lo - plan.pad_lo
@@ -342,26 +342,26 @@ class SquarePlanner:
             plan = e.plan
             own_lo, own_hi = dst.own_lo, dst.own_hi
             if not plan.recvs and not plan.sends:
-                e.matrix.rmatvec(dst.owned, own_lo, own_hi, src.owned, src.own_lo, 0 if first else 1)
+                e.matrix.rmatvec(dst._own, own_lo, own_hi, src._own, src.own_lo, 0 if first else 1)
                 continue
             w_lo, w_hi = own_lo - plan.pad_lo, own_hi + plan.pad_hi
             if e.rstaging is None:
                 e.rstaging = (be.empty(w_hi - w_lo + 1, self.dtype),
                               [(t, be.empty(t.count, self.dtype)) for t in sorted(plan.sends, key=lambda t: t.peer)])
             window, landing = e.rstaging
-            e.matrix.rmatvec(window, w_lo, w_hi, src.owned, src.own_lo, 0)
+            e.matrix.rmatvec(window, w_lo, w_hi, src._own, src.own_lo, 0)
             handle = comm.exchange_start(
                 [(t.peer, window[t.start - w_lo:t.start - w_lo + t.count]) for t in plan.recvs],
                 [(t.peer, buf) for t, buf in landing])
             if dst.local_size:
                 mine = window[own_lo - w_lo:own_lo - w_lo + dst.local_size]
                 if first:
-                    be.copy(dst.owned, mine)
+                    be.copy(dst._own, mine)
                 else:
-                    be.axpy(dst.owned, [], mine)   # no futures: alpha = 1
+                    be.axpy(dst._own, [], mine)   # no futures: alpha = 1
             comm.exchange_finish(handle)
             for t, buf in landing:
-                be.axpy(dst.owned[t.start - own_lo:t.start - own_lo + t.count], [], buf)
+                be.axpy(dst._own[t.start - own_lo:t.start - own_lo + t.count], [], buf)
         for i in range(self.get_num_spaces()):
             if i not in touched:
                 self.get_vector(dst_idx, i).zero_fill()

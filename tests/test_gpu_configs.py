@@ -138,14 +138,14 @@ def test_bicgstab_random_coo_scaled(gpu_ctx):
     assert np.linalg.norm(rhs - y) <= 1e-10 * np.linalg.norm(rhs)
 
 
-def test_coo_against_csr_at_full_random_size(gpu_ctx):
+@pytest.mark.parametrize("rows", [15_625_000], ids=["15625000rows"])
+def test_coo_against_csr_at_full_random_size(gpu_ctx, rows):
     """The random COO configuration at full size (15 625 000 rows x 32 = 5.0e8 entries, 12 GB):
     every row has exactly 32 consecutive entries, so the same arrays are also a CSR matrix with
     rects {32 r, 32 r + 31}; the COO kernel (atomics) and the CSR kernel must agree."""
-    rows, per_row = 15_625_000, 32
-    free, _ = torch.cuda.mem_get_info()
-    if free < 40 * (1 << 30):
-        rows //= 8
+    from conftest import require_device_memory
+    per_row = 32
+    require_device_memory(40, f"random COO against CSR at {rows} rows x {per_row} entries")
     nnz = rows * per_row
     print(f"case coo vs csr random rows={rows} nnz={nnz}", flush=True)
     g = torch.Generator(device="cuda").manual_seed(20250310)
@@ -206,14 +206,13 @@ def test_gmres30_7pt_fp32_scaled(gpu_ctx):
     assert np.abs(got - want).max() <= 1e-3 * np.abs(want).max()
 
 
-def test_spmv_properties_7pt_fp32_768(gpu_ctx, monkeypatch):
+@pytest.mark.parametrize("n1", [768], ids=["768cubed"])
+def test_spmv_properties_7pt_fp32_768(gpu_ctx, monkeypatch, n1):
     """The GMRES configuration's matrix at full size (7-point, 768^3, fp32 entries, int64
     indices: 453M rows, 3.17G entries, 45 GB): entry count, zero interior row sums,
     symmetry and linearity of the fp32 SpMV."""
-    n1 = 768
-    free, _ = torch.cuda.mem_get_info()
-    if free < 80 * (1 << 30):
-        n1 = 256
+    from conftest import require_device_memory
+    require_device_memory(120, f"7-point fp32 CSR SpMV properties at {n1}^3 (3 167 354 880 entries)")
     n = n1 ** 3
     print(f"case spmv properties 7pt fp32 {n1}^3", flush=True)
     _, offs, cfs = sg.benchmark_stencil(3)

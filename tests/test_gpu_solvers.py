@@ -101,16 +101,15 @@ def test_solvers_match_oracle(gpu_ctx, dtype, solver_name, kind):
     assert np.abs(got - want).max() <= rtol * 10 * scale
 
 
-def test_spmv_properties_at_headline_size(gpu_ctx, monkeypatch):
+@pytest.mark.parametrize("n1", [512], ids=["512cubed"])
+def test_spmv_properties_at_headline_size(gpu_ctx, monkeypatch, n1):
     """BenchmarkStencil's headline matrix (3-D 27-point, 512^3, fp64: 134M rows, 3.6G entries,
     58 GB of col+val) is far beyond what the CPU oracle can check; these properties are
     size-independent: interior row sums are 0 (88 - 6*6 - 12*3 - 8*2 = 0), boundary row sums
     are positive, A is symmetric (x.Ay == y.Ax), A is linear, and the entry count is
     (3*512-2)^3."""
-    n1 = 512
-    free, _ = torch.cuda.mem_get_info()
-    if free < 80 * (1 << 30):
-        n1 = 256  # smaller cards: same properties on 256^3
+    from conftest import require_device_memory
+    require_device_memory(150, f"27-point fp64 CSR SpMV properties at {n1}^3 (3 609 741 304 entries)")
     n = n1 ** 3
     print(f"case spmv properties {n1}^3", flush=True)
     dim, offs, cfs = sg.benchmark_stencil(4)
@@ -446,3 +445,84 @@ def test_row_sorted_coo_stencil_gets_the_sliced_copy(gpu_ctx, monkeypatch, piece
         so.step()
     for h in histories:
         np.testing.assert_allclose(h, [float(v) for v in so.residual_norm_squared], rtol=1e-10)
+
+
+@pytest.mark.parametrize("kind,sliced", [("csr", "1"), ("csr", "0"), ("coo", "1"), ("coo", "blocked")])
+def test_values_changed_brings_every_copy_up_to_date(gpu_ctx, monkeypatch, kind, sliced):
+    """Set-up may move the arrays (placement redraws) and keeps copies of the values (sliced-pattern
+    copy, column-blocked COO order, the transpose); the reference's tasks read the region on every call
+    (src/CSRMatrixTasks.cu:88-118).  After the caller rewrites `val` in place and says so, every product
+    equals the oracle's on the new values."""
+    from legionsolvers_amd import COOMatrix, CSRMatrix
+    monkeypatch.setattr(CSRMatrix, "TUNE_MIN_ROWS", 1)   # force the tuner and the redraws on a small problem
+    monkeypatch.setattr(COOMatrix, "TUNE_MIN_ROWS", 1)
+    monkeypatch.setenv("LSK_TUNE_REDRAWS", "2")
+    rng = np.random.default_rng(60)
+    if sliced == "blocked":
+        monkeypatch.setenv("LSK_COO_BLOCK", "1")
+        monkeypatch.setattr(COOMatrix, "BLOCK_MIN_WINDOW", 0)
+        monkeypatch.setattr(COOMatrix, "BLOCK_BYTES", 1 << 12)
+        n, per = 6000, 12
+        rects = None
+        row = np.repeat(np.arange(n), per).astype(np.int64)
+        col = rng.integers(0, n, size=n * per).astype(np.int64)
+        pieces = 1
+    else:
+        monkeypatch.setenv("LSK_SLICED", sliced)
+        rects, row, col, _, n = hc.stencil_problem(4, (11, 9, 21), np.float64)
+        pieces = 2
+    old = rng.standard_normal(col.size)
+    new = rng.standard_normal(col.size)
+    x = rng.standard_normal(n)
+    print(f"case values_changed {kind} sliced={sliced}", flush=True)
+    mpl = hc.mirror_planner(gpu_ctx, kind, rects, row, col, old, n, pieces, np.float64, x)
+    matrix = mpl.row_partitioned_matrices[0].matrix
+    if sliced == "blocked":
+        assert matrix.blocked
+    else:
+        assert bool(matrix.sliced) == (sliced == "1")
+    given = matrix._val_given if kind == "csr" else matrix.val
+    mpl.allocate_workspace(2)
+
+    def products():
+        mpl.matvec(2, 1)
+        mpl.rmatvec(3, 1)
+        return mpl.get_vector(2, 0).to_host().numpy(), mpl.get_vector(3, 0).to_host().numpy()
+
+    def expected(values):
+        y, yt = np.zeros(n), np.zeros(n)
+        oracle.coo_matvec(row, col, values, x, 0, n - 1, y, 0, n - 1)
+        oracle.coo_matvec(col, row, values, x, 0, n - 1, yt, 0, n - 1)   # the transpose, entry by entry
+        return y, yt
+
+    for got, want in zip(products(), expected(old)):
+        np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-12)
+    given.copy_(hc.to_dev(gpu_ctx, new))   # the caller rewrites its entries in place ...
+    matrix.values_changed()                # ... and says so
+    for got, want in zip(products(), expected(new)):
+        np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-12)
+
+
+def test_write_through_a_view_is_seen_by_the_next_dot(gpu_ctx):
+    """A fused leaf leaves partial sums of a dot product with the vector; a write through one of the
+    vector's views afterwards must not be answered with those stale sums."""
+    n = 70000
+    ip = IndexPartition.equal(IndexSpace(0, n - 1), 3)
+    g = torch.Generator(device="cuda").manual_seed(9)
+    x = PartitionedVector(gpu_ctx, "x", ip)
+    y = PartitionedVector(gpu_ctx, "y", ip)
+    x.owned.copy_(torch.randn(n, generator=g, device="cuda", dtype=torch.float64))
+    y.owned.copy_(torch.randn(n, generator=g, device="cuda", dtype=torch.float64))
+    y.axpy(0.5, x, speculate=True)          # leaves the shares of y.y
+    assert y._ready is not None
+    first = y.dot(y).get_value()
+    y.owned.mul_(2.0)                        # an external write through the view
+    assert y._ready is None
+    assert y.dot(y).get_value() == pytest.approx(4.0 * first, rel=1e-13)
+    kept = y.piece(1)
+    y.axpy(0.25, x, speculate=True)
+    kept.zero_()                             # a view kept across an operation: the caller says so
+    y.mark_written()
+    fresh = PartitionedVector(gpu_ctx, "f", ip)
+    fresh.assign(y)
+    assert y.dot(y).get_value() == fresh.dot(fresh).get_value()

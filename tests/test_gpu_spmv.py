@@ -799,3 +799,57 @@ def test_csr_sliced_mixed_and_gapped_rows():
     info = sliced_case("f64", rects, 0, col, rng.standard_normal(val.size), rng.standard_normal(n), 0, n - 1, 0,
                        "gapped rects")
     assert info[2] + info[4] == info[1]  # every slice mixes patterns
+
+
+@pytest.mark.parametrize("suf", ["f64", "f32"])
+def test_csr_sliced_update_values_bit_exact(suf):
+    """create -> overwrite val in place -> product still gives the OLD values' result (the structure
+    holds a copy) -> lsk_csr_sliced_update_values_* -> product equals the oracle on the NEW values,
+    bit for bit; masked slices (grid-line ends) and a piece with k_base > 0 included."""
+    npdt, tdt, _ = DT[suf]
+    rng = np.random.default_rng(29)
+    lib = _lib.lib()
+    for flag, extent, piece in ((4, (7, 12, 70), False), (3, (9, 11, 13), True), (2, (37, 41), True)):
+        offs, cfs = oracle.benchmark_stencil_offsets(flag)
+        rects, _, col, val = oracle.linearized_stencil(extent, offs, cfs, dtype=npdt, coo=True)
+        n = int(np.prod(extent))
+        a, b = (n // 3, n - n // 4) if piece else (0, n)
+        k_lo, k_hi = int(rects[a, 0]), int(rects[b - 1, 1])
+        pr, pc = rects[a:b], col[k_lo:k_hi + 1]
+        x_lo, x_hi = int(pc.min()), int(pc.max())
+        rows, nnz = b - a, pc.size
+        print(f"case csr_sliced_update_{suf} stencil{flag}{extent} rows={rows} nnz={nnz} k_base={k_lo}", flush=True)
+        old = rng.standard_normal(nnz).astype(npdt)
+        new = rng.standard_normal(nnz).astype(npdt)
+        x = rng.standard_normal(x_hi - x_lo + 1).astype(npdt)
+        rd, cd, vd, xd = dev(pr), dev(pc), dev(old), dev(x)
+        handle = ctypes.c_void_p(0)
+        _lib.call(f"lsk_csr_sliced_create_{suf}", rows, nnz, P(rd), k_lo, P(cd), P(vd), a, x_lo, x_hi, stream(),
+                  ctypes.byref(handle))
+        try:
+            def product():
+                yd = torch.full((rows,), 3.0, dtype=tdt, device="cuda")
+                _lib.call(f"lsk_csr_sliced_spmv_{suf}", handle, 0, rows, P(xd), P(yd), 0, stream())
+                return yd.cpu().numpy()
+
+            def expected(values):
+                want = np.zeros(rows, dtype=npdt)
+                oracle.csr_matvec(pr, k_lo, pc, values, x, x_lo, x_hi, want, beta=0)
+                return want
+
+            assert np.array_equal(product().view(np.uint8), expected(old).view(np.uint8))
+            vd.copy_(torch.from_numpy(new))  # the caller rewrites its entries in place
+            assert np.array_equal(product().view(np.uint8), expected(old).view(np.uint8)), "the copy followed val by itself?"
+            _lib.call(f"lsk_csr_sliced_update_values_{suf}", handle, rows, nnz, P(rd), k_lo, P(vd), stream())
+            assert np.array_equal(product().view(np.uint8), expected(new).view(np.uint8))
+            # a call that does not describe the piece the structure was made from is refused
+            fn = getattr(lib, f"lsk_csr_sliced_update_values_{suf}")
+            assert fn(handle, rows - 1, nnz, P(rd), k_lo, P(vd), stream()) == _lib.LSK_ERR_ARG
+            assert fn(handle, rows, nnz, P(rd), k_lo + 1, P(vd), stream()) == _lib.LSK_ERR_ARG
+            assert fn(handle, rows, nnz, P(rd), k_lo, None, stream()) == _lib.LSK_ERR_ARG
+            other = "f32" if suf == "f64" else "f64"
+            assert getattr(lib, f"lsk_csr_sliced_update_values_{other}")(handle, rows, nnz, P(rd), k_lo, P(vd),
+                                                                          stream()) == _lib.LSK_ERR_ARG
+            assert np.array_equal(product().view(np.uint8), expected(new).view(np.uint8))
+        finally:
+            _lib.call("lsk_csr_sliced_destroy", handle)

@@ -1,0 +1,89 @@
+"""The N-rank Krylov path on real kernels with device-resident halos, on one GPU: the ranks are
+threads of this process (tests/thread_ranks.py).  Every rank holds one row block of the headline
+operator (27-point stencil), its products are split into the rows that need no ghost cell (phase 0,
+launched while the halo is in flight) and the two edge runs (phase 1), on the sliced-pattern copy
+both phases leave their shares of p.Ap, and every dot product crosses the ranks in one all-reduce.
+Compared with the CPU oracle on the whole problem: fp64 CG residual histories within 1e-10."""
+import numpy as np
+import pytest
+import torch
+
+import host_cases as hc
+import oracle
+from oracle import solvers as S
+from thread_ranks import run_ranks
+
+from legionsolvers_amd import BiCGStabSolver, CGSolver, GMRESSolver
+from legionsolvers_amd import benchmark_stencil as bs
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_history(n1, steps, solver_flag, pieces, dtype=np.float64):
+    oracle.set_threads(8)
+    rects, row, col, val, n = hc.stencil_problem(4, (n1, n1, n1), dtype)
+    opl = hc.oracle_planner("csr", rects, row, col, val, n, pieces, dtype)
+    solver = {1: S.CGSolver, 2: S.BiCGStabSolver}[solver_flag](opl) if solver_flag != 3 else S.GMRESSolver(opl, 10)
+    for _ in range(steps):
+        solver.step()
+    return solver, opl.get_vector(0, 0)
+
+
+@pytest.mark.parametrize("world,pieces,n1,sliced", [(8, 8, 128, "1"), (8, 8, 128, "0"), (4, 8, 96, "1"), (3, 6, 40, "1")],
+                         ids=["8ranks-128cubed-sliced", "8ranks-128cubed-c32", "4ranks-8pieces-96cubed", "3ranks-6pieces-40cubed"])
+def test_cg_thread_ranks_halo_split(monkeypatch, world, pieces, n1, sliced):
+    monkeypatch.setenv("LSK_SLICED", sliced)
+    monkeypatch.setenv("LSK_TUNE", "0")
+    steps = 6
+    print(f"case thread ranks CG world={world} pieces={pieces} {n1}^3 sliced={sliced}", flush=True)
+
+    def body(ctx):
+        matrix, planner, solver = bs.build_problem(ctx, 4, n1, n1, n1, pieces, 1, torch.float64, num_systems=1)
+        entry = planner.row_partitioned_matrices[0]
+        for _ in range(steps):
+            solver.step()
+        sol = planner.get_vector(0, 0).to_host().numpy().copy()
+        split_phases = sorted({run[0] for runs in (entry.split or {}).values() for run in runs})
+        return {
+            "history": [s.get_value() for s in solver.residual_norm_squared],
+            "sol": sol, "own": (planner.get_vector(0, 0).own_lo, planner.get_vector(0, 0).own_hi),
+            "recvs": len(entry.plan.recvs), "sends": len(entry.plan.sends), "phases": split_phases,
+            "sliced": bool(matrix.sliced), "fused_used": planner._fused_dot_used,
+            "all_reduces": ctx.comm.all_reduces, "exchanges": ctx.comm.exchanges,
+        }
+
+    out = run_ranks(world, body)
+    osolver, osol = _oracle_history(n1, steps, 1, pieces)
+    want = [float(v) for v in osolver.residual_norm_squared]
+    for r, res in enumerate(out):
+        np.testing.assert_allclose(res["history"], want, rtol=1e-10, err_msg=f"rank {r}")
+        assert res["history"] == out[0]["history"]          # every rank holds the same reduced scalars
+        lo, hi = res["own"]
+        assert np.abs(res["sol"] - osol[lo:hi + 1]).max() <= 1e-10 * np.abs(osol).max()
+        # interior ranks exchange with both neighbours, and their products ran in two phases
+        assert res["recvs"] == res["sends"] == (2 if 0 < r < world - 1 else 1)
+        assert res["phases"] == [0, 1], f"rank {r}: halo/interior split not in force: {res['phases']}"
+        assert res["sliced"] == (sliced == "1")
+        if sliced == "1":
+            assert res["fused_used"] >= steps - 1   # both phases left the shares of p.Ap
+        assert res["exchanges"] >= steps and res["all_reduces"] >= 2 * steps
+
+
+@pytest.mark.parametrize("solver_flag", [2, 3], ids=["bicgstab", "gmres10"])
+def test_other_solvers_thread_ranks(monkeypatch, solver_flag):
+    monkeypatch.setenv("LSK_TUNE", "0")
+    world, pieces, n1 = 4, 4, 48
+    steps = 5 if solver_flag == 2 else 12
+    print(f"case thread ranks solver={solver_flag} world={world} {n1}^3", flush=True)
+
+    def body(ctx):
+        _, planner, solver = bs.build_problem(ctx, 4, n1, n1, n1, pieces, solver_flag, torch.float64, num_systems=1)
+        for _ in range(steps):
+            solver.step()
+        v = planner.get_vector(0, 0)
+        return v.to_host().numpy().copy(), (v.own_lo, v.own_hi)
+
+    out = run_ranks(world, body)
+    _, osol = _oracle_history(n1, steps, solver_flag, pieces)
+    for sol, (lo, hi) in out:
+        assert np.abs(sol - osol[lo:hi + 1]).max() <= 1e-9 * np.abs(osol).max()
