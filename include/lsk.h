@@ -160,6 +160,18 @@ int lsk_dot_host_f32(int64_t n, const float *v, const float *w, float *result_ho
 int lsk_dot_host_f64(int64_t n, const double *v, const double *w, double *result_host,
                      lsk_stream_t stream);
 
+/* lsk_dot_f64 for callers that cannot allocate (code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc): no counterpart in the reference.  Same kernels, same order of
+ * additions and so the same bits as lsk_dot_f64; the partial sums live in a static device array
+ * inside the library (32 KiB per GPU, held until the process ends), whose address on the current
+ * device is looked up once (lsk_init does it; otherwise the first call on that device).  Calls no
+ * hipMalloc / hipFree and no allocating routine.  n above LSK_DOT_NOALLOC_MAX_N is refused with
+ * LSK_ERR_ARG.  Every call on a GPU uses that GPU's one array: calls that overlap on one GPU
+ * (different streams or host threads) race; calls on one stream do not. */
+#define LSK_DOT_NOALLOC_MAX_N (INT64_C(1) << 34)
+int lsk_dot_noalloc_f64(int64_t n, const double *v, const double *w, double *result_dev,
+                        lsk_stream_t stream);
+
 /* *result_dev <- sqrt(sum_i v[i]^2) in one pass over v.  The reference has no nrm2 task:
  * its solvers compute dot(v,v) followed by SqrtScalarTask (src/GMRESSolver.hpp:101-103,
  * src/UtilityTasks.cpp:78-84); this fuses the two. */

@@ -69,6 +69,7 @@ PROTOTYPES = {
     "lsk_memcpy_d2h": (_i, [_p, _p, _sz, _p]),
     "lsk_memcpy_d2d": (_i, [_p, _p, _sz, _p]),
     "lsk_dot_workspace_bytes": (_sz, [_i64]),
+    "lsk_dot_noalloc_f64": (_i, [_i64, _p, _p, _p, _p]),
     "lsk_csr_spmv_dot_partials": (_i64, [_i64, _i64, _i]),
     "lsk_rects_to_indptr_i64": (_i, [_i64, _p, _p, _p]),
     "lsk_index_bounds_i64": (_i, [_i64, _p, _p, _p]),

@@ -6,7 +6,15 @@
 // Arithmetic follows the reference's CPU leaf tasks (src/LinearAlgebraTasks.cpp:37-43,
 // 80-87, 124-131): scal is one multiply, axpy is fma(alpha, x, y), xpay is fma(alpha, y, x),
 // so element results are bit-identical to the CPU path.
+#include <mutex>
+
 #include "lsk_common.hpp"
+
+// Partial sums of lsk_dot_noalloc_f64: part of the library's image on every GPU it runs on (32 KiB
+// each, held until the process ends), so that entry point never asks the driver for memory.  In
+// host code this name is only a handle for hipGetSymbolAddress; kernels are given the address that
+// call returns for the current device (noalloc_scratch below), never the name.
+static __device__ __align__(256) unsigned char scratch[lsk::kScratchBytes];
 
 namespace {
 
@@ -548,6 +556,30 @@ int dot_host(const char *name, int64_t n, const T *v, const T *w, T *result_host
     return LSK_OK;
 }
 
+// ------------------------------------------------------------------ allocation-free dot --
+//
+// Address of `scratch` on the current device: every GPU holds its own copy of the array at its own
+// address, looked up once per device (here or from lsk_init) and kept.
+constexpr int kNoAllocMaxDevices = 64;
+void *g_noalloc_scratch[kNoAllocMaxDevices] = {};
+std::mutex g_noalloc_mutex;
+
+int noalloc_scratch(void **out) {
+    int dev = -1;
+    LSK_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= kNoAllocMaxDevices)
+        return lsk::fail(LSK_ERR_UNSUPPORTED, "device ordinal %d outside 0..%d", dev, kNoAllocMaxDevices - 1);
+    std::lock_guard<std::mutex> lock(g_noalloc_mutex);
+    if (!g_noalloc_scratch[dev]) {
+        void *ptr = nullptr;
+        LSK_HIP(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
+        if (!ptr) return lsk::fail(LSK_ERR_HIP, "hipGetSymbolAddress gave a null address for the dot scratch");
+        g_noalloc_scratch[dev] = ptr;
+    }
+    *out = g_noalloc_scratch[dev];
+    return LSK_OK;
+}
+
 // ------------------------------------------------------------------ scalar ops -------
 
 template <typename T>
@@ -653,7 +685,26 @@ int launch_xpay_nd(int dim, const int64_t *extent, T alpha, const T *x, const in
 
 } // namespace
 
+namespace lsk {
+int noalloc_scratch_init() {
+    void *ptr = nullptr;
+    return noalloc_scratch(&ptr);
+}
+} // namespace lsk
+
 extern "C" {
+
+int lsk_dot_noalloc_f64(int64_t n, const double *v, const double *w, double *result_dev, lsk_stream_t stream) {
+    if (n > LSK_DOT_NOALLOC_MAX_N)
+        return lsk::fail(LSK_ERR_ARG, "lsk_dot_noalloc_f64: %lld elements, at most %lld are taken", (long long)n,
+                         (long long)LSK_DOT_NOALLOC_MAX_N);
+    void *partials = nullptr;
+    const int rc = noalloc_scratch(&partials);
+    if (rc != LSK_OK) return rc;
+    // Every slot the fold reads has been written by this call's first stage, so nothing is cleared.
+    return launch_dot<double>("lsk_dot_noalloc_f64", n, v, w, result_dev, partials, lsk::kScratchBytes, FIN_NONE,
+                              stream);
+}
 
 size_t lsk_dot_workspace_bytes(int64_t n) {
     (void)n;

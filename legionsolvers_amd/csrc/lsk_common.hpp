@@ -51,6 +51,10 @@ constexpr size_t kScratchBytes = size_t(kMaxGridBlocks) * 16; // one 16-byte slo
 // State of the current device, created on first use (lsk_init does it eagerly).
 int device_state(DeviceState **out);
 
+// Looks up, for the current device, the address of the static device array behind
+// lsk_dot_noalloc_f64 (defined next to the array in blas1.hip; lsk_init calls it).
+int noalloc_scratch_init();
+
 // Library options (lsk_set_option); initial values may come from the environment variables
 // LSK_CSR_VARIANT / LSK_CSR_NT / LSK_XCD_REMAP.
 struct Options {

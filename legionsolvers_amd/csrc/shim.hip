@@ -163,7 +163,9 @@ int lsk_init(int device) {
         return lsk::fail(LSK_ERR_ARG, "lsk_init: device %d outside 0..%d", device, n - 1);
     LSK_HIP(hipSetDevice(device));
     lsk::DeviceState *st = nullptr;
-    return lsk::device_state(&st);
+    rc = lsk::device_state(&st);
+    if (rc != LSK_OK) return rc;
+    return lsk::noalloc_scratch_init();
 }
 
 int lsk_malloc(void **ptr, size_t bytes) {
