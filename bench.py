@@ -13,13 +13,14 @@ on the device and resident in HBM before the timed region.  Rank 0 prints ONE JS
 Besides the contract's fields the line carries:
   roofline      the CSR SpMV kernel of the timed steps against the HBM roof: algorithmic bytes of
                 one launch in the layout it reads (the sliced-pattern copy: padded entries * 8 +
-                rows * 16 + 16 per slice + 4 per row of a masked slice; else nnz*12 + rows*20 on the
+                rows * 16 + 16 per block + 4 per row of a masked wave; else nnz*12 + rows*20 on the
                 set-up-time 32-bit structure, nnz*16 + rows*32 on the arrays as handed over) / its
                 mean duration from HIP events
   roofline_32bit_structure, roofline_int64_columns   the same for the kernels that read the
                 32-bit copy of the structure and the reference's 64-bit column field
-  cpu_baseline  the CPU oracle's CG step (OpenMP over row blocks) on a bounded 27-point sample,
+  cpu_baseline  the CPU oracle's CG step (OpenMP over row blocks) on the same matrix, copied to the host,
                 rank 0 at N = 1 only
+  value_untuned, value_reference_layout, setup_s, host_ms_per_step   see "notes" in the line
 """
 from __future__ import annotations
 
@@ -87,44 +88,70 @@ def spmv_kernel_time_inner(ctx, matrix, entry, dst, x, x_lo, x_hi, reps: int, do
     return start.elapsed_time(stop) * 1e-3 / reps
 
 
-def cpu_baseline(full_rows: int):
-    """CG iterations/s of the CPU oracle, measured on a 256^3 sample of the same 27-point
-    operator and scaled by rows to the full problem."""
+def cpu_baseline(matrix, n1: int):
+    """CG iterations/s of the CPU oracle on this box's host cores, on the SAME matrix: the device
+    arrays (bit-identical to what the oracle's own generator builds) are copied to the host, then a few
+    CG steps run with one OpenMP thread per row block, and one step on a single thread.  When the host
+    lacks the memory for the whole matrix, a 256^3 sample of the same operator is timed instead and
+    scaled by rows (named in `sample`)."""
     import numpy as np
     import oracle
-    n1 = int(os.environ.get("LSK_CPU_SAMPLE", "256"))
-    cores = min(len(os.sched_getaffinity(0)), int(os.environ.get("OMP_NUM_THREADS", "16")), 16)
-    cores = oracle.set_threads(cores)
-    offs, cfs = oracle.benchmark_stencil_offsets(4)
-    rects, _, col, val = oracle.linearized_stencil((n1, n1, n1), offs, cfs)
-    rows = n1 ** 3
-    sol = np.zeros(rows)
-    r = np.ones(rows)
-    p = np.ones(rows)
-    q = np.zeros(rows)
+    affinity = len(os.sched_getaffinity(0))
+    env_threads = os.environ.get("OMP_NUM_THREADS")
+    # the box's CPU share is what OMP_NUM_THREADS says when it is set (the affinity mask of a GPU box
+    # lists every CPU of the machine, of which one job gets a share)
+    cores = oracle.set_threads(min(affinity, int(env_threads)) if env_threads else affinity)
+    rows = matrix.rows
+    need = matrix.rects.numel() * 8 + matrix.col.numel() * 8 + matrix.val.numel() * 8 + 5 * rows * 8
+    try:
+        import psutil
+        available = psutil.virtual_memory().available
+    except Exception:  # noqa: BLE001
+        available = 0
+    sample_n = int(os.environ.get("LSK_CPU_SAMPLE", "0"))
+    t_copy = time.perf_counter()
+    if not sample_n and available > 1.3 * need:
+        rects, col, val = (t.cpu().numpy() for t in (matrix.rects, matrix.col, matrix._val_given))
+        scale, where = 1.0, f"the benchmark's own matrix ({n1}^3: {rows} rows, {val.size} entries, copied from the device)"
+    else:
+        sample_n = sample_n or 256
+        offs, cfs = oracle.benchmark_stencil_offsets(4)
+        rects, _, col, val = oracle.linearized_stencil((sample_n,) * 3, offs, cfs)
+        scale = sample_n ** 3 / rows
+        rows = sample_n ** 3
+        where = (f"a {sample_n}^3 sample of the same operator ({rows} rows, {val.size} entries; the host has "
+                 f"{available / 2**30:.0f} GiB free, the whole matrix needs {need / 2**30:.0f}), scaled by rows to {n1}^3")
+    t_copy = time.perf_counter() - t_copy
+    sol, r, p, q = np.zeros(rows), np.ones(rows), np.ones(rows), np.zeros(rows)
     rr = float(rows)
-    rr = oracle.cg_step_mt(rects, col, val, sol, p, q, r, rr, cores)  # warm-up
+    rr = oracle.cg_step_mt(rects, col, val, sol, p, q, r, rr, cores)  # warm-up (first touch of the vectors)
     steps = 3
     t0 = time.perf_counter()
     for _ in range(steps):
         rr = oracle.cg_step_mt(rects, col, val, sol, p, q, r, rr, cores)
     dt = (time.perf_counter() - t0) / steps
-    # the same step on one thread, one row block (the scalar port)
     oracle.set_threads(1)
     t0 = time.perf_counter()
     rr = oracle.cg_step_mt(rects, col, val, sol, p, q, r, rr, 1)
     dt1 = time.perf_counter() - t0
     oracle.set_threads(cores)
     return {
-        "value": (1.0 / dt) * rows / full_rows,
+        "value": scale / dt,
         "unit": "iters/s",
         "cores": cores,
         "kind": "port",
-        "sample": f"{steps} CG steps of the CPU oracle (OpenMP, {cores} row blocks) on the 27-pt "
-                  f"stencil at {n1}^3 ({rows} rows, {val.size} entries); {dt * 1e3:.1f} ms/step there, "
-                  f"scaled by rows to 512^3",
-        "value_one_thread": (1.0 / dt1) * rows / full_rows,
+        "sample": f"{steps} CG steps of the CPU oracle (OpenMP, {cores} threads = one row block each; the affinity mask "
+                  f"lists {affinity} CPUs, OMP_NUM_THREADS={env_threads}) on {where}; {dt * 1e3:.0f} ms per step there, "
+                  f"{dt1 * 1e3:.0f} ms on one thread; {t_copy:.0f} s to bring the matrix to the host",
+        "value_one_thread": scale / dt1,
     }
+
+
+def host_ms_per_step(ctx, world: int) -> float:
+    """What the host spends enqueueing one CG step: the same solver on a 32^3 grid, where the GPU
+    finishes a step's kernels faster than the host issues them, so wall time per step is host time."""
+    _, _, solver = bs.build_problem(ctx, 4, 32, 32, 32, world, 1, torch.float64, num_systems=1)
+    return bs.timed_steps(ctx, solver, 20, 500) / 500 * 1e3
 
 
 def main():
@@ -142,21 +169,59 @@ def main():
     ctx = Context(torch.device("cuda", local_rank))
     n1 = args.n
     rows = n1 ** 3
+    setup_s = {}
 
-    # single-system CG: the metric
-    matrix, planner, solver = bs.build_problem(ctx, 4, n1, n1, n1, world, 1, torch.float64, num_systems=1)
+    def stage(name, t0):
+        ctx.synchronize()
+        setup_s[name] = setup_s.get(name, 0.0) + time.perf_counter() - t0
+
+    # single-system CG: the metric.  Set-up first WITHOUT the speed tuning (placement tuner, redraws
+    # of the copies, steadiness wait), so that the untuned rate can be timed; then the tuning, then
+    # the rate the line reports.
+    tune_env = os.environ.get("LSK_TUNE")
+    os.environ["LSK_TUNE"] = "0"
+    t0 = time.perf_counter()
+    _, offsets, coeffs = bs.sg.benchmark_stencil(4)
+    partition = IndexPartition.equal(IndexSpace(0, rows - 1), world)
+    matrix = bs.sg.create_linearized_csr_stencil_matrix(ctx, (n1, n1, n1), offsets, coeffs, partition, torch.float64)
+    stage("generator", t0)
+    t0 = time.perf_counter()
+    _, planner, solver = bs.build_problem(ctx, 4, n1, n1, n1, world, 1, torch.float64, num_systems=1, matrix=matrix)
+    stage("vectors_partitions_halo_plan", t0)
+    for key in ("compress_32bit", "sliced_copy"):
+        if key in matrix.setup_seconds:
+            setup_s[key] = matrix.setup_seconds[key]
+            setup_s["vectors_partitions_halo_plan"] -= matrix.setup_seconds[key]
+    if tune_env is None:
+        del os.environ["LSK_TUNE"]
+    else:
+        os.environ["LSK_TUNE"] = tune_env
     nnz_total = (3 * n1 - 2) ** 3
     # One untimed matvec Q <- A P before anything is timed: it opens the point-to-point
     # connections of the halo exchange, so that a run with --warmup 0 does not time their set-up.
     # CG's first step overwrites Q with the same product.
     planner.matvec(CGSolver.Q, CGSolver.P)
     ctx.comm.all_reduce_sum(torch.zeros(1, dtype=torch.float64, device=ctx.device))  # likewise the dots' all-reduce
+    untuned_steps = max(args.steps // 2, 2)
+    iters_untuned = untuned_steps / bs.timed_steps(ctx, solver, args.warmup, untuned_steps)
+    if tune_env != "0":
+        before = dict(matrix.setup_seconds)
+        if matrix.sliced:
+            matrix.tune_sliced_copies()
+        else:
+            entry = planner.row_partitioned_matrices[0]
+            x_lo, x_hi = matrix.col32_window if matrix.col32_window else (planner.get_vector(2, 0).own_lo,
+                                                                         planner.get_vector(2, 0).own_hi)
+            matrix.tune(x_lo, x_hi, entry.kernel_partition, partition)
+        for key, v in matrix.setup_seconds.items():
+            if v != before.get(key):
+                setup_s[key] = v - before.get(key, 0.0)
     seconds = bs.timed_steps(ctx, solver, args.warmup, args.steps)
     iters_per_s = args.steps / seconds
     rr = solver.residual_norm_squared[-1].get_value()
 
     # the dominant kernel against its roofline (this rank's launch), priced on the bytes of the
-    # layout it reads: the sliced-pattern copy (values in slices of 64 rows, no column array), else
+    # layout it reads: the sliced-pattern copy (values in blocks of 512 rows, no column array), else
     # the 32-bit copy of the structure, else the 64-bit arrays as handed over
     sliced = bool(matrix.sliced)
     compressed = matrix.col32 is not None
@@ -164,19 +229,20 @@ def main():
     algo_bytes64 = matrix.nnz * 16 + matrix.rows * 32
     if sliced:
         parts = list(matrix.sliced.values())
-        algo_bytes = (sum(p.padded_entries for p in parts) * 8 + matrix.rows * 16 + sum(p.slices for p in parts) * 16
-                      + sum(p.masked_slices for p in parts) * 64 * 4 + sum(p.mixed_slices for p in parts) * 64)
-        kernel = f"sliced_spmv_kernel<double, 9, {'true' if planner_fuses_dot(planner) else 'false'}>"
-        layout = ("values copied once at set-up into slices of 64 rows, one column-pattern id per slice (27 "
-                  "patterns), no column array and no row offsets; every row summed in entry order, bit for bit "
-                  "the reference's CPU loop")
+        algo_bytes = sum(p.algorithmic_bytes(partition.pieces[c].volume, 8) for c, p in matrix.sliced.items())
+        cap = 27
+        kernel = f"sliced_spmv_kernel<double, {cap}, {'true' if planner_fuses_dot(planner) else 'false'}, false>"
+        layout = ("sliced-pattern copy made once at set-up: the values in blocks of 512 rows (16 bytes per lane and "
+                  "entry), one column-pattern id per block (27 patterns), no column array and no row offsets; x "
+                  "staged through LDS; every row summed in entry order, bit for bit the CPU restatement of the "
+                  "reference's loop compiled without floating-point contraction")
     elif compressed:
         algo_bytes, kernel = algo_bytes32, "csr_spmv_wave_kernel<double, unsigned int, 5, false, 8, false>"
         layout = ("32-bit copies of the structure made once at set-up (window-relative columns, row offsets); "
-                  "bit-identical products")
+                  "products bit-identical to those on the 64-bit arrays")
     else:
         algo_bytes, kernel = algo_bytes64, "csr_spmv_wave_kernel<double, long, 5, false, 8, false>"
-        layout = "int64 global columns and 16-byte rects as handed over"
+        layout = "int64 global columns and 16-byte rects as handed over (the reference's layout)"
     t_spmv = spmv_kernel_time(ctx, matrix, planner, reps=20, form="sliced")
     achieved = algo_bytes / t_spmv / 1e9
     # the whole job's product: every rank's bytes over the slowest rank's launch
@@ -187,11 +253,23 @@ def main():
     t_spmv64 = spmv_kernel_time(ctx, matrix, planner, reps=20, form="int64") if (sliced or compressed) else t_spmv
     traffic = traffic32 = traffic64 = None
     traffic_file = os.path.join(REPO, "profiles", "spmv_hbm_traffic.json")
+    traffic_source = None
     if world == 1 and n1 == 512 and os.path.exists(traffic_file):
         measured = json.load(open(traffic_file))
         traffic64 = measured.get("bytes_per_launch")
         traffic32 = measured.get("bytes_per_launch_c32")
         traffic = measured.get("bytes_per_launch_sliced") if sliced else traffic32 if compressed else traffic64
+        traffic_source = ("recorded, not measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                          "tools/pmc_spmv.py, profiles/spmv_hbm_traffic.json")
+
+    # the whole CG step on the reference's arrays as handed over (no set-up-time copy of any kind)
+    held = matrix.sliced_window, matrix.col32_window
+    matrix.sliced_window = matrix.col32_window = None
+    ref_steps = max(args.steps // 4, 2)
+    try:
+        iters_reference_layout = ref_steps / bs.timed_steps(ctx, solver, 2, ref_steps)
+    finally:
+        matrix.sliced_window, matrix.col32_window = held
 
     # the reference's own set-up: two identical systems per step
     del solver, planner
@@ -199,9 +277,12 @@ def main():
                                             matrix=matrix)
     seconds2 = bs.timed_steps(ctx, solver2, 2, max(args.steps // 5, 2))
     two_system = max(args.steps // 5, 2) / seconds2
+    del solver2, planner2
+    host_ms = host_ms_per_step(ctx, world)
 
     line = {
-        "metric": f"CG iters/sec (fp64) on 3D 27-pt stencil {n1}^3, single system",
+        "metric": f"CG iters/sec (fp64) on 3D 27-pt stencil {n1}^3, single system (the reference's BenchmarkStencil "
+                  "steps two such systems per iteration: two_system_iters_per_s)",
         "value": iters_per_s,
         "unit": "iters/s",
         "n_gpus": world,
@@ -214,18 +295,32 @@ def main():
         "dtype": "f64",
         "data": "synthetic",
         "config": {
-            "workload": f"BenchmarkStencil -dim 4 -nx {n1} -ny {n1} -nz {n1} -solver 1 -vp {world}: "
-                        "3-D 27-pt stencil, fp64 CSR with int64 indices and 16-byte row rects, "
-                        "rhs=1, x0=0, one row block per GPU",
+            "workload": f"timed layout: {layout}.  Problem: BenchmarkStencil -dim 4 -nx {n1} -ny {n1} -nz {n1} "
+                        f"-solver 1 -vp {world}: 3-D 27-pt stencil, fp64, generated as CSR with int64 indices and "
+                        "16-byte row rects (kept in HBM beside the copy), rhs=1, x0=0, one row block per GPU",
             "rows": rows, "nnz": nnz_total, "pieces": world,
             "structure_layout": layout,
         },
         "spmv_gbps": spmv_gbps_job,
         "two_system_iters_per_s": two_system,
+        "value_untuned": iters_untuned,
+        "value_reference_layout": iters_reference_layout,
+        "setup_s": {k: round(v, 3) for k, v in setup_s.items()},
+        "host_ms_per_step": host_ms,
+        "notes": {
+            "value_untuned": "the same steps before the set-up-time speed tuning (workgroup placement chosen by timing, "
+                             "the copy re-made up to 6 times keeping the fastest, wait for the driver's scrubbing of freed "
+                             "memory): LSK_TUNE=0",
+            "value_reference_layout": "the same steps with every product on the int64 columns and 16-byte rects as handed "
+                                      "over (csr_spmv_wave_kernel<double, long, ...>), no set-up-time copy",
+            "setup_s": "wall-clock seconds before the first timed step, stage by stage, this rank",
+            "host_ms_per_step": "wall time per CG step on a 32^3 grid with the same ranks, where the host, not the GPU, "
+                                "is the limit: what enqueueing one step costs",
+        },
         "residual_norm_squared_last": rr,
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+            "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
             "kernel": kernel,
             "ms_per_launch": t_spmv * 1e3,
             "algorithmic_bytes_per_launch": algo_bytes,
@@ -245,9 +340,11 @@ def main():
         },
     }
     if ctx.rank == 0 and world == 1 and not args.no_cpu_baseline:
-        del solver2, planner2, matrix
+        for c in list(matrix.sliced):
+            matrix.sliced[c].close()
+        matrix.sliced, matrix.col32, matrix.rowoff = {}, None, {}
         torch.cuda.empty_cache()
-        line["cpu_baseline"] = cpu_baseline(rows)
+        line["cpu_baseline"] = cpu_baseline(matrix, n1)
     if ctx.rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:

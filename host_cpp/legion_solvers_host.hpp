@@ -531,14 +531,14 @@ public:
                                        dst.piece(c), beta, ctx_->stream()));
         }
     }
-    // On the sliced-pattern copy one lane owns a row, so the product can leave the shares of
-    // dot(dst, w) for a wave reduction per slice: one share per 256 rows of every piece.
+    // On the sliced-pattern copy a lane owns its rows, so the product can leave the shares of
+    // dot(dst, w) for a wave reduction per block: one share per block of every piece.
     int64_t dot_shares() const override {
         if (!sliced()) return 0;
         int64_t total = 0;
         for (int c = 0; c < range_.colors(); ++c) {
             if (range_.volume(c) > 0 && !sliced_[c].handle) return 0; // a piece without entries: no fused form
-            total += shares_of(range_.volume(c));
+            total += shares_of(c, range_.volume(c));
         }
         return total;
     }
@@ -552,7 +552,7 @@ public:
             int64_t count = 0;
             check(lsk_set_option("xcd_remap", sliced_[c].placement));
             check(Abi<T>::csr_sliced_spmv_dot(sliced_[c].handle, 0, rows, src.data(), dst.piece(c), 0, w.piece(c), shares,
-                                              shares_of(rows), &count, ctx_->stream()));
+                                              shares_of(c, rows), &count, ctx_->stream()));
             shares += count;
         }
     }
@@ -624,7 +624,7 @@ private:
         Sliced &operator=(const Sliced &) = delete;
         ~Sliced() { lsk_csr_sliced_destroy(handle); }
     };
-    static int64_t shares_of(int64_t rows) { return ((rows + 63) / 64 + 3) / 4; }
+    int64_t shares_of(int c, int64_t rows) const { return lsk_csr_sliced_dot_partials(sliced_[c].handle, 0, rows); }
     bool make_slice(int c, Sliced &out) const { // false: the library declined
         const Piece &p = pieces_[c];
         const int rc = Abi<T>::csr_sliced_create(range_.volume(c), p.nnz, rects_.get() + 2 * range_.piece[c].first, p.k_lo,

@@ -460,10 +460,12 @@ int lsk_sorted_key_offsets_u32(int64_t n, const uint32_t *keys, int64_t nkeys, u
 /* A set-up-time re-layout for CSR matrices whose rows repeat a few column patterns (every
  * linearised stencil: col = row + one of a few lists of distances; at most 64 patterns of at most
  * 32 entries).  lsk_csr_sliced_create_* gives every row the id of its pattern, verifies every entry
- * against the pattern table, and copies the values into slices of 64 consecutive rows stored
- * entry-major (short rows padded with zeros); lsk_csr_sliced_spmv_* then computes rows
- * row_begin..row_end-1 of y <- A x + beta y from that copy alone: no column array and no row
- * offsets are read.  Every row is summed by one lane in ascending entry order with separate
+ * against the pattern table, and copies the values into blocks of 256 R consecutive rows, R = 16 /
+ * sizeof(T) (512 rows of fp64, 1024 of fp32), stored so that one lane loads the j-th values of its R
+ * rows with one 16-byte access (short rows padded with zeros); lsk_csr_sliced_spmv_* then computes
+ * rows row_begin..row_end-1 of y <- A x + beta y from that copy alone: no column array and no row
+ * offsets are read, the windows of x a block's list reads are staged once through LDS, and y leaves
+ * in bursts of 4 KiB.  Every row is summed by one lane in ascending entry order with separate
  * multiply and add, which is bit for bit the loop of the reference's CPU task
  * (src/CSRMatrixTasks.cpp:73-91); the reference's GPU task hands the arrays to cuSPARSE instead
  * (src/CSRMatrixTasks.cu:117-150).
@@ -476,9 +478,10 @@ int lsk_sorted_key_offsets_u32(int64_t n, const uint32_t *keys, int64_t nkeys, u
  * (more patterns, longer rows, a column outside the window, rects outside the piece, or padding
  * that would cost more than the column array saves): stay with lsk_csr_spmv_c32_* / lsk_csr_spmv_*.
  * Set-up time: allocates, synchronises.  lsk_csr_sliced_info: out[0] = padded entries (the values
- * one product reads), out[1] = slices, out[2] = slices whose rows fit no common distance list (every
- * lane looks its own up), out[3] = patterns, out[4] = slices whose rows differ but are ordered parts
- * of one list (run like uniform ones, with a 32-bit mask per row); out holds 5 values.
+ * one product reads), out[1] = blocks, out[2] = blocks whose rows fit no common distance list (every
+ * row looks its own up), out[3] = patterns, out[4] = waves (quarter blocks) in which some row has
+ * only an ordered part of its block's list (they read a 32-bit mask per row), out[5] = rows per
+ * block, out[6] = bytes of LDS a launch uses; out holds 7 values.
  * Option "xcd_remap" places the workgroups as for lsk_csr_spmv_*. */
 typedef struct lsk_csr_sliced lsk_csr_sliced_t;
 int lsk_csr_sliced_create_f32(int64_t rows, int64_t nnz, const int64_t *rects, int64_t k_base, const int64_t *col,
@@ -501,11 +504,13 @@ int lsk_csr_sliced_spmv_f32(const lsk_csr_sliced_t *m, int64_t row_begin, int64_
                             int beta, lsk_stream_t stream);
 int lsk_csr_sliced_spmv_f64(const lsk_csr_sliced_t *m, int64_t row_begin, int64_t row_end, const double *x, double *y,
                             int beta, lsk_stream_t stream);
-/* The same product, and partials[0 .. *count) <- sums over groups of 256 rows of y_new[r] * w[r]
- * (w[0] pairs with the structure's first row, like y), formed from values still in registers and
- * added in a fixed order whatever the placement; lsk_sum_partials_* gives the dot product (CG's
- * p.Ap, src/CGSolver.hpp:46-47, without a pass over y and w).  capacity >= one per 256 rows of
- * row_begin/64*64 .. row_end, rounded up; *count is written on the host. */
+/* The same product, and partials[0 .. *count) <- one sum per block of y_new[r] * w[r] over the
+ * block's rows inside row_begin..row_end-1 (w[0] pairs with the structure's first row, like y),
+ * formed from values still in registers and added in a fixed order whatever the placement;
+ * lsk_sum_partials_* gives the dot product (CG's p.Ap, src/CGSolver.hpp:46-47, without a pass over y
+ * and w).  capacity >= lsk_csr_sliced_dot_partials(m, row_begin, row_end), the number of blocks those
+ * rows touch; *count (that number) is written on the host. */
+int64_t lsk_csr_sliced_dot_partials(const lsk_csr_sliced_t *m, int64_t row_begin, int64_t row_end);
 int lsk_csr_sliced_spmv_dot_f32(const lsk_csr_sliced_t *m, int64_t row_begin, int64_t row_end, const float *x, float *y,
                                 int beta, const float *w, float *partials, int64_t capacity, int64_t *count,
                                 lsk_stream_t stream);

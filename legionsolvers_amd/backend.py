@@ -207,9 +207,12 @@ class HipBackend:
         return remap.value, ms.value
 
     @staticmethod
-    def csr_sliced_dot_slots(row_end: int, row_begin: int = 0) -> int:
-        """Partial sums lsk_csr_sliced_spmv_dot_* leaves for rows row_begin..row_end-1."""
-        return -(-(-(-row_end // 64) - row_begin // 64) // 4)
+    def csr_sliced_dot_slots(sliced: "SlicedStructure", row_end: int, row_begin: int = 0) -> int:
+        """Partial sums lsk_csr_sliced_spmv_dot_* leaves for rows row_begin..row_end-1: one per block
+        of the structure those rows touch."""
+        if row_end <= row_begin:
+            return 0
+        return -(-row_end // sliced.block_rows) - row_begin // sliced.block_rows
 
     def csr_sliced_spmv_dot(self, sliced: "SlicedStructure", row_end: int, x: torch.Tensor, y: torch.Tensor, beta: int,
                             w: torch.Tensor, partials: torch.Tensor, placement: int = 0, row_begin: int = 0) -> int:
@@ -336,9 +339,16 @@ class SlicedStructure:
 
     def __init__(self, lib, handle, dtype):
         self.lib, self.handle, self.dtype = lib, handle, dtype
-        out = (ctypes.c_int64 * 5)()
+        out = (ctypes.c_int64 * 7)()
         _lib.check(lib.lsk_csr_sliced_info(handle, out))
-        self.padded_entries, self.slices, self.mixed_slices, self.patterns, self.masked_slices = (int(v) for v in out)
+        (self.padded_entries, self.blocks, self.mixed_blocks, self.patterns, self.masked_waves, self.block_rows,
+         self.lds_bytes) = (int(v) for v in out)
+
+    def algorithmic_bytes(self, rows: int, elem_size: int) -> int:
+        """Bytes one product of `rows` rows must move: the padded values, x and y once, 16 per block,
+        a 4-byte mask per row of a masked wave, a pattern id per row of a block without a common list."""
+        return (self.padded_entries * elem_size + rows * 2 * elem_size + self.blocks * 16
+                + self.masked_waves * (self.block_rows // 4) * 4 + self.mixed_blocks * self.block_rows)
 
     def close(self) -> None:
         if self.handle:

@@ -2,43 +2,37 @@
 // repeat a few column patterns (every linearised stencil: col = row + one of a few distance lists).
 //
 // At set-up each row gets the id of its pattern (the list of col - row over its entries, in entry
-// order), the patterns go into a small table, and the entry values are copied into slices of 64
-// consecutive rows stored entry-major (value j of lane l of a slice at base + 64 j + l, short rows
-// padded with zeros).  The product then reads NO column array and no row offsets: one wave takes
-// one slice, lane l owns row l, and for j = 0, 1, ... every lane loads its j-th value (one
-// contiguous 64-element run per wave) and x[row + distance_j] (for a slice whose rows share one
-// pattern also one contiguous run, the distance being wave-uniform).  Each row is summed by one
-// lane in ascending entry order with separate multiply and add: bit for bit the loop of the
-// reference's CPU task (src/CSRMatrixTasks.cpp:73-91 visits the entries in ascending k and adds
-// val * x into the row's sum).  What the reference does on the GPU instead is hand the arrays to
-// cuSPARSE on every call (src/CSRMatrixTasks.cu:117-150).
+// order) and the patterns go into a small table.  Rows are taken in BLOCKS of 256 R consecutive rows,
+// R = 16 / sizeof(T) (512 rows of fp64, 1024 of fp32): one workgroup of four waves per block, a lane
+// owning R consecutive rows.  The entry values are copied block by block, for each of the block's four
+// waves entry-major: value j of the R rows of lane l of wave w at
+//     base + (w * maxlen + j) * 64 R + l * R,
+// 16 bytes that one lane loads at once (1 KiB per wave-instruction), short rows padded with zeros.
+// The product reads NO column array and no row offsets.  A block whose rows all follow one distance
+// list (or ordered parts of one list: the row's 32-bit mask says which entries it has) is served
+// through LDS: the list falls into runs of consecutive distances (27-point stencil: 9 runs of 3), the
+// window of x each run reads, 256 R + length - 1 consecutive elements, is staged once, coalesced, and
+// every lane then takes its x values from there -- 9 global reads of x per row instead of 27, which
+// measured 1.3 ms of a 6.4 ms product on the 27-point 512^3 matrix.  y leaves with nontemporal
+// 16-byte stores behind the block's barrier, 4 KiB per workgroup at a time: stores trickling out wave
+// by wave, 512 bytes at a time, cost another 1.5 ms there.  Each row is summed by one lane in
+// ascending entry order with separate multiply and add: bit for bit the loop of the reference's CPU
+// task (src/CSRMatrixTasks.cpp:73-91 visits the entries in ascending k and adds val * x into the row's
+// sum).  What the reference does on the GPU instead is hand the arrays to cuSPARSE on every call
+// (src/CSRMatrixTasks.cu:117-150).
 //
-// A slice whose rows differ (the ends of a grid line) still runs on one distance list when every
-// row's list is an ordered part of the slice's longest one: the row's 32-bit mask says which
-// entries it has, the others hold a zero that is never used.
-//
-// Bytes per launch: padded entries * sizeof(T) + rows * 2 sizeof(T) (x once, y once) + 16 per
-// slice + 4 per row of a masked slice (+ 1 per row of a slice that fits no common list).
+// Bytes per launch: padded entries * sizeof(T) + rows * 2 sizeof(T) (x once, y once) + 16 per block
+// + 4 per row of a masked wave's rows (+ 1 per row of a block that fits no common list).
 #include <algorithm>
 #include <climits>
 #include <cstdlib>
 #include <new>
+#include <type_traits>
+#include <vector>
 
 #include <hipcub/hipcub.hpp>
 
 #include "lsk_common.hpp"
-
-struct lsk_csr_sliced {
-    int elem_bytes = 0;
-    int64_t rows = 0, nnz = 0, k_base = 0, row_first = 0, x_lo = 0, x_hi = -1;
-    int64_t slices = 0, padded_entries = 0, mixed_slices = 0, masked_slices = 0;
-    int patterns = 0;
-    void *val = nullptr;           // padded_entries values, slice by slice, entry-major inside a slice
-    void *meta = nullptr;          // per slice {int64 base; int32 maxlen; int32 pattern (| kSliceMasked) or -1}
-    unsigned char *row_pattern = nullptr; // per row
-    unsigned *row_mask = nullptr;  // per row: which entries of its slice's list the row has (masked slices)
-    int *table = nullptr;          // kMaxPatterns lengths, then kMaxPatterns x kMaxLength distances
-};
 
 namespace {
 
@@ -46,20 +40,83 @@ using lsk::kBlock;
 using lsk::kWave;
 constexpr int kMaxPatterns = 64;
 constexpr int kMaxLength = 32;
-constexpr int kTableInts = kMaxPatterns + kMaxPatterns * kMaxLength;
+constexpr int kMaxRuns = 16;
+constexpr int kWavesPerBlock = kBlock / kWave;
+constexpr size_t kMaxStageBytes = 60 << 10; // of LDS per workgroup for the staged windows of x
 
-constexpr int kSliceMasked = 0x100;
-struct SliceMeta {
+// One pattern: its distance list and how a block stages the windows of x the list reads.
+struct PatternInfo {
+    int len;        // entries; -1: unused slot
+    int nruns;      // runs of consecutive distances; 0: not staged (too many runs or too much LDS)
+    int lds_elems;  // elements of LDS the staged windows take, for blocks of 256 R rows
+    int pad;
+    int dist[kMaxLength];     // distance of entry j
+    int lds_off[kMaxLength];  // where the x value of entry j for the block's first row sits in LDS
+    unsigned lds_off_packed[kMaxLength / 2]; // the same, two 16-bit offsets per word (entry 2k low, 2k + 1 high)
+    int run_start[kMaxRuns];  // first distance of run q
+    int run_len[kMaxRuns];
+    int run_off[kMaxRuns];    // where run q's window starts in LDS
+    // A run's window is the block's 256 R rows wide plus run_len - 1 elements; those extra elements
+    // of all runs, as one list (at most kMaxLength - 1 of them): element t of it is x at distance
+    // tail_dist[t] from the block's first row and goes to LDS position tail_off[t].
+    int ntail;
+    int tail_dist[kMaxLength];
+    int tail_off[kMaxLength];
+};
+
+} // namespace
+
+struct lsk_csr_sliced {
+    int elem_bytes = 0;
+    int64_t rows = 0, nnz = 0, k_base = 0, row_first = 0, x_lo = 0, x_hi = -1;
+    int64_t blocks = 0, padded_entries = 0, mixed_blocks = 0, masked_waves = 0;
+    int patterns = 0, max_len = 0;
+    bool all_staged = true;        // every pattern's x windows fit the staging area
+    size_t lds_bytes = 0;          // dynamic LDS of a launch: the largest staging area of any pattern
+    void *val = nullptr;           // padded_entries values, block by block
+    void *meta = nullptr;          // per block {int64 base; int32 maxlen; int32 pattern | flags, or -1}
+    unsigned char *row_pattern = nullptr; // per row
+    unsigned *row_mask = nullptr;  // per row: which entries of its block's list the row has
+    PatternInfo *table = nullptr;  // kMaxPatterns entries
+};
+
+namespace {
+
+template <typename T> struct Lane;
+template <> struct Lane<double> {
+    static constexpr int R = 2;
+    typedef double V __attribute__((ext_vector_type(2)));
+};
+template <> struct Lane<float> {
+    static constexpr int R = 4;
+    typedef float V __attribute__((ext_vector_type(4)));
+};
+
+// A 16-byte nontemporal store, written out: given the builtin, the compiler merges this path with the
+// row-by-row one beside it into two plain 8-byte stores.
+typedef float Bits16 __attribute__((ext_vector_type(4)));
+template <typename V>
+__device__ __forceinline__ void store16_nontemporal(void *p, V value) {
+    static_assert(sizeof(V) == 16, "16-byte vectors");
+    const Bits16 bits = __builtin_bit_cast(Bits16, value);
+    asm volatile("global_store_dwordx4 %0, %1, off nt" : : "v"(p), "v"(bits) : "memory");
+}
+
+constexpr int kBlockMasked = 0x100;      // some row of the block has only part of the block's list
+constexpr int kWaveMaskedShift = 12;     // bits 12..15: which of the block's four waves have such rows
+struct BlockMeta {
     long long base;
     int maxlen;
-    // pattern id: every row of the slice has exactly that distance list; id | kSliceMasked: every row
-    // has an ordered part of that list (its row_mask says which); -1: neither
+    // list id (| flags): every row of the block has that distance list, or (kBlockMasked) an ordered
+    // part of it given by its row_mask; -1: the rows fit no common list
     int pattern;
 };
-static_assert(sizeof(SliceMeta) == 16, "slice record is 16 bytes");
+static_assert(sizeof(BlockMeta) == 16, "block record is 16 bytes");
 
 // Flags the set-up kernels raise (any non-zero: the matrix does not get this structure).
 enum { kFlagTooManyPatterns = 0, kFlagRowTooLong = 1, kFlagMismatch = 2, kFlagOutsideWindow = 3, kFlagBadRect = 4, kFlags = 8 };
+// Per block, while it is being classified.
+enum { kBlkNeedsMasks = 1, kBlkMixed = 2, kBlkWaveShift = 4 };
 
 __device__ __forceinline__ unsigned long long mix64(unsigned long long h, unsigned long long v) {
     h ^= v + 0x9e3779b97f4a7c15ull + (h << 6) + (h >> 2);
@@ -67,11 +124,11 @@ __device__ __forceinline__ unsigned long long mix64(unsigned long long h, unsign
     return h ^ (h >> 32);
 }
 
-__global__ void sliced_init_kernel(unsigned long long *keys, int *flags, long long *mixed, int *table) {
-    for (int i = threadIdx.x; i < kTableInts; i += blockDim.x) table[i] = 0;
+__global__ void sliced_init_kernel(unsigned long long *keys, int *flags, long long *counts, int *lists) {
+    for (int i = threadIdx.x; i < kMaxPatterns * (kMaxLength + 1); i += blockDim.x) lists[i] = 0;
     if (threadIdx.x < kMaxPatterns) keys[threadIdx.x] = 0;
     if (threadIdx.x < kFlags) flags[threadIdx.x] = 0;
-    if (threadIdx.x < 2) mixed[threadIdx.x] = 0;
+    if (threadIdx.x < 3) counts[threadIdx.x] = 0;
 }
 
 // Pass 1: hash of every row's (length, distances) list; first come, first served into the pattern
@@ -113,35 +170,37 @@ __global__ __launch_bounds__(kBlock) void sliced_assign_kernel(
     flags[kFlagTooManyPatterns] = 1;
 }
 
-// Pass 2: the table, from the representatives.  table[s] = length, table[kMaxPatterns + 32 s + j] =
-// distance of entry j.
-__global__ void sliced_table_kernel(const long long *__restrict__ rects, long long k_base,
+// Pass 2: the lists, from the representatives.  lists[s * 33] = length (-1: unused slot),
+// lists[s * 33 + 1 + j] = distance of entry j.
+__global__ void sliced_lists_kernel(const long long *__restrict__ rects, long long k_base,
                                     const long long *__restrict__ col, long long row_first,
                                     const unsigned long long *__restrict__ keys, const long long *__restrict__ rep,
-                                    int *__restrict__ table, int *flags) {
+                                    int *__restrict__ lists, int *flags) {
     const int s = threadIdx.x;
     if (s >= kMaxPatterns) return;
+    int *mine = lists + s * (kMaxLength + 1);
     if (keys[s] == 0) {
-        table[s] = -1;
+        mine[0] = -1;
         return;
     }
     const long long r = rep[s];
     const long long lo = rects[2 * r] - k_base, hi = rects[2 * r + 1] - k_base;
-    table[s] = hi >= lo ? static_cast<int>(hi - lo + 1) : 0;
+    mine[0] = hi >= lo ? static_cast<int>(hi - lo + 1) : 0;
     for (long long k = lo; k <= hi; ++k) {
         const long long d = col[k] - (row_first + r);
-        if (d > INT_MAX || d < INT_MIN) flags[kFlagOutsideWindow] = 1;
-        table[kMaxPatterns + kMaxLength * s + static_cast<int>(k - lo)] = static_cast<int>(d);
+        if (d > INT_MAX / 2 || d < INT_MIN / 2) flags[kFlagOutsideWindow] = 1;
+        mine[1 + static_cast<int>(k - lo)] = static_cast<int>(d);
     }
 }
 
 // Pass 3: every entry against the table (so that a hash collision can never produce a wrong
-// column) and against the window of x; per slice, the longest row and whether one pattern covers it.
+// column) and against the window of x; per group of 64 rows, the longest row, the pattern of a
+// longest row, and the one pattern all its rows share (-1: they differ).
 __global__ __launch_bounds__(kBlock) void sliced_verify_kernel(
     int64_t rows, const long long *__restrict__ rects, long long k_base, const long long *__restrict__ col,
     long long row_first, long long x_lo, long long x_hi, const unsigned char *__restrict__ row_pattern,
-    const int *__restrict__ table, unsigned *__restrict__ row_mask, long long *__restrict__ slice_entries,
-    SliceMeta *__restrict__ meta, int *flags) {
+    const PatternInfo *__restrict__ table, int *__restrict__ g_maxlen, int *__restrict__ g_holder,
+    int *__restrict__ g_uniform, int *flags) {
     const int64_t r = int64_t(blockIdx.x) * kBlock + threadIdx.x;
     const bool live = r < rows;
     int len = 0, pat = -1;
@@ -149,10 +208,10 @@ __global__ __launch_bounds__(kBlock) void sliced_verify_kernel(
         pat = row_pattern[r];
         const long long lo = rects[2 * r] - k_base;
         len = max(static_cast<int>(rects[2 * r + 1] - k_base - lo + 1), 0);
-        bool ok = table[pat] == len;
+        bool ok = table[pat].len == len;
         for (int j = 0; ok && j < len; ++j) {
             const long long c = col[lo + j];
-            ok = c == row_first + r + table[kMaxPatterns + kMaxLength * pat + j];
+            ok = c == row_first + r + table[pat].dist[j];
             if (c < x_lo || c > x_hi) flags[kFlagOutsideWindow] = 1;
         }
         if (!ok) flags[kFlagMismatch] = 1;
@@ -160,178 +219,448 @@ __global__ __launch_bounds__(kBlock) void sliced_verify_kernel(
     int maxlen = len;
 #pragma unroll
     for (int off = kWave / 2; off > 0; off >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, off, kWave));
-    // the first live lane's pattern, compared by all live lanes
-    const int first = __builtin_amdgcn_readfirstlane(pat); // lane 0 of a slice is live whenever the slice exists
+    const int first = __builtin_amdgcn_readfirstlane(pat); // lane 0 of a group is live whenever the group exists
     const bool uniform = __all(!live || pat == first);
-    int slice_pattern = uniform ? first : -1;
-    unsigned mask = live ? 0xffffffffu : 0u;
-    if (!uniform) {
-        // The slice's longest list (lowest lane among equals) as the common list: does every row's own
-        // list occur in it, in order?  Then the row's mask marks its entries' positions there.
-        const unsigned long long holders = __ballot(live && len == maxlen);
-        const int common = __shfl(pat, __ffsll(static_cast<long long>(holders)) - 1, kWave);
-        bool fits = true;
-        mask = 0u;
-        if (live) {
-            const int *mine = table + kMaxPatterns + kMaxLength * pat;
-            const int *list = table + kMaxPatterns + kMaxLength * common;
-            int pos = 0;
-            for (int j = 0; fits && j < len; ++j) {
-                while (pos < maxlen && list[pos] != mine[j]) ++pos;
-                fits = pos < maxlen;
-                if (fits) mask |= 1u << pos++;
-            }
-        }
-        if (__all(fits)) slice_pattern = common | kSliceMasked;
-    }
-    if (live) row_mask[r] = mask;
+    const unsigned long long holders = __ballot(live && len == maxlen);
+    const int holder = holders ? __shfl(pat, __ffsll(static_cast<long long>(holders)) - 1, kWave) : -1;
     if (threadIdx.x % kWave == 0 && live) {
-        const int64_t slice = r / kWave;
-        slice_entries[slice] = static_cast<long long>(maxlen) * kWave;
-        meta[slice].maxlen = maxlen;
-        meta[slice].pattern = slice_pattern;
+        const int64_t g = r / kWave;
+        g_maxlen[g] = maxlen;
+        g_holder[g] = holder;
+        g_uniform[g] = uniform ? first : -1;
     }
 }
 
-__global__ __launch_bounds__(kBlock) void sliced_bases_kernel(int64_t slices, const long long *__restrict__ entries,
-                                                              const long long *__restrict__ inclusive,
-                                                              SliceMeta *__restrict__ meta, long long *mixed) {
-    const int64_t s = int64_t(blockIdx.x) * kBlock + threadIdx.x;
-    if (s >= slices) return;
-    meta[s].base = inclusive[s] - entries[s];
-    if (meta[s].pattern < 0) atomicAdd(reinterpret_cast<unsigned long long *>(mixed), 1ull);
-    else if (meta[s].pattern & kSliceMasked) atomicAdd(reinterpret_cast<unsigned long long *>(mixed) + 1, 1ull);
+// Pass 4: per block of `groups` groups of 64 rows: the longest row, the list of a longest row as
+// the block's common list, and whether every row has exactly that list.
+__global__ __launch_bounds__(kBlock) void sliced_combine_kernel(int64_t blocks, int64_t total_groups, int groups,
+                                                                const int *__restrict__ g_maxlen,
+                                                                const int *__restrict__ g_holder,
+                                                                const int *__restrict__ g_uniform,
+                                                                BlockMeta *__restrict__ meta, int *__restrict__ blk_flags) {
+    const int64_t b = int64_t(blockIdx.x) * kBlock + threadIdx.x;
+    if (b >= blocks) return;
+    int maxlen = -1, common = -1;
+    bool uniform = true;
+    for (int i = 0; i < groups; ++i) {
+        const int64_t g = b * groups + i;
+        if (g >= total_groups) break;
+        if (g_maxlen[g] > maxlen) {
+            maxlen = g_maxlen[g];
+            common = g_holder[g];
+        }
+    }
+    for (int i = 0; i < groups; ++i) {
+        const int64_t g = b * groups + i;
+        if (g >= total_groups) break;
+        uniform = uniform && g_uniform[g] == common;
+    }
+    meta[b].maxlen = max(maxlen, 0);
+    meta[b].pattern = common;
+    blk_flags[b] = uniform ? 0 : kBlkNeedsMasks;
 }
 
-// Pass 4: the values into their slices -- entry j of a row at position j, or, in a masked slice, at
-// the position of its distance in the slice's list -- zeros everywhere else.
-template <typename T>
-__global__ __launch_bounds__(kBlock) void sliced_fill_kernel(int64_t rows, const long long *__restrict__ rects,
-                                                             long long k_base, const T *__restrict__ val,
-                                                             const SliceMeta *__restrict__ meta,
-                                                             const unsigned *__restrict__ row_mask, T *__restrict__ out) {
+// Pass 5: every row's mask: which entries of its block's common list it has (in order).  A row whose
+// list is no ordered part of the common list makes the block "mixed".
+__global__ __launch_bounds__(kBlock) void sliced_masks_kernel(int64_t rows, int block_rows,
+                                                              const unsigned char *__restrict__ row_pattern,
+                                                              const PatternInfo *__restrict__ table,
+                                                              const BlockMeta *__restrict__ meta, int *blk_flags,
+                                                              unsigned *__restrict__ row_mask) {
     const int64_t r = int64_t(blockIdx.x) * kBlock + threadIdx.x;
-    const int64_t slice = r / kWave;
-    if (slice * kWave >= rows) return;
-    const SliceMeta m = meta[slice];
+    if (r >= rows) return;
+    const int64_t b = r / block_rows;
+    const int pat = row_pattern[r];
+    const int len = table[pat].len;
+    const unsigned full = len >= 32 ? 0xffffffffu : (1u << len) - 1u;
+    const int common = meta[b].pattern;
+    if (pat == common || !(blk_flags[b] & kBlkNeedsMasks)) {
+        row_mask[r] = full;
+        return;
+    }
+    const int *mine = table[pat].dist;
+    const int *list = table[common].dist;
+    const int maxlen = table[common].len;
+    unsigned mask = 0u;
+    int pos = 0;
+    bool fits = true;
+    for (int j = 0; fits && j < len; ++j) {
+        while (pos < maxlen && list[pos] != mine[j]) ++pos;
+        fits = pos < maxlen;
+        if (fits) mask |= 1u << pos++;
+    }
+    if (!fits) {
+        atomicOr(&blk_flags[b], kBlkMixed);
+        row_mask[r] = full; // in a mixed block entry j of a row sits at position j
+        return;
+    }
+    row_mask[r] = mask;
+    const int wave = static_cast<int>((r % block_rows) / (block_rows / kWavesPerBlock));
+    atomicOr(&blk_flags[b], 1 << (kBlkWaveShift + wave));
+}
+
+// Pass 6: the blocks' final records and sizes.
+__global__ __launch_bounds__(kBlock) void sliced_finish_kernel(int64_t blocks, int64_t rows, int block_rows,
+                                                               const int *__restrict__ blk_flags,
+                                                               BlockMeta *__restrict__ meta, long long *__restrict__ entries,
+                                                               long long *counts) {
+    const int64_t b = int64_t(blockIdx.x) * kBlock + threadIdx.x;
+    if (b >= blocks) return;
+    const int f = blk_flags[b];
+    entries[b] = static_cast<long long>(meta[b].maxlen) * block_rows;
+    // counts[2]: the padded entries of rows that exist (the last block's missing rows left out)
+    const long long here = min(static_cast<long long>(block_rows), static_cast<long long>(rows - b * block_rows));
+    atomicAdd(reinterpret_cast<unsigned long long *>(counts) + 2, static_cast<unsigned long long>(meta[b].maxlen * here));
+    if (f & kBlkMixed) {
+        meta[b].pattern = -1;
+        atomicAdd(reinterpret_cast<unsigned long long *>(counts), 1ull);
+        return;
+    }
+    const int waves = (f >> kBlkWaveShift) & 0xf;
+    if (waves) {
+        meta[b].pattern |= kBlockMasked | (waves << kWaveMaskedShift);
+        atomicAdd(reinterpret_cast<unsigned long long *>(counts) + 1, static_cast<unsigned long long>(__popc(waves)));
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void sliced_bases_kernel(int64_t blocks, const long long *__restrict__ entries,
+                                                              const long long *__restrict__ inclusive,
+                                                              BlockMeta *__restrict__ meta) {
+    const int64_t b = int64_t(blockIdx.x) * kBlock + threadIdx.x;
+    if (b < blocks) meta[b].base = inclusive[b] - entries[b];
+}
+
+// Pass 7: the values into their blocks -- entry j of a row at position j, or, in a masked block, at
+// the position of its distance in the block's list -- zeros everywhere else (rows past the end too).
+template <typename T>
+__global__ __launch_bounds__(kBlock) void sliced_fill_kernel(int64_t rows, int64_t padded_rows, const long long *__restrict__ rects,
+                                                             long long k_base, const T *__restrict__ val,
+                                                             const BlockMeta *__restrict__ meta,
+                                                             const unsigned *__restrict__ row_mask, T *__restrict__ out) {
+    constexpr int R = Lane<T>::R;
+    constexpr int kBlockRows = kBlock * R, kWaveRows = kWave * R;
+    const int64_t r = int64_t(blockIdx.x) * kBlock + threadIdx.x;
+    if (r >= padded_rows) return;
+    const int64_t b = r / kBlockRows;
+    const int in = static_cast<int>(r % kBlockRows);
+    const BlockMeta m = meta[b];
     long long lo = 0;
-    int len = 0;
     unsigned mask = 0u;
     if (r < rows) {
         lo = rects[2 * r] - k_base;
-        len = max(static_cast<int>(rects[2 * r + 1] - k_base - lo + 1), 0);
-        mask = (m.pattern >= 0 && (m.pattern & kSliceMasked)) ? row_mask[r] : (len >= 32 ? 0xffffffffu : (1u << len) - 1u);
+        const int len = max(static_cast<int>(rects[2 * r + 1] - k_base - lo + 1), 0);
+        mask = (m.pattern >= 0 && (m.pattern & kBlockMasked)) ? row_mask[r] : (len >= 32 ? 0xffffffffu : (1u << len) - 1u);
     }
-    T *dst = out + m.base + (r % kWave);
+    T *dst = out + m.base + int64_t(in / kWaveRows) * m.maxlen * kWaveRows + in % kWaveRows;
     for (int j = 0; j < m.maxlen; ++j) {
         const bool has = (mask >> j) & 1u;
-        dst[int64_t(j) * kWave] = has ? val[lo + __popc(mask & ((1u << j) - 1u))] : T(0);
+        dst[int64_t(j) * kWaveRows] = has ? val[lo + __popc(mask & ((1u << j) - 1u))] : T(0);
     }
 }
 
-// Entries j0 .. j0 + B - 1 of a slice whose lanes all follow the distance list `dist` (wave-uniform,
-// so the x loads of a wave are one contiguous run): B loads of values (streamed past the caches:
-// nothing reads them twice) and of x in flight per lane, then the sums in entry order.  `mask` bit j
-// says whether the lane's row has entry j; a padding zero is never multiplied with an x value.
-template <typename T, int B>
-__device__ __forceinline__ T sliced_batch(T acc, const T *vp, const T *xp, const int *dist, int j0, int maxlen,
-                                          unsigned mask) {
-    T v[B], xv[B];
-#pragma unroll
-    for (int i = 0; i < B; ++i) {
-        if (j0 + i < maxlen) { // wave-uniform
-            v[i] = __builtin_nontemporal_load(vp + int64_t(j0 + i) * kWave);
-            xv[i] = (mask >> (j0 + i)) & 1u ? xp[dist[j0 + i]] : T(0);
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < B; ++i)
-        if (j0 + i < maxlen && ((mask >> (j0 + i)) & 1u)) acc = acc + v[i] * xv[i];
-    return acc;
+// The product.  One workgroup per block of 256 R rows; lane t owns rows R t .. R t + R - 1 of the
+// block.  CAP: the longest row the instance serves (all of a lane's value loads are in flight at
+// once).  DOT: workgroup g (of the logical order, whatever its placement) also leaves partials[g] =
+// the sum over its rows of y_new[r] * w[r], added up in a fixed order.
+// Four waves per SIMD (128 registers) where the instance fits them without spilling -- a spill costs
+// far more here than the fourth wave brings -- else three.
+template <typename T, int CAP, bool GENERAL>
+constexpr int sliced_waves_per_simd() {
+    if (GENERAL && CAP > 27) return 2;
+    return (CAP <= 20 || (CAP <= 27 && sizeof(T) == 8 && !GENERAL)) && !(GENERAL && sizeof(T) == 4 && CAP > 16) ? 4 : 3;
 }
-
-// The product.  One wave per slice, lane l = row l of the slice.  DOT: workgroup g (of the logical
-// order, whatever its placement) also leaves partials[g] = the sum over its rows of y_new[r] * w[r],
-// added up in a fixed order.
-template <typename T, int B, bool DOT>
-__global__ __launch_bounds__(kBlock) void sliced_spmv_kernel(
-    int64_t slice_begin, int64_t slice_count, int64_t row_begin, int64_t row_end, const SliceMeta *__restrict__ meta,
+// GENERAL: also serves blocks whose list is not staged (x straight from memory) and blocks without a
+// common list; the instance without it is what every stencil matrix runs on.
+template <typename T, int CAP, bool DOT, bool GENERAL>
+__global__ __launch_bounds__(kBlock, (sliced_waves_per_simd<T, CAP, GENERAL>())) void sliced_spmv_kernel(
+    int64_t block_begin, int64_t rows, int64_t row_begin, int64_t row_end, const BlockMeta *__restrict__ meta,
     const T *__restrict__ val, const unsigned char *__restrict__ row_pattern, const unsigned *__restrict__ row_mask,
-    const int *__restrict__ table, const T *__restrict__ x, long long x_shift, T *__restrict__ y, int beta, int remap,
-    const T *__restrict__ w, T *__restrict__ partials) {
-    __shared__ T wave_share[kBlock / kWave];
+    const PatternInfo *__restrict__ table, const T *__restrict__ x, long long x_shift, long long x_extent,
+    T *__restrict__ y, int beta, int remap, const T *__restrict__ w, T *__restrict__ partials, int yw_aligned) {
+    constexpr int R = Lane<T>::R;
+    using V = typename Lane<T>::V;
+    // y and w are accessed 16 bytes at a time where they are 16-byte aligned (the lane's first row is a
+    // multiple of R, so that is a property of the base pointers: yw_aligned), else element by element
+    constexpr int kBlockRows = kBlock * R, kWaveRows = kWave * R;
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    T *xs = reinterpret_cast<T *>(lds_raw);
+    __shared__ T wave_share[kWavesPerBlock];
+
     const unsigned wg = lsk::xcd_remap(blockIdx.x, gridDim.x, remap);
-    const int64_t local = int64_t(wg) * (kBlock / kWave) + threadIdx.x / kWave;
-    if (local >= slice_count) { // (only in the last workgroup)
-        if constexpr (DOT) {
-            wave_share[threadIdx.x / kWave] = T(0);
-            __syncthreads();
-        }
-        return;
-    }
-    const int64_t slice = slice_begin + local;
-    const int lane = threadIdx.x % kWave;
-    const int64_t r = slice * kWave + lane;
-    const bool live = r >= row_begin && r < row_end;
-    const SliceMeta m = meta[slice];
+    const int64_t block = block_begin + wg;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave), lane = threadIdx.x % kWave;
+    const BlockMeta m = meta[block];
     const long long base = lsk::wave_first(m.base);
     const int maxlen = __builtin_amdgcn_readfirstlane(m.maxlen);
     const int pattern = __builtin_amdgcn_readfirstlane(m.pattern);
-    const T *vp = val + base + lane;
-    const T *xp = x + (r + x_shift); // x[column] = xp[distance]
-    T acc = (beta && live) ? y[r] : T(0);
-    if (pattern >= 0) {
-        // One distance list for the whole slice: every row has all of it (kSliceMasked clear) or an
-        // ordered part of it, given by the row's mask.
-        const int *dist = table + kMaxPatterns + kMaxLength * (pattern & 0xff); // wave-uniform address
-        const unsigned mask = !live ? 0u : (pattern & kSliceMasked) ? row_mask[r] : 0xffffffffu;
-        for (int j = 0; j < maxlen; j += B) acc = sliced_batch<T, B>(acc, vp, xp, dist, j, maxlen, mask);
-    } else {
-        // Rows whose patterns fit no common list: every lane looks its own distances up, eight at a
-        // time (the table's rows are 128-byte aligned), and adds only the entries its row has.
-        const int pat = live ? row_pattern[r] : 0;
-        const int len = live ? table[pat] : 0;
-        const int4 *dist4 = reinterpret_cast<const int4 *>(table + kMaxPatterns + kMaxLength * pat);
-        for (int j = 0; j < maxlen; j += 8) {
-            const int4 da = dist4[j / 4], db = dist4[j / 4 + 1];
-            const int d[8] = {da.x, da.y, da.z, da.w, db.x, db.y, db.z, db.w};
-            T v[8], xv[8];
+    const int64_t r0 = block * kBlockRows;
+    const int64_t r = r0 + int64_t(threadIdx.x) * R;
+
+    // all of the lane's values first: they are what comes from HBM (streamed past the caches: nothing
+    // reads them twice)
+    const T *vp = val + base + int64_t(wave) * maxlen * kWaveRows + lane * R;
+    // All of a lane's values are requested at once, after the x windows have been staged and the
+    // registers of that are free again (27 values of two doubles and everything else: 128 registers,
+    // four waves per SIMD).  (Measured on the 27-point 512^3 matrix: everything in flight without a
+    // spill 4.7 ms; 8 to 12 values in flight, the others requested as those are used, 5.4-5.7 ms; any
+    // spill 5.5-6.8 ms.  LSK_SLICED_CHUNK builds the burst forms for such measurements.)
+#ifdef LSK_SLICED_CHUNK
+    constexpr int CHUNK = CAP < LSK_SLICED_CHUNK ? CAP : LSK_SLICED_CHUNK;
+#else
+    constexpr int CHUNK = CAP;
+#endif
+    constexpr int NCHUNKS = (CAP + CHUNK - 1) / CHUNK;
+    V v[CAP];
+    auto load_chunk = [&](int c) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                v[i] = j + i < maxlen ? __builtin_nontemporal_load(vp + int64_t(j + i) * kWave) : T(0);
-                xv[i] = j + i < len ? xp[d[i]] : T(0);
+        for (int j = c * CHUNK; j < (c + 1) * CHUNK && j < CAP; ++j) {
+            // (a value past the block's longest row is 0, not undefined: undefined ones cost spills)
+            if (j < maxlen) v[j] = __builtin_nontemporal_load(reinterpret_cast<const V *>(vp + int64_t(j) * kWaveRows));
+            else v[j] = V(0);
+        }
+    };
+#ifndef LSK_SLICED_STAGE_FIRST
+#define LSK_SLICED_STAGE_FIRST 1
+#endif
+    if (GENERAL || !LSK_SLICED_STAGE_FIRST) load_chunk(0);
+
+    bool live[R];
+    bool all_live = true;
+    T acc[R];
+#pragma unroll
+    for (int h = 0; h < R; ++h) {
+        live[h] = r + h >= row_begin && r + h < row_end;
+        all_live = all_live && live[h];
+        acc[h] = (beta && live[h]) ? y[r + h] : T(0);
+    }
+
+    if (!GENERAL || pattern >= 0) {
+        const PatternInfo &info = table[pattern & 0xff]; // wave-uniform address
+        unsigned mask[R];
+        const bool masked = (pattern >> (kWaveMaskedShift + wave)) & 1;
+#pragma unroll
+        for (int h = 0; h < R; ++h) mask[h] = !live[h] ? 0u : masked ? row_mask[r + h] : 0xffffffffu;
+        const int nruns = info.nruns;
+        if (!GENERAL || nruns > 0) {
+            // The windows of x the block's list reads, one per run of consecutive distances, staged
+            // once: four runs' loads in flight at a time, never behind a branch (an element outside
+            // the vector -- only rows that lack the entry point there -- is read from a clamped address
+            // and replaced by 0), then the few elements by which the windows are wider than the block.
+            const long long xbase = r0 + x_shift + threadIdx.x;
+            const long long xlast = x_extent - 1;
+            auto fetch = [&](long long xi) {
+                const long long c = xi < 0 ? 0 : (xi > xlast ? xlast : xi);
+                const T got = x[c];
+                return c == xi ? got : T(0);
+            };
+            constexpr int QB = 4;
+            for (int q0 = 0; q0 < nruns; q0 += QB) {
+                T got[QB][R];
+                // (run slots past the last one repeat it: staged again, harmlessly)
+                int start[QB], off[QB];
+#pragma unroll
+                for (int qi = 0; qi < QB; ++qi) {
+                    start[qi] = info.run_start[q0 + qi];
+                    off[qi] = info.run_off[q0 + qi];
+                }
+#pragma unroll
+                for (int qi = 0; qi < QB; ++qi) {
+                    const long long first = xbase + start[qi];
+#pragma unroll
+                    for (int i = 0; i < R; ++i) got[qi][i] = fetch(first + i * kBlock);
+                }
+#pragma unroll
+                for (int qi = 0; qi < QB; ++qi) {
+                    T *dst = xs + off[qi] + threadIdx.x;
+#pragma unroll
+                    for (int i = 0; i < R; ++i) dst[i * kBlock] = got[qi][i];
+                }
             }
+            if (static_cast<int>(threadIdx.x) < info.ntail)
+                xs[info.tail_off[threadIdx.x]] = fetch(r0 + x_shift + info.tail_dist[threadIdx.x]);
+            // every entry's place in LDS into scalar registers now: a scalar load between the LDS
+            // reads below would make each of them wait for the one before
+            unsigned packed[(CAP + 1) / 2];
 #pragma unroll
-            for (int i = 0; i < 8; ++i)
-                if (j + i < len) acc = acc + v[i] * xv[i];
+            for (int k = 0; k < (CAP + 1) / 2; ++k) packed[k] = info.lds_off_packed[k];
+            if (!GENERAL && LSK_SLICED_STAGE_FIRST) {
+                __builtin_amdgcn_sched_barrier(0); // (the value loads stay behind the staging, whose registers they take)
+                load_chunk(0);
+            }
+            __syncthreads();
+            // A wave whose rows all have the whole list adds without looking at masks.
+            const unsigned lenmask = maxlen >= 32 ? 0xffffffffu : (1u << maxlen) - 1u;
+            const bool plain = !masked && __all(all_live);
+            const T *lane_xs = xs + threadIdx.x * R;
+            auto entry = [&](int j, auto plain_tag) {
+                if (j < maxlen) { // (wave-uniform)
+                    const T *src = lane_xs + ((packed[j / 2] >> (16 * (j % 2))) & 0xffffu);
+                    T xv[R];
+#pragma unroll
+                    for (int h = 0; h < R; ++h) xv[h] = src[h];
+                    if constexpr (decltype(plain_tag)::value) {
+#pragma unroll
+                        for (int h = 0; h < R; ++h) acc[h] = acc[h] + v[j][h] * xv[h];
+                    } else {
+                        // (the empty asm pins the LDS reads here: left alone, the compiler moves each
+                        // one behind a branch on its row's mask bit, and the reads then wait one by one)
+#pragma unroll
+                        for (int h = 0; h < R; ++h) asm volatile("" : "+v"(xv[h]));
+#pragma unroll
+                        for (int h = 0; h < R; ++h) {
+                            const T sum = acc[h] + v[j][h] * xv[h];
+                            acc[h] = ((mask[h] & lenmask) >> j) & 1u ? sum : acc[h];
+                        }
+                    }
+                }
+            };
+            if (plain) {
+#pragma unroll
+                for (int c = 0; c < NCHUNKS; ++c) {
+                    if (c + 1 < NCHUNKS) load_chunk(c + 1);
+#pragma unroll
+                    for (int j = c * CHUNK; j < (c + 1) * CHUNK && j < CAP; ++j) entry(j, std::true_type{});
+                    __builtin_amdgcn_sched_barrier(0); // (no load of a later burst moves up past this one's use)
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < NCHUNKS; ++c) {
+                    if (c + 1 < NCHUNKS) load_chunk(c + 1);
+#pragma unroll
+                    for (int j = c * CHUNK; j < (c + 1) * CHUNK && j < CAP; ++j) entry(j, std::false_type{});
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        } else if constexpr (GENERAL) {
+            // a list with too many runs for the staging area: x straight from memory
+#pragma unroll
+            for (int c = 1; c < NCHUNKS; ++c) load_chunk(c);
+            const T *xp = x + (r + x_shift);
+#pragma unroll
+            for (int j = 0; j < CAP; ++j) {
+                if (j < maxlen) {
+                    const int d = info.dist[j];
+#pragma unroll
+                    for (int h = 0; h < R; ++h)
+                        if ((mask[h] >> j) & 1u) acc[h] = acc[h] + v[j][h] * xp[h + d];
+                }
+            }
+        }
+    } else if constexpr (GENERAL) {
+        // Rows whose patterns fit no common list: every row looks its own distances up and adds the
+        // entries it has (entry j at position j).
+#pragma unroll
+        for (int c = 1; c < NCHUNKS; ++c) load_chunk(c);
+#pragma unroll
+        for (int h = 0; h < R; ++h) {
+            if (!live[h]) continue;
+            const PatternInfo &mine = table[row_pattern[r + h]];
+            const int len = mine.len;
+            const T *xp = x + (r + h + x_shift);
+#pragma unroll
+            for (int j = 0; j < CAP; ++j)
+                if (j < len) acc[h] = acc[h] + v[j][h] * xp[mine.dist[j]];
         }
     }
-    if (live) y[r] = acc;
+
     if constexpr (DOT) {
-        const T share = lsk::wave_sum(live ? acc * w[r] : T(0));
-        if (lane == 0) wave_share[threadIdx.x / kWave] = share;
-        __syncthreads();
+        T share = T(0);
+        if (all_live && yw_aligned) {
+            const V wv = *reinterpret_cast<const V *>(w + r);
+#pragma unroll
+            for (int h = 0; h < R; ++h) share = share + acc[h] * wv[h];
+        } else {
+#pragma unroll
+            for (int h = 0; h < R; ++h)
+                if (live[h]) share = share + acc[h] * w[r + h];
+        }
+        share = lsk::wave_sum(share);
+        if (lane == 0) wave_share[wave] = share;
+    }
+    // (the barrier of the staged path, or this one, also gathers the block's stores: 4 KiB at a time)
+    __syncthreads();
+    if (all_live && yw_aligned) {
+        V out;
+#pragma unroll
+        for (int h = 0; h < R; ++h) out[h] = acc[h];
+        store16_nontemporal(y + r, out);
+    } else {
+#pragma unroll
+        for (int h = 0; h < R; ++h)
+            if (live[h]) y[r + h] = acc[h];
+    }
+    if constexpr (DOT) {
         if (threadIdx.x == 0) {
             T total = wave_share[0];
 #pragma unroll
-            for (int i = 1; i < kBlock / kWave; ++i) total = total + wave_share[i];
+            for (int i = 1; i < kWavesPerBlock; ++i) total = total + wave_share[i];
             partials[wg] = total;
         }
     }
 }
 
+// Runs of consecutive distances of a list, and where each entry's x value sits in the staging area
+// of a block of `block_rows` rows.  Returns false (nruns = 0) when the list needs more than
+// kMaxRuns runs or more than kMaxStageBytes.
+bool plan_staging(PatternInfo &p, int block_rows, size_t elem_bytes) {
+    p.nruns = 0;
+    p.lds_elems = 0;
+    if (p.len <= 0) return false;
+    int nruns = 0, off = 0;
+    int run_of[kMaxLength];
+    for (int j = 0; j < p.len; ++j) {
+        if (j > 0 && p.dist[j] == p.dist[j - 1] + 1) {
+            p.run_len[nruns - 1] += 1;
+        } else {
+            if (nruns == kMaxRuns) return false;
+            p.run_start[nruns] = p.dist[j];
+            p.run_len[nruns] = 1;
+            ++nruns;
+        }
+        run_of[j] = nruns - 1;
+    }
+    for (int q = 0; q < nruns; ++q) {
+        p.run_off[q] = off;
+        off += (block_rows + p.run_len[q] - 1 + 3) & ~3; // keep the windows 16-byte aligned
+    }
+    if (static_cast<size_t>(off) * elem_bytes > kMaxStageBytes) return false;
+    for (int j = 0; j < p.len; ++j) p.lds_off[j] = p.run_off[run_of[j]] + (p.dist[j] - p.run_start[run_of[j]]);
+    for (int k = 0; k < kMaxLength / 2; ++k)
+        p.lds_off_packed[k] = static_cast<unsigned>(p.lds_off[2 * k]) | (static_cast<unsigned>(p.lds_off[2 * k + 1]) << 16);
+    // unused run slots repeat the last run, so that the kernel can take them four at a time
+    for (int q = nruns; q < kMaxRuns; ++q) {
+        p.run_start[q] = p.run_start[nruns - 1];
+        p.run_len[q] = p.run_len[nruns - 1];
+        p.run_off[q] = p.run_off[nruns - 1];
+    }
+    p.ntail = 0;
+    for (int q = 0; q < nruns; ++q)
+        for (int e = 0; e + 1 < p.run_len[q]; ++e) {
+            p.tail_dist[p.ntail] = p.run_start[q] + block_rows + e;
+            p.tail_off[p.ntail] = p.run_off[q] + block_rows + e;
+            ++p.ntail;
+        }
+    p.nruns = nruns;
+    p.lds_elems = off;
+    return true;
+}
+
 template <typename T>
 int create(const char *name, int64_t rows, int64_t nnz, const int64_t *rects, int64_t k_base, const int64_t *col,
            const T *val, int64_t row_first, int64_t x_lo, int64_t x_hi, lsk_stream_t stream, lsk_csr_sliced **out) {
+    constexpr int R = Lane<T>::R;
+    constexpr int kBlockRows = kBlock * R;
     if (!out) return lsk::fail(LSK_ERR_ARG, "%s: null output", name);
     *out = nullptr;
     if (rows < 0 || nnz < 0) return lsk::fail(LSK_ERR_ARG, "%s: negative size", name);
     if (rows == 0 || nnz == 0 || x_hi < x_lo) return lsk::decline(LSK_ERR_UNSUPPORTED, "%s: empty piece", name);
     if (!rects || !col || !val) return lsk::fail(LSK_ERR_ARG, "%s: null pointer", name);
-    if (rows > (int64_t(1) << 31) * kBlock - kBlock) return lsk::decline(LSK_ERR_UNSUPPORTED, "%s: too many rows", name);
+    if (rows > (int64_t(1) << 31) * kBlock - kBlockRows) return lsk::decline(LSK_ERR_UNSUPPORTED, "%s: too many rows", name);
     hipStream_t s = lsk::as_stream(stream);
-    const int64_t slices = lsk::ceil_div(rows, kWave);
-    const unsigned row_blocks = static_cast<unsigned>(lsk::ceil_div(rows, kBlock));
+    const int64_t blocks = lsk::ceil_div(rows, kBlockRows);
+    const int64_t groups = lsk::ceil_div(rows, kWave);
+    const unsigned row_grid = static_cast<unsigned>(lsk::ceil_div(rows, kBlock));
+    const unsigned block_grid = static_cast<unsigned>(lsk::ceil_div(blocks, kBlock));
 
     lsk_csr_sliced *m = new (std::nothrow) lsk_csr_sliced;
     if (!m) return lsk::fail(LSK_ERR_ARG, "%s: out of host memory", name);
@@ -342,92 +671,125 @@ int create(const char *name, int64_t rows, int64_t nnz, const int64_t *rects, in
     m->row_first = row_first;
     m->x_lo = x_lo;
     m->x_hi = x_hi;
-    m->slices = slices;
+    m->blocks = blocks;
     unsigned long long *keys = nullptr;
-    long long *rep = nullptr, *slice_entries = nullptr, *inclusive = nullptr, *mixed = nullptr;
-    int *flags = nullptr;
+    long long *rep = nullptr, *entries = nullptr, *inclusive = nullptr, *counts = nullptr;
+    int *flags = nullptr, *lists = nullptr, *g_maxlen = nullptr, *g_holder = nullptr, *g_uniform = nullptr, *blk_flags = nullptr;
     void *temp = nullptr;
     int status = LSK_OK;
     int host_flags[kFlags] = {0};
     auto release_scratch = [&] {
-        (void)hipFree(keys);
-        (void)hipFree(rep);
-        (void)hipFree(slice_entries);
-        (void)hipFree(inclusive);
-        (void)hipFree(mixed);
-        (void)hipFree(flags);
-        (void)hipFree(temp);
+        for (void *p : {static_cast<void *>(keys), static_cast<void *>(rep), static_cast<void *>(entries),
+                        static_cast<void *>(inclusive), static_cast<void *>(counts), static_cast<void *>(flags),
+                        static_cast<void *>(lists), static_cast<void *>(g_maxlen), static_cast<void *>(g_holder),
+                        static_cast<void *>(g_uniform), static_cast<void *>(blk_flags), temp})
+            (void)hipFree(p);
     };
 #define LSK_TRY(expr)                                                                               \
     do {                                                                                            \
         const hipError_t e_ = (expr);                                                               \
         if (e_ != hipSuccess && status == LSK_OK) status = lsk::hip_fail(e_, #expr, __FILE__, __LINE__); \
     } while (0)
-    LSK_TRY(hipMalloc(reinterpret_cast<void **>(&keys), kMaxPatterns * sizeof(unsigned long long)));
-    LSK_TRY(hipMalloc(reinterpret_cast<void **>(&rep), kMaxPatterns * sizeof(long long)));
-    LSK_TRY(hipMalloc(reinterpret_cast<void **>(&flags), kFlags * sizeof(int)));
-    LSK_TRY(hipMalloc(reinterpret_cast<void **>(&mixed), 2 * sizeof(long long)));
-    LSK_TRY(hipMalloc(reinterpret_cast<void **>(&slice_entries), static_cast<size_t>(slices) * sizeof(long long)));
-    LSK_TRY(hipMalloc(reinterpret_cast<void **>(&inclusive), static_cast<size_t>(slices) * sizeof(long long)));
-    LSK_TRY(hipMalloc(reinterpret_cast<void **>(&m->row_pattern), static_cast<size_t>(rows)));
-    LSK_TRY(hipMalloc(reinterpret_cast<void **>(&m->row_mask), static_cast<size_t>(rows) * sizeof(unsigned)));
-    LSK_TRY(hipMalloc(reinterpret_cast<void **>(&m->table), kTableInts * sizeof(int)));
-    LSK_TRY(hipMalloc(&m->meta, static_cast<size_t>(slices) * sizeof(SliceMeta)));
+#define LSK_ALLOC(ptr, count) LSK_TRY(hipMalloc(reinterpret_cast<void **>(&(ptr)), static_cast<size_t>(count) * sizeof(*(ptr))))
+    LSK_ALLOC(keys, kMaxPatterns);
+    LSK_ALLOC(rep, kMaxPatterns);
+    LSK_ALLOC(flags, kFlags);
+    LSK_ALLOC(counts, 3);
+    LSK_ALLOC(lists, kMaxPatterns * (kMaxLength + 1));
+    LSK_ALLOC(entries, blocks);
+    LSK_ALLOC(inclusive, blocks);
+    LSK_ALLOC(blk_flags, blocks);
+    LSK_ALLOC(g_maxlen, groups);
+    LSK_ALLOC(g_holder, groups);
+    LSK_ALLOC(g_uniform, groups);
+    LSK_ALLOC(m->row_pattern, rows);
+    LSK_ALLOC(m->row_mask, rows);
+    LSK_ALLOC(m->table, kMaxPatterns);
+    LSK_TRY(hipMalloc(&m->meta, static_cast<size_t>(blocks) * sizeof(BlockMeta)));
+#undef LSK_ALLOC
+    const long long *rc = reinterpret_cast<const long long *>(rects);
+    const long long *cl = reinterpret_cast<const long long *>(col);
     bool declined = false;
     if (status == LSK_OK) {
-        sliced_init_kernel<<<1, kBlock, 0, s>>>(keys, flags, mixed, m->table);
+        sliced_init_kernel<<<1, kBlock, 0, s>>>(keys, flags, counts, lists);
         LSK_TRY(hipGetLastError());
-        const long long *rc = reinterpret_cast<const long long *>(rects);
-        const long long *cl = reinterpret_cast<const long long *>(col);
-        sliced_assign_kernel<<<row_blocks, kBlock, 0, s>>>(rows, nnz, rc, k_base, cl, row_first, keys, rep,
-                                                           m->row_pattern, flags);
+        sliced_assign_kernel<<<row_grid, kBlock, 0, s>>>(rows, nnz, rc, k_base, cl, row_first, keys, rep, m->row_pattern, flags);
         LSK_TRY(hipGetLastError());
         LSK_TRY(hipMemcpyAsync(host_flags, flags, sizeof(host_flags), hipMemcpyDeviceToHost, s));
         LSK_TRY(hipStreamSynchronize(s));
         declined = host_flags[kFlagTooManyPatterns] || host_flags[kFlagRowTooLong] || host_flags[kFlagBadRect];
     }
     if (status == LSK_OK && !declined) {
-        const long long *rc = reinterpret_cast<const long long *>(rects);
-        const long long *cl = reinterpret_cast<const long long *>(col);
-        sliced_table_kernel<<<1, kMaxPatterns, 0, s>>>(rc, k_base, cl, row_first, keys, rep, m->table, flags);
+        // the distance lists, and on the host their runs and places in the staging area
+        sliced_lists_kernel<<<1, kMaxPatterns, 0, s>>>(rc, k_base, cl, row_first, keys, rep, lists, flags);
         LSK_TRY(hipGetLastError());
-        sliced_verify_kernel<<<row_blocks, kBlock, 0, s>>>(rows, rc, k_base, cl, row_first, x_lo, x_hi, m->row_pattern,
-                                                           m->table, m->row_mask, slice_entries,
-                                                           static_cast<SliceMeta *>(m->meta), flags);
+        std::vector<int> host_lists(kMaxPatterns * (kMaxLength + 1));
+        LSK_TRY(hipMemcpyAsync(host_lists.data(), lists, host_lists.size() * sizeof(int), hipMemcpyDeviceToHost, s));
+        LSK_TRY(hipMemcpyAsync(host_flags, flags, sizeof(host_flags), hipMemcpyDeviceToHost, s));
+        LSK_TRY(hipStreamSynchronize(s));
+        declined = host_flags[kFlagOutsideWindow] != 0;
+        if (status == LSK_OK && !declined) {
+            std::vector<PatternInfo> infos(kMaxPatterns);
+            for (int p = 0; p < kMaxPatterns; ++p) {
+                PatternInfo &info = infos[p];
+                info = PatternInfo{};
+                const int *mine = host_lists.data() + p * (kMaxLength + 1);
+                info.len = mine[0];
+                for (int j = 0; j < kMaxLength; ++j) info.dist[j] = j < info.len ? mine[1 + j] : 0;
+                if (info.len >= 0) {
+                    m->patterns += 1;
+                    m->max_len = std::max(m->max_len, info.len);
+                    if (plan_staging(info, kBlockRows, sizeof(T)))
+                        m->lds_bytes = std::max(m->lds_bytes, static_cast<size_t>(info.lds_elems) * sizeof(T));
+                    else if (info.len > 0)
+                        m->all_staged = false;
+                }
+            }
+            LSK_TRY(hipMemcpyAsync(m->table, infos.data(), kMaxPatterns * sizeof(PatternInfo), hipMemcpyHostToDevice, s));
+            LSK_TRY(hipStreamSynchronize(s)); // (infos leaves scope)
+        }
+    }
+    if (status == LSK_OK && !declined) {
+        sliced_verify_kernel<<<row_grid, kBlock, 0, s>>>(rows, rc, k_base, cl, row_first, x_lo, x_hi, m->row_pattern, m->table,
+                                                         g_maxlen, g_holder, g_uniform, flags);
         LSK_TRY(hipGetLastError());
         LSK_TRY(hipMemcpyAsync(host_flags, flags, sizeof(host_flags), hipMemcpyDeviceToHost, s));
         LSK_TRY(hipStreamSynchronize(s));
         declined = host_flags[kFlagMismatch] || host_flags[kFlagOutsideWindow];
     }
     if (status == LSK_OK && !declined) {
+        BlockMeta *meta = static_cast<BlockMeta *>(m->meta);
+        sliced_combine_kernel<<<block_grid, kBlock, 0, s>>>(blocks, groups, kBlockRows / kWave, g_maxlen, g_holder, g_uniform,
+                                                            meta, blk_flags);
+        LSK_TRY(hipGetLastError());
+        sliced_masks_kernel<<<row_grid, kBlock, 0, s>>>(rows, kBlockRows, m->row_pattern, m->table, meta, blk_flags, m->row_mask);
+        LSK_TRY(hipGetLastError());
+        sliced_finish_kernel<<<block_grid, kBlock, 0, s>>>(blocks, rows, kBlockRows, blk_flags, meta, entries, counts);
+        LSK_TRY(hipGetLastError());
         size_t temp_bytes = 0;
-        LSK_TRY(hipcub::DeviceScan::InclusiveSum(nullptr, temp_bytes, slice_entries, inclusive, static_cast<int>(slices), s));
+        LSK_TRY(hipcub::DeviceScan::InclusiveSum(nullptr, temp_bytes, entries, inclusive, static_cast<int>(blocks), s));
         LSK_TRY(hipMalloc(&temp, temp_bytes ? temp_bytes : 1));
         if (status == LSK_OK)
-            LSK_TRY(hipcub::DeviceScan::InclusiveSum(temp, temp_bytes, slice_entries, inclusive, static_cast<int>(slices), s));
-        const unsigned slice_blocks = static_cast<unsigned>(lsk::ceil_div(slices, kBlock));
-        sliced_bases_kernel<<<slice_blocks, kBlock, 0, s>>>(slices, slice_entries, inclusive,
-                                                            static_cast<SliceMeta *>(m->meta), mixed);
+            LSK_TRY(hipcub::DeviceScan::InclusiveSum(temp, temp_bytes, entries, inclusive, static_cast<int>(blocks), s));
+        sliced_bases_kernel<<<block_grid, kBlock, 0, s>>>(blocks, entries, inclusive, meta);
         LSK_TRY(hipGetLastError());
-        long long total = 0, mixed_host[2] = {0, 0};
-        LSK_TRY(hipMemcpyAsync(&total, inclusive + (slices - 1), sizeof(total), hipMemcpyDeviceToHost, s));
-        LSK_TRY(hipMemcpyAsync(mixed_host, mixed, sizeof(mixed_host), hipMemcpyDeviceToHost, s));
+        long long total = 0, counts_host[3] = {0, 0, 0};
+        LSK_TRY(hipMemcpyAsync(&total, inclusive + (blocks - 1), sizeof(total), hipMemcpyDeviceToHost, s));
+        LSK_TRY(hipMemcpyAsync(counts_host, counts, sizeof(counts_host), hipMemcpyDeviceToHost, s));
         LSK_TRY(hipStreamSynchronize(s));
         m->padded_entries = total;
-        m->mixed_slices = mixed_host[0];
-        m->masked_slices = mixed_host[1];
-        int host_table[kMaxPatterns];
-        LSK_TRY(hipMemcpy(host_table, m->table, sizeof(host_table), hipMemcpyDeviceToHost));
-        for (int i = 0; i < kMaxPatterns; ++i) m->patterns += host_table[i] >= 0 ? 1 : 0;
-        // not worth it when the padding would cost more than the column array saves
-        if (status == LSK_OK && static_cast<double>(total) * sizeof(T) > static_cast<double>(nnz) * (sizeof(T) + 3.0))
+        m->mixed_blocks = counts_host[0];
+        m->masked_waves = counts_host[1];
+        // not worth it when padding short rows to their block's longest would cost more than the column
+        // array saves (the rows the last block lacks are left out: at most one block per piece)
+        if (status == LSK_OK && static_cast<double>(counts_host[2]) * sizeof(T) > static_cast<double>(nnz) * (sizeof(T) + 3.0))
             declined = true;
         if (status == LSK_OK && !declined) {
             LSK_TRY(hipMalloc(&m->val, static_cast<size_t>(std::max<long long>(total, 1)) * sizeof(T)));
             if (status == LSK_OK) {
-                sliced_fill_kernel<T><<<static_cast<unsigned>(lsk::ceil_div(slices * kWave, kBlock)), kBlock, 0, s>>>(
-                    rows, reinterpret_cast<const long long *>(rects), k_base, val,
-                    static_cast<const SliceMeta *>(m->meta), m->row_mask, static_cast<T *>(m->val));
+                const int64_t padded_rows = blocks * kBlockRows;
+                sliced_fill_kernel<T><<<static_cast<unsigned>(lsk::ceil_div(padded_rows, kBlock)), kBlock, 0, s>>>(
+                    rows, padded_rows, rc, k_base, val, meta, m->row_mask, static_cast<T *>(m->val));
                 LSK_TRY(hipGetLastError());
                 LSK_TRY(hipStreamSynchronize(s));
             }
@@ -448,9 +810,9 @@ int create(const char *name, int64_t rows, int64_t nnz, const int64_t *rects, in
     return LSK_OK;
 }
 
-// The values again, from the caller's array into the slices (pass 4 alone): for a caller that has
-// rewritten the entries of the matrix in place.  The structure (rects, columns) must be the one the
-// copy was made from; that is the caller's promise, only the sizes can be checked here.
+// The values again, from the caller's array into the blocks (the last set-up pass alone): for a caller
+// that has rewritten the entries of the matrix in place.  The structure (rects, columns) must be the
+// one the copy was made from; that is the caller's promise, only the sizes can be checked here.
 template <typename T>
 int update_values(const char *name, lsk_csr_sliced *m, int64_t rows, int64_t nnz, const int64_t *rects, int64_t k_base,
                   const T *val, lsk_stream_t stream) {
@@ -461,16 +823,26 @@ int update_values(const char *name, lsk_csr_sliced *m, int64_t rows, int64_t nnz
                          name, (long long)rows, (long long)nnz, (long long)k_base, (long long)m->rows, (long long)m->nnz,
                          (long long)m->k_base);
     if (!rects || !val) return lsk::fail(LSK_ERR_ARG, "%s: null pointer", name);
-    sliced_fill_kernel<T><<<static_cast<unsigned>(lsk::ceil_div(m->slices * kWave, kBlock)), kBlock, 0, lsk::as_stream(stream)>>>(
-        rows, reinterpret_cast<const long long *>(rects), k_base, val, static_cast<const SliceMeta *>(m->meta), m->row_mask,
-        static_cast<T *>(m->val));
+    const int64_t padded_rows = m->blocks * kBlock * Lane<T>::R;
+    sliced_fill_kernel<T><<<static_cast<unsigned>(lsk::ceil_div(padded_rows, kBlock)), kBlock, 0, lsk::as_stream(stream)>>>(
+        rows, padded_rows, reinterpret_cast<const long long *>(rects), k_base, val, static_cast<const BlockMeta *>(m->meta),
+        m->row_mask, static_cast<T *>(m->val));
     LSK_LAUNCH_CHECK();
     return LSK_OK;
+}
+
+// Partial sums the fused product + dot leaves for rows row_begin .. row_end - 1: one per block touched.
+template <typename T>
+int64_t dot_partials(int64_t row_begin, int64_t row_end) {
+    constexpr int64_t kBlockRows = int64_t(kBlock) * Lane<T>::R;
+    if (row_end <= row_begin) return 0;
+    return lsk::ceil_div(row_end, kBlockRows) - row_begin / kBlockRows;
 }
 
 template <typename T>
 int spmv(const char *name, const lsk_csr_sliced *m, int64_t row_begin, int64_t row_end, const T *x, T *y, int beta,
          const T *w, T *partials, int64_t capacity, int64_t *count, lsk_stream_t stream) {
+    constexpr int64_t kBlockRows = int64_t(kBlock) * Lane<T>::R;
     const bool dot = count != nullptr;
     if (dot) *count = 0;
     if (!m) return lsk::fail(LSK_ERR_ARG, "%s: null structure", name);
@@ -481,21 +853,37 @@ int spmv(const char *name, const lsk_csr_sliced *m, int64_t row_begin, int64_t r
     if (beta != 0 && beta != 1) return lsk::fail(LSK_ERR_ARG, "%s: beta must be 0 or 1", name);
     if (row_begin == row_end) return LSK_OK;
     if (!x || !y) return lsk::fail(LSK_ERR_ARG, "%s: null vector", name);
-    const int64_t slice_begin = row_begin / kWave;
-    const int64_t slice_count = lsk::ceil_div(row_end, kWave) - slice_begin;
-    const unsigned blocks = static_cast<unsigned>(lsk::ceil_div(slice_count, kBlock / kWave));
+    const int64_t block_begin = row_begin / kBlockRows;
+    const unsigned blocks = static_cast<unsigned>(dot_partials<T>(row_begin, row_end));
     if (dot) {
         if (!w || !partials) return lsk::fail(LSK_ERR_ARG, "%s: null w or partials", name);
         if (capacity < static_cast<int64_t>(blocks))
             return lsk::fail(LSK_ERR_ARG, "%s: room for %lld partial sums, %u needed", name, (long long)capacity, blocks);
     }
-#define LSK_SLICED_LAUNCH(DOT)                                                                                  \
-    sliced_spmv_kernel<T, 9, DOT><<<blocks, kBlock, 0, lsk::as_stream(stream)>>>(                                \
-        slice_begin, slice_count, row_begin, row_end, static_cast<const SliceMeta *>(m->meta),                   \
-        static_cast<const T *>(m->val), m->row_pattern, m->row_mask, m->table, x, m->row_first - m->x_lo, y, beta, \
-        lsk::xcd_remap_option(), w, partials)
-    if (dot) LSK_SLICED_LAUNCH(true);
-    else LSK_SLICED_LAUNCH(false);
+    const BlockMeta *meta = static_cast<const BlockMeta *>(m->meta);
+    const T *val = static_cast<const T *>(m->val);
+    const long long x_shift = m->row_first - m->x_lo, x_extent = m->x_hi - m->x_lo + 1;
+    const int remap = lsk::xcd_remap_option();
+    const int yw_aligned = lsk::aligned16(y) && (!dot || lsk::aligned16(w));
+    hipStream_t s = lsk::as_stream(stream);
+    const bool general = !m->all_staged || m->mixed_blocks > 0;
+#define LSK_SLICED_LAUNCH(CAP, DOT, GENERAL)                                                                      \
+    sliced_spmv_kernel<T, CAP, DOT, GENERAL><<<blocks, kBlock, m->lds_bytes, s>>>(                                \
+        block_begin, m->rows, row_begin, row_end, meta, val, m->row_pattern, m->row_mask, m->table, x, x_shift,   \
+        x_extent, y, beta, remap, w, partials, yw_aligned)
+#define LSK_SLICED_CAP(CAP)                                                                                       \
+    do {                                                                                                          \
+        if (dot && general) LSK_SLICED_LAUNCH(CAP, true, true);                                                   \
+        else if (dot) LSK_SLICED_LAUNCH(CAP, true, false);                                                        \
+        else if (general) LSK_SLICED_LAUNCH(CAP, false, true);                                                    \
+        else LSK_SLICED_LAUNCH(CAP, false, false);                                                                \
+    } while (0)
+    if (m->max_len <= 8) LSK_SLICED_CAP(8);
+    else if (m->max_len <= 16) LSK_SLICED_CAP(16);
+    else if (m->max_len <= 20) LSK_SLICED_CAP(20);
+    else if (m->max_len <= 27) LSK_SLICED_CAP(27);
+    else LSK_SLICED_CAP(32);
+#undef LSK_SLICED_CAP
 #undef LSK_SLICED_LAUNCH
     LSK_LAUNCH_CHECK();
     if (dot) *count = blocks;
@@ -602,13 +990,20 @@ int lsk_csr_sliced_spmv_dot_f64(const lsk_csr_sliced_t *m, int64_t row_begin, in
     return spmv<double>("lsk_csr_sliced_spmv_dot_f64", m, row_begin, row_end, x, y, beta, w, partials, capacity, count, stream);
 }
 
+int64_t lsk_csr_sliced_dot_partials(const lsk_csr_sliced_t *m, int64_t row_begin, int64_t row_end) {
+    if (!m) return 0;
+    return m->elem_bytes == 8 ? dot_partials<double>(row_begin, row_end) : dot_partials<float>(row_begin, row_end);
+}
+
 int lsk_csr_sliced_info(const lsk_csr_sliced_t *m, int64_t *out) {
     if (!m || !out) return lsk::fail(LSK_ERR_ARG, "lsk_csr_sliced_info: null pointer");
     out[0] = m->padded_entries;
-    out[1] = m->slices;
-    out[2] = m->mixed_slices;
+    out[1] = m->blocks;
+    out[2] = m->mixed_blocks;
     out[3] = m->patterns;
-    out[4] = m->masked_slices;
+    out[4] = m->masked_waves;
+    out[5] = int64_t(kBlock) * (16 / m->elem_bytes);
+    out[6] = static_cast<int64_t>(m->lds_bytes);
     return LSK_OK;
 }
 

@@ -134,34 +134,75 @@ class _SlicedCopies:
         self.sliced_window = None # ... for products against this window
         self.sliced_placement = {}
         self._sliced_refill = {}  # piece colour -> refill(copy): the piece's current values into that copy
+        self._sliced_make = None
+        self.setup_seconds = {}   # wall-clock seconds of the set-up stages run on this matrix
 
     def _refill_sliced_copies(self) -> None:
         """The sliced-pattern copies hold a copy of the entry values: bring them up to date."""
         for c, s in self.sliced.items():
             self._sliced_refill[c](s)
 
-    def _make_sliced_copies(self, make, x_lo: int, x_hi: int, kernel_partition, range_partition) -> bool:
-        """make(i, c): the copy of local piece i (colour c), None when the library declines."""
-        be = self.ctx.backend
-        made = {}
-        for i, c in enumerate(kernel_partition.colors):
-            k_lo, k_hi = kernel_partition.intervals[i]
-            if range_partition.pieces[c].volume == 0 or k_hi < k_lo:
-                continue
-            made[c] = make(i, c)
-            if made[c] is None:
+    def _stage(self, name: str):
+        """Context manager: wall-clock seconds of a set-up stage (device work included), added to
+        self.setup_seconds[name]."""
+        matrix = self
+
+        class _Timer:
+            def __enter__(self):
+                if matrix.val.is_cuda:
+                    torch.cuda.synchronize(matrix.val.device)
+                self.t0 = time.perf_counter()
+
+            def __exit__(self, *exc):
+                if matrix.val.is_cuda:
+                    torch.cuda.synchronize(matrix.val.device)
+                matrix.setup_seconds[name] = matrix.setup_seconds.get(name, 0.0) + time.perf_counter() - self.t0
                 return False
+
+        return _Timer()
+
+    def _make_sliced_copies(self, make, x_lo: int, x_hi: int, kernel_partition, range_partition) -> bool:
+        """make(i, c): the copy of local piece i (colour c), None when the library declines.  The
+        copies are made for all pieces or none; unless LSK_TUNE=0, their placement is then chosen by
+        timing and they are re-made a few times (tune_sliced_copies)."""
+        made = {}
+        with self._stage("sliced_copy"):
+            for i, c in enumerate(kernel_partition.colors):
+                k_lo, k_hi = kernel_partition.intervals[i]
+                if range_partition.pieces[c].volume == 0 or k_hi < k_lo:
+                    continue
+                made[c] = make(i, c)
+                if made[c] is None:
+                    return False
         if not made:
             return False
         self.sliced, self.sliced_window = made, (int(x_lo), int(x_hi))
-        if os.environ.get("LSK_TUNE", "1") == "0" or not self.val.is_cuda:
-            return True
+        self._sliced_make = (make, kernel_partition, range_partition)
+        if os.environ.get("LSK_TUNE", "1") != "0":
+            self.tune_sliced_copies()
+        return True
+
+    def tune_sliced_copies(self, redraws: int = None) -> None:
+        """Set-up-time speed tuning of the sliced-pattern copies of large pieces (TUNE_MIN_ROWS rows
+        or more), none of which changes a result: (1) the workgroup -> XCD placement is chosen by
+        timing a few candidates; (2) the copy is made up to `redraws` more times (LSK_TUNE_REDRAWS,
+        default SLICED_REDRAWS) while the previous one is still held, and the fastest is kept: where
+        the driver puts an array in HBM moves the product's time by several per cent, the draw cannot
+        be steered but it can be repeated (needs room for a second copy); (3) a wait until the
+        driver's scrubbing of what the redraws freed no longer slows the product.  The planner runs it
+        when it registers a matrix (unless LSK_TUNE=0); seconds per stage in self.setup_seconds."""
+        if not self.sliced or not self.val.is_cuda or getattr(self, "_sliced_make", None) is None:
+            return
+        make, kernel_partition, range_partition = self._sliced_make
+        x_lo, x_hi = self.sliced_window
+        be = self.ctx.backend
         x = y = last = None
         freed_total = 0
-        redraws = int(os.environ.get("LSK_TUNE_REDRAWS", self.SLICED_REDRAWS))
+        if redraws is None:
+            redraws = int(os.environ.get("LSK_TUNE_REDRAWS", self.SLICED_REDRAWS))
         for i, c in enumerate(kernel_partition.colors):
             rows = range_partition.pieces[c].volume
-            if c not in made or rows < self.TUNE_MIN_ROWS:
+            if c not in self.sliced or rows < self.TUNE_MIN_ROWS:
                 continue
             if x is None:
                 x = torch.zeros(x_hi - x_lo + 1, dtype=self.dtype, device=self.val.device)
@@ -171,27 +212,29 @@ class _SlicedCopies:
             def best_of(s):
                 return be.csr_sliced_tune(s, x, y)
 
-            self.sliced_placement[c], best = best_of(self.sliced[c])
+            with self._stage("placement_tuner"):
+                self.sliced_placement[c], best = best_of(self.sliced[c])
             freed = 0
-            for _ in range(redraws):
-                try:
-                    other = make(i, c)  # a second copy while the first is alive: another place in HBM
-                except RuntimeError:    # no room for it
-                    break
-                if other is None:
-                    break
-                pl, t = best_of(other)
-                freed += other.padded_entries * self.val.element_size()
-                if t < best:
-                    self.sliced[c].close()
-                    self.sliced[c], self.sliced_placement[c], best = other, pl, t
-                else:
-                    other.close()
+            with self._stage("placement_redraws"):
+                for _ in range(redraws):
+                    try:
+                        other = make(i, c)  # a second copy while the first is alive: another place in HBM
+                    except RuntimeError:    # no room for it
+                        break
+                    if other is None:
+                        break
+                    pl, t = best_of(other)
+                    freed += other.padded_entries * self.val.element_size()
+                    if t < best:
+                        self.sliced[c].close()
+                        self.sliced[c], self.sliced_placement[c], best = other, pl, t
+                    else:
+                        other.close()
             freed_total += freed
             last = (c, rows, best)
         if freed_total >= (1 << 30):  # (smaller amounts are scrubbed before anyone could notice)
-            self._wait_until_steady(last[0], last[1], x, y, last[2], freed_total)
-        return True
+            with self._stage("steadiness_wait"):
+                self._wait_until_steady(last[0], last[1], x, y, last[2], freed_total)
 
     SETTLE_SECONDS = 12.0
 
@@ -309,26 +352,27 @@ class CSRMatrix(AbstractMatrix, _SlicedCopies):
                 or self.nnz == 0 or x_hi - x_lo + 1 > be.COMPRESS_MAX_EXTENT):
             return False
         rowoff = {}
-        for i, c in enumerate(kernel_partition.colors):
-            p = range_partition.pieces[c]
-            k_lo, k_hi = kernel_partition.intervals[i]
-            nnz = max(k_hi - k_lo + 1, 0)
-            if p.volume == 0:
-                continue
-            r0 = p.lo[0] - self.row_lo
-            off = rows_of(self.rects[r0:r0 + p.volume], k_lo if nnz else self.k_base, nnz)
-            if off is None:
-                return False
-            rowoff[c] = off
-        self.rowoff = rowoff
-        self.col32 = cols(self.col, x_lo, x_hi)
-        self.col32_window = (int(x_lo), int(x_hi))
+        with self._stage("compress_32bit"):
+            for i, c in enumerate(kernel_partition.colors):
+                p = range_partition.pieces[c]
+                k_lo, k_hi = kernel_partition.intervals[i]
+                nnz = max(k_hi - k_lo + 1, 0)
+                if p.volume == 0:
+                    continue
+                r0 = p.lo[0] - self.row_lo
+                off = rows_of(self.rects[r0:r0 + p.volume], k_lo if nnz else self.k_base, nnz)
+                if off is None:
+                    return False
+                rowoff[c] = off
+            self.rowoff = rowoff
+            self.col32 = cols(self.col, x_lo, x_hi)
+            self.col32_window = (int(x_lo), int(x_hi))
         return True
 
     def slice_structure(self, x_lo: int, x_hi: int, kernel_partition, range_partition) -> bool:
         """Set-up-time re-layout for matrices whose rows repeat a few column patterns (every
-        linearised stencil): per piece a copy of the values in slices of 64 rows plus one pattern id
-        per row; products against the window x_lo..x_hi then read no column array and no row
+        linearised stencil): per piece a copy of the values in blocks of 512 (fp64) / 1024 (fp32) rows
+        plus one pattern id per row; products against the window x_lo..x_hi then read no column array and no row
         structure, and sum every row in entry order with separate multiply and add -- bit for bit
         the loop of src/CSRMatrixTasks.cpp:73-91.  All pieces or none.  LSK_SLICED=0 turns it off.
         For large pieces the tile placement is then chosen by timing, and the copy is made up to
@@ -373,7 +417,11 @@ class CSRMatrix(AbstractMatrix, _SlicedCopies):
         x = torch.zeros(x_hi - x_lo + 1, dtype=self.dtype, device=self.val.device)
         y = torch.empty(max(range_partition.pieces[kernel_partition.colors[i]].volume for i in big),
                         dtype=self.dtype, device=self.val.device)
-        self._redraw_arrays(x, x_lo, x_hi, y, kernel_partition, range_partition, big)
+        with self._stage("placement_redraws"):
+            self._redraw_arrays(x, x_lo, x_hi, y, kernel_partition, range_partition, big)
+        self._tune_placement(tuner, x, x_lo, x_hi, y, kernel_partition, range_partition, big)
+
+    def _tune_placement(self, tuner, x, x_lo, x_hi, y, kernel_partition, range_partition, big) -> None:
         for i, c in enumerate(kernel_partition.colors):
             p = range_partition.pieces[c]
             k_lo, k_hi = kernel_partition.intervals[i]
@@ -546,7 +594,8 @@ class CSRMatrix(AbstractMatrix, _SlicedCopies):
             nnz = max(k_hi - k_lo + 1, 0)
             if split is not None and i in split:
                 if fused:  # every run's shares side by side in one buffer, whichever phase launches it
-                    slots = [be.csr_sliced_dot_slots(rb, ra) for _, ra, rb, _, _ in split[i]]
+                    slots = ([be.csr_sliced_dot_slots(sliced[c], rb, ra) for _, ra, rb, _, _ in split[i]] if c in sliced
+                             else [0] * len(split[i]))
                     buf = dst._partials("mv", i, sum(slots))
                     if last_phase:
                         pieces.append((buf, sum(slots)))
@@ -574,7 +623,7 @@ class CSRMatrix(AbstractMatrix, _SlicedCopies):
             if split is not None and phase == 0:
                 continue  # a piece without a split entry (no entries) goes with the late phase
             if c in sliced and fused:
-                buf = dst._partials("mv", i, be.csr_sliced_dot_slots(rows))
+                buf = dst._partials("mv", i, be.csr_sliced_dot_slots(sliced[c], rows))
                 pieces.append((buf, be.csr_sliced_spmv_dot(sliced[c], rows, x, dst._piece(i), beta, dot_with._piece(i),
                                                            buf, self.sliced_placement.get(c, 0))))
                 continue

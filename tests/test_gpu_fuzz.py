@@ -158,13 +158,20 @@ def test_spmv_random_structures(gpu_ctx, suf, kind):
 def test_sliced_pattern_products_fuzz(seed, suf):
     """Random matrices made of a few row patterns (lists of column distances with repeats, in any
     order, some of them ordered parts of others, some unrelated, some empty), laid out in runs of
-    random length so that slices of 64 rows come out uniform, masked and mixed: the sliced-pattern
-    product equals the oracle's ascending-k loop bit for bit, whole and by ranges of rows."""
+    random length so that blocks come out uniform, masked and mixed: the sliced-pattern product equals
+    the oracle's ascending-k loop bit for bit, whole and by ranges of rows.  Odd seeds draw lists made
+    of a few runs of consecutive distances (served through the LDS staging area), even seeds arbitrary
+    ones (mostly too many runs for it: x straight from memory)."""
     npdt, tdt, _ = DT[suf]
     rng = np.random.default_rng(1000 + seed)
-    rows = int(rng.integers(65, 3000))
+    rows = int(rng.integers(65, 6000))
     n_patterns = int(rng.integers(1, 9))
-    base = rng.integers(-40, 41, size=int(rng.integers(8, 33)))      # one long list ...
+    if seed % 2:
+        nr = int(rng.integers(1, 6))
+        base = np.concatenate([int(s0) + np.arange(int(ln)) for s0, ln in
+                               zip(rng.integers(-40, 36, size=nr), rng.integers(1, 7, size=nr))])[:32]
+    else:
+        base = rng.integers(-40, 41, size=int(rng.integers(8, 33)))      # one long list ...
     patterns = [base]
     for _ in range(n_patterns - 1):
         kind = rng.integers(0, 8)
@@ -196,17 +203,21 @@ def test_sliced_pattern_products_fuzz(seed, suf):
     code = getattr(_lib.lib(), f"lsk_csr_sliced_create_{suf}")(rows, nnz, P(rd), k_base, P(cd), P(vd), row_first, x_lo,
                                                              x_hi, stream(), ctypes.byref(handle))
     if code == _lib.LSK_ERR_UNSUPPORTED:   # too much padding for this draw: a legitimate answer
-        padded = sum(64 * int(lens[s:s + 64].max()) for s in range(0, rows, 64))
+        br = 512 if suf == "f64" else 1024
+        padded = sum(int(lens[s:s + br].size) * int(lens[s:s + br].max()) for s in range(0, rows, br))
         assert padded * np.dtype(npdt).itemsize > nnz * (np.dtype(npdt).itemsize + 3)
         return
     assert code == _lib.LSK_OK, _lib.lib().lsk_last_error().decode()
     try:
-        info = (ctypes.c_int64 * 5)()
+        info = (ctypes.c_int64 * 7)()
         _lib.call("lsk_csr_sliced_info", handle, info)
-        assert info[3] <= len(patterns) and info[2] + info[4] <= info[1]
-        print(f"  slices {info[1]}: {info[2]} mixed, {info[4]} masked; {info[3]} patterns", flush=True)
+        assert info[3] <= len(patterns) and info[2] <= info[1] and info[4] <= 4 * (info[1] - info[2])
+        print(f"  blocks {info[1]}: {info[2]} mixed, {info[4]} masked waves; {info[3]} patterns, "
+              f"{info[6]} bytes of LDS", flush=True)
         y0 = rng.standard_normal(rows).astype(npdt)
-        for beta, (ra, rb) in ((0, (0, rows)), (1, (0, rows)), (1, (rows // 4, rows - rows // 3)), (0, (63, 130))):
+        for beta, (ra, rb) in ((0, (0, rows)), (1, (0, rows)), (1, (rows // 4, rows - rows // 3)), (0, (63, 130)),
+                               (0, (509, 1030)), (1, (1023, 1025))):
+            ra = min(ra, rows)
             rb = min(rb, rows)
             want = y0.copy()
             part = want[ra:rb].copy()

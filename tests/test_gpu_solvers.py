@@ -154,14 +154,15 @@ def test_spmv_properties_at_headline_size(gpu_ctx, monkeypatch, n1):
     assert Az.dot(Az).get_value() ** 0.5 <= 1e-12 * (4 * Ax.dot(Ax).get_value() + 9 * Ay.dot(Ay).get_value()) ** 0.5
     # the two set-up-time layouts the planner puts this matrix in, against the product above (which
     # read the int64 arrays): the 32-bit structure bit for bit, the sliced-pattern copy (27 patterns,
-    # a quarter of the slices masked, rows summed in entry order) to rounding
+    # the two end rows of every grid line masked, rows summed in entry order) to rounding
     del Az, Ay, z, y
     monkeypatch.setenv("LSK_TUNE_REDRAWS", "0")
     assert A.compress(0, n - 1, kp, ip)
     assert torch.equal(matvec(x).owned, Ax.owned)
     assert A.slice_structure(0, n - 1, kp, ip)
     s = A.sliced[0]
-    assert (s.patterns, s.mixed_slices, s.masked_slices * 4) == (27, 0, s.slices) and s.slices * 64 == n
+    # a block is one grid line (512 rows): its first and its last wave hold a line end each
+    assert (s.patterns, s.mixed_blocks, s.masked_waves) == (27, 0, 2 * s.blocks) and s.blocks * s.block_rows == n
     # padding: the two end rows of every grid line have 2/3 of the line's row length (27, 18 or 12)
     assert s.padded_entries == A.nnz + 2 * (9 * (n1 - 2) ** 2 + 6 * 4 * (n1 - 2) + 4 * 4)
     diff = float((matvec(x).owned - Ax.owned).abs().max())

@@ -50,7 +50,7 @@ ctx.synchronize()
 print(f"tile placement {A.placement} sliced {A.sliced_placement}")
 if A.sliced:
     s = A.sliced[0]
-    print(f"sliced_algorithmic_bytes={s.padded_entries * 8 + rows * 16 + s.slices * 16 + s.masked_slices * 256 + s.mixed_slices * 64}")
+    print(f"sliced_algorithmic_bytes={s.algorithmic_bytes(rows, 8)}")
 print(f"rows={rows} nnz={A.nnz} spmv_algorithmic_bytes={A.nnz * 16 + rows * 32} "
       f"spmv_c32_algorithmic_bytes={A.nnz * 12 + rows * 20} "
       f"dot_bytes={rows * 16} axpy_read_bytes={rows * 16} axpy_write_bytes={rows * 8}")

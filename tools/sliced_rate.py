@@ -43,10 +43,9 @@ def main():
     if matrix.sliced:
         s = matrix.sliced[0]
         out["sliced_ms"] = round(timed(ctx, lambda: planner.matvec(3, 2), 20), 3)
-        out["sliced_bytes"] = (s.padded_entries * esz + matrix.rows * 2 * esz + s.slices * 16 + s.mixed_slices * 64
-                               + s.masked_slices * 256)
+        out["sliced_bytes"] = s.algorithmic_bytes(matrix.rows, esz)
         out["sliced_TBps"] = round(out["sliced_bytes"] / out["sliced_ms"] / 1e9, 3)
-        out.update(patterns=s.patterns, mixed_slices=s.mixed_slices, masked_slices=s.masked_slices, slices=s.slices, padded_entries=s.padded_entries,
+        out.update(patterns=s.patterns, mixed_blocks=s.mixed_blocks, masked_waves=s.masked_waves, blocks=s.blocks, padded_entries=s.padded_entries,
                    placement=matrix.sliced_placement)
         a = planner.get_vector(3, 0).owned.clone()
         held, matrix.sliced_window = matrix.sliced_window, None
