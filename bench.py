@@ -278,7 +278,8 @@ def main():
     seconds2 = bs.timed_steps(ctx, solver2, 2, max(args.steps // 5, 2))
     two_system = max(args.steps // 5, 2) / seconds2
     del solver2, planner2
-    host_ms = host_ms_per_step(ctx, world)
+    # (LSK_BENCH_HOST_COST=0 leaves it out: a profile of this run then holds launches of one problem size only)
+    host_ms = host_ms_per_step(ctx, world) if os.environ.get("LSK_BENCH_HOST_COST", "1") != "0" else None
 
     line = {
         "metric": f"CG iters/sec (fp64) on 3D 27-pt stencil {n1}^3, single system (the reference's BenchmarkStencil "

@@ -54,6 +54,7 @@ template <typename T> struct Abi;
         static constexpr auto csr_sliced_spmv = lsk_csr_sliced_spmv_##SUF;                         \
         static constexpr auto csr_sliced_spmv_dot = lsk_csr_sliced_spmv_dot_##SUF;                 \
         static constexpr auto csr_sliced_tune = lsk_csr_sliced_tune_##SUF;                         \
+        static constexpr auto csr_sliced_update_values = lsk_csr_sliced_update_values_##SUF;       \
         static constexpr auto stencil_fill_csr = lsk_stencil_fill_csr_##SUF;                       \
         static constexpr auto stencil_fill_coo = lsk_stencil_fill_coo_##SUF;                       \
     }
@@ -569,6 +570,21 @@ public:
         transposed_->apply(dst.data(), src.data(), beta);
     }
     int transposed_runs() const { return transposed_ ? transposed_->runs() : 0; }
+    // The entries, for a caller that rewrites them in place (same structure, new values) ...
+    T *values() { return val_.get(); }
+    // ... and then says so, before the next product: the set-up-time copies of the values (the
+    // sliced-pattern copies, the transpose behind rmatvec) are brought up to date.  The reference's
+    // task reads the region on every call (src/CSRMatrixTasks.cu:88-118).
+    void values_changed() {
+        for (int c = 0; c < static_cast<int>(sliced_.size()); ++c) {
+            if (!sliced_[c].handle) continue;
+            const Piece &p = pieces_[c];
+            check(Abi<T>::csr_sliced_update_values(sliced_[c].handle, range_.volume(c), p.nnz,
+                                                   rects_.get() + 2 * range_.piece[c].first, p.k_lo, val_.get() + p.k_lo,
+                                                   ctx_->stream()));
+        }
+        transposed_.reset();
+    }
     int64_t transpose_chunk = Transposed<T>::kChunk; // entries per run of the transposition (tests lower it)
 
 private:

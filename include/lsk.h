@@ -61,7 +61,8 @@ void lsk_set_abort_on_error(int enable);
  * from another thread), "csr.log_rows_per_wave" (-1 = from
  * the mean row length, else 0..8), "csr.max_units" (16-byte units per lane the wave-tile form
  * keeps in flight: 0 = chosen from the mean tile size, 4 or 8), "blas1.form" (0 grid-strided | 1 contiguous chunk per
- * workgroup, default 1), "coo.variant" (0 workgroup chunks through LDS | 1 wave-wide segmented
+ * workgroup, default 1), "blas1.nontemporal" (whether the BLAS-1 streams go past the caches: 1 | 0 |
+ * -1 = for vectors of 256 MiB and more, the default), "coo.variant" (0 workgroup chunks through LDS | 1 wave-wide segmented
  * scan, default 1), "comm.skip_single_rank" (1, the default: lsk_allreduce_sum_* / lsk_allgather_* on a
  * one-rank communicator answer without calling RCCL | 0: they enqueue the RCCL collective all the
  * same).  No counterpart in the reference

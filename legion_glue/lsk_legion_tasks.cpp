@@ -15,6 +15,7 @@
 // 123-145).
 #include <cstdlib>
 #include <map>
+#include <mutex>
 #include <utility>
 
 #include <legion.h>
@@ -60,6 +61,7 @@ template <> struct Abi<float> {
     static constexpr auto csr_spmv = lsk_csr_spmv_f32;
     static constexpr auto csr_spmv_c32 = lsk_csr_spmv_c32_f32;
     static constexpr auto csr_sliced_create = lsk_csr_sliced_create_f32;
+    static constexpr auto csr_sliced_update_values = lsk_csr_sliced_update_values_f32;
     static constexpr auto csr_sliced_spmv = lsk_csr_sliced_spmv_f32;
     static constexpr auto coo_spmv = lsk_coo_spmv_f32;
 };
@@ -72,14 +74,19 @@ template <> struct Abi<double> {
     static constexpr auto csr_spmv = lsk_csr_spmv_f64;
     static constexpr auto csr_spmv_c32 = lsk_csr_spmv_c32_f64;
     static constexpr auto csr_sliced_create = lsk_csr_sliced_create_f64;
+    static constexpr auto csr_sliced_update_values = lsk_csr_sliced_update_values_f64;
     static constexpr auto csr_sliced_spmv = lsk_csr_sliced_spmv_f64;
     static constexpr auto coo_spmv = lsk_coo_spmv_f64;
 };
 
 // Set-up-time 32-bit copy of a CSR piece's structure, made on the first product of a piece and
 // reused by every later one: the once-only form of what the reference redoes per call
-// (src/CuSPARSEHelpers.hpp:9-31,71-80).  One table per GPU processor, like CUDALibraryContext
-// (src/CUDAUtilities.cpp:125-130); a GPU processor runs one task at a time, so no lock.
+// (src/CuSPARSEHelpers.hpp:9-31,71-80).  Entries are keyed by GPU processor, like CUDALibraryContext
+// (src/CUDAUtilities.cpp:125-130); the tables themselves are shared by the processors' threads, so
+// every look-up and insertion holds table_mutex (a std::map may rebalance under an insertion).  The
+// copy holds STRUCTURE only (row offsets, columns): the entry values are read from the region on
+// every call, as the reference does (src/CSRMatrixTasks.cu:88-118).
+std::mutex table_mutex;
 struct Structure32 {
     const void *rects = nullptr;
     int64_t rows = 0, nnz = 0, x_lo = 0, x_hi = -1;
@@ -91,6 +98,7 @@ const Structure32 &structure32(const int64_t *rects, int64_t rows, int64_t k_bas
                                int64_t nnz, int64_t x_lo, int64_t x_hi, lsk_stream_t stream) {
     const auto key = std::make_pair(Legion::Processor::get_executing_processor().id,
                                     static_cast<const void *>(col));
+    std::lock_guard<std::mutex> lock(table_mutex);
     Structure32 &s = structure_table[key];
     if (s.rects == rects && s.rows == rows && s.nnz == nnz && s.x_lo == x_lo && s.x_hi == x_hi) return s;
     if (s.rowoff) check(lsk_free(s.rowoff));
@@ -115,14 +123,20 @@ const Structure32 &structure32(const int64_t *rects, int64_t rows, int64_t k_bas
     return s;
 }
 
-// The sliced-pattern copy of a CSR piece (values in slices of 64 rows, no column array; made for
-// matrices whose rows repeat a few column patterns, i.e. every stencil), tried first and cached the
-// same way.  It holds a COPY of the entry values: an application that rewrites a matrix's entries in
-// place sets LSK_SLICED=0 (or drops the table entry) so that products keep reading the region.
+// The sliced-pattern copy of a CSR piece (values in blocks of 512 / 1024 rows, no column array; made
+// for matrices whose rows repeat a few column patterns, i.e. every stencil; 1.9 x the rate of the
+// 32-bit structure on the 27-point matrix).  It holds a COPY of the entry values, which the reference's
+// task does not: OPT-IN, for applications that promise to say when they rewrite a matrix's entries.
+//   LSK_SLICED=1 in the environment switches it on; without it every product reads live values
+//   through the 32-bit structure above.
+//   lsk_legion_matrix_values_changed(col_ptr) is the hook: call it (from any thread) after rewriting
+//   the entries of the matrix whose column field instance starts at col_ptr; the next product of every
+//   GPU processor then refills its copy from the region (lsk_csr_sliced_update_values_*: one pass over
+//   the values) before it multiplies.
 struct Sliced {
     const void *rects = nullptr, *val = nullptr;
     int64_t rows = 0, nnz = 0, x_lo = 0, x_hi = -1;
-    bool tried = false;
+    bool tried = false, stale = false;
     lsk_csr_sliced_t *handle = nullptr; // null after a refusal
 };
 std::map<std::pair<unsigned long long, const void *>, Sliced> sliced_table;
@@ -131,18 +145,35 @@ template <typename T>
 const lsk_csr_sliced_t *sliced_structure(const int64_t *rects, int64_t rows, int64_t k_base, const int64_t *col,
                                          const T *val, int64_t nnz, int64_t row_first, int64_t x_lo, int64_t x_hi,
                                          lsk_stream_t stream) {
-    static const bool off = std::getenv("LSK_SLICED") && std::getenv("LSK_SLICED")[0] == '0';
-    if (off) return nullptr;
+    static const bool on = std::getenv("LSK_SLICED") && std::getenv("LSK_SLICED")[0] == '1';
+    if (!on) return nullptr;
     const auto key = std::make_pair(Legion::Processor::get_executing_processor().id, static_cast<const void *>(col));
+    std::lock_guard<std::mutex> lock(table_mutex);
     Sliced &s = sliced_table[key];
-    if (s.tried && s.rects == rects && s.val == val && s.rows == rows && s.nnz == nnz && s.x_lo == x_lo && s.x_hi == x_hi)
+    if (s.tried && s.rects == rects && s.val == val && s.rows == rows && s.nnz == nnz && s.x_lo == x_lo && s.x_hi == x_hi) {
+        if (s.handle && s.stale) {
+            check(Abi<T>::csr_sliced_update_values(s.handle, rows, nnz, rects, k_base, val, stream));
+            s.stale = false;
+        }
         return s.handle;
+    }
     if (s.handle) check(lsk_csr_sliced_destroy(s.handle));
-    s = Sliced{rects, val, rows, nnz, x_lo, x_hi, true, nullptr};
+    s = Sliced{rects, val, rows, nnz, x_lo, x_hi, true, false, nullptr};
     const int rc = Abi<T>::csr_sliced_create(rows, nnz, rects, k_base, col, val, row_first, x_lo, x_hi, stream, &s.handle);
     if (rc != LSK_OK && rc != LSK_ERR_UNSUPPORTED) check(rc);
     return s.handle;
 }
+
+} // namespace
+
+// See the note above sliced_table.
+void lsk_legion_matrix_values_changed(const void *col_ptr) {
+    std::lock_guard<std::mutex> lock(table_mutex);
+    for (auto &entry : sliced_table)
+        if (entry.first.second == col_ptr) entry.second.stale = true;
+}
+
+namespace {
 
 // One vector argument of a BLAS-1 task: base pointer of the dense piece and its volume.
 template <typename T, int DIM, typename COORD_T, typename ACC>

@@ -43,9 +43,25 @@ __device__ __forceinline__ T resolve_alpha(const Alpha<T> &a) {
     }
 }
 
+// 16-byte vectors as the compiler's own vector types (the nontemporal builtins take no others).
+typedef double double2v __attribute__((ext_vector_type(2)));
+typedef float float4v __attribute__((ext_vector_type(4)));
 template <typename T> struct Vec;
-template <> struct Vec<double> { using type = double2; static constexpr int N = 2; };
-template <> struct Vec<float> { using type = float4; static constexpr int N = 4; };
+template <> struct Vec<double> { using type = double2v; static constexpr int N = 2; };
+template <> struct Vec<float> { using type = float4v; static constexpr int N = 4; };
+
+// Loads and stores of the streams.  NT: nontemporal (streamed past the caches).  On vectors far
+// larger than the caches that is worth 7-10 % (fp64, 2^27 elements: dot 0.340 -> 0.305 ms, axpy 0.604
+// -> 0.542 ms, and only with BOTH the loads and the stores nontemporal); on vectors the Infinity Cache
+// can hold between two kernels (128 MB) the plain forms are as fast or faster.
+template <bool NT, typename E> __device__ __forceinline__ E ld(const E *p) {
+    if constexpr (NT) return __builtin_nontemporal_load(p);
+    else return *p;
+}
+template <bool NT, typename E> __device__ __forceinline__ void st(E *p, E v) {
+    if constexpr (NT) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
 
 __device__ __forceinline__ double fma_t(double a, double b, double c) { return __builtin_fma(a, b, c); }
 __device__ __forceinline__ float fma_t(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
@@ -60,13 +76,13 @@ __device__ __forceinline__ T apply(T alpha, T x, T y) {
 }
 
 template <typename T, int OP>
-__device__ __forceinline__ double2 apply_v(T alpha, double2 x, double2 y) {
-    return double2{apply<double, OP>(alpha, x.x, y.x), apply<double, OP>(alpha, x.y, y.y)};
+__device__ __forceinline__ double2v apply_v(T alpha, double2v x, double2v y) {
+    return double2v{apply<double, OP>(alpha, x.x, y.x), apply<double, OP>(alpha, x.y, y.y)};
 }
 template <typename T, int OP>
-__device__ __forceinline__ float4 apply_v(T alpha, float4 x, float4 y) {
-    return float4{apply<float, OP>(alpha, x.x, y.x), apply<float, OP>(alpha, x.y, y.y),
-                  apply<float, OP>(alpha, x.z, y.z), apply<float, OP>(alpha, x.w, y.w)};
+__device__ __forceinline__ float4v apply_v(T alpha, float4v x, float4v y) {
+    return float4v{apply<float, OP>(alpha, x.x, y.x), apply<float, OP>(alpha, x.y, y.y),
+                   apply<float, OP>(alpha, x.z, y.z), apply<float, OP>(alpha, x.w, y.w)};
 }
 
 constexpr bool reads_x(int op) { return op == OP_AXPY || op == OP_XPAY || op == OP_COPY; }
@@ -74,7 +90,7 @@ constexpr bool reads_y(int op) { return op == OP_SCAL || op == OP_AXPY || op == 
 
 // E = element type of one access: the 16-byte vector when every pointer is 16-byte aligned,
 // else the scalar.  x and y are not declared restrict: y == x is a legal call.
-template <typename T, int OP, typename E, int EN>
+template <typename T, int OP, typename E, int EN, bool NT = false>
 __global__ __launch_bounds__(kBlock) void ew_kernel(int64_t n, Alpha<T> a, const T *x, T *y, int form) {
     const T alpha = resolve_alpha(a);
     const int64_t ne = n / EN;
@@ -93,13 +109,13 @@ __global__ __launch_bounds__(kBlock) void ew_kernel(int64_t n, Alpha<T> a, const
         E xv[4], yv[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            if constexpr (reads_x(OP)) xv[u] = xe[i + u * inner]; else xv[u] = E{};
-            if constexpr (reads_y(OP)) yv[u] = ye[i + u * inner]; else yv[u] = E{};
+            if constexpr (reads_x(OP)) xv[u] = ld<NT>(xe + i + u * inner); else xv[u] = E{};
+            if constexpr (reads_y(OP)) yv[u] = ld<NT>(ye + i + u * inner); else yv[u] = E{};
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            if constexpr (EN == 1) ye[i + u * inner] = apply<T, OP>(alpha, xv[u], yv[u]);
-            else ye[i + u * inner] = apply_v<T, OP>(alpha, xv[u], yv[u]);
+            if constexpr (EN == 1) st<NT>(ye + i + u * inner, apply<T, OP>(alpha, xv[u], yv[u]));
+            else st<NT>(ye + i + u * inner, apply_v<T, OP>(alpha, xv[u], yv[u]));
         }
     }
 #pragma unroll
@@ -107,10 +123,10 @@ __global__ __launch_bounds__(kBlock) void ew_kernel(int64_t n, Alpha<T> a, const
         const int64_t j = i + u * inner;
         if (j < ne) {
             E xv{}, yv{};
-            if constexpr (reads_x(OP)) xv = xe[j];
-            if constexpr (reads_y(OP)) yv = ye[j];
-            if constexpr (EN == 1) ye[j] = apply<T, OP>(alpha, xv, yv);
-            else ye[j] = apply_v<T, OP>(alpha, xv, yv);
+            if constexpr (reads_x(OP)) xv = ld<NT>(xe + j);
+            if constexpr (reads_y(OP)) yv = ld<NT>(ye + j);
+            if constexpr (EN == 1) st<NT>(ye + j, apply<T, OP>(alpha, xv, yv));
+            else st<NT>(ye + j, apply_v<T, OP>(alpha, xv, yv));
         }
     }
     if (EN > 1 && first) { // the n % EN trailing elements
@@ -121,6 +137,14 @@ __global__ __launch_bounds__(kBlock) void ew_kernel(int64_t n, Alpha<T> a, const
             y[j] = apply<T, OP>(alpha, xs, ys);
         }
     }
+}
+
+// Whether a stream over n elements uses the nontemporal accesses: option "blas1.nontemporal" (1, 0,
+// or -1 = for vectors of 256 MiB and more, which no cache holds from one kernel to the next).
+inline bool stream_past_caches(int64_t n, size_t elem_bytes) {
+    const int opt = lsk::options().blas1_nontemporal;
+    if (opt >= 0) return opt != 0;
+    return static_cast<double>(n) * static_cast<double>(elem_bytes) >= 256.0 * 1024.0 * 1024.0;
 }
 
 inline int stream_grid(int64_t accesses) {
@@ -144,7 +168,9 @@ int launch_ew(const char *name, int64_t n, Alpha<T> a, const T *x, T *y, lsk_str
     const bool vec = lsk::aligned16(y) && (!reads_x(OP) || lsk::aligned16(x));
     hipStream_t s = lsk::as_stream(stream);
     const int form = lsk::options().blas1_form;
-    if (vec) {
+    if (vec && stream_past_caches(n, sizeof(T))) {
+        ew_kernel<T, OP, V, VN, true><<<stream_grid(n / VN + 1), kBlock, 0, s>>>(n, a, x, y, form);
+    } else if (vec) {
         ew_kernel<T, OP, V, VN><<<stream_grid(n / VN + 1), kBlock, 0, s>>>(n, a, x, y, form);
     } else {
         ew_kernel<T, OP, T, 1><<<stream_grid(n), kBlock, 0, s>>>(n, a, x, y, form);
@@ -188,11 +214,11 @@ __device__ __forceinline__ T block_sum(T v) {
     return total;
 }
 
-template <typename T> __device__ __forceinline__ T dot_v(double2 a, double2 b, T acc) {
+template <typename T> __device__ __forceinline__ T dot_v(double2v a, double2v b, T acc) {
     acc = fma_t(a.x, b.x, acc);
     return fma_t(a.y, b.y, acc);
 }
-template <typename T> __device__ __forceinline__ T dot_v(float4 a, float4 b, T acc) {
+template <typename T> __device__ __forceinline__ T dot_v(float4v a, float4v b, T acc) {
     acc = fma_t(a.x, b.x, acc);
     acc = fma_t(a.y, b.y, acc);
     acc = fma_t(a.z, b.z, acc);
@@ -201,7 +227,7 @@ template <typename T> __device__ __forceinline__ T dot_v(float4 a, float4 b, T a
 template <typename T> __device__ __forceinline__ T dot_v(T a, T b, T acc) { return fma_t(a, b, acc); }
 
 // SAME: w is v (dot(v,v), nrm2): the vector is read once.
-template <typename T, typename E, int EN, bool SAME>
+template <typename T, typename E, int EN, bool SAME, bool NT = false>
 __global__ __launch_bounds__(kBlock) void dot_kernel(int64_t n, const T *__restrict__ v,
                                                      const T *__restrict__ w,
                                                      T *__restrict__ out, int fin, int form) {
@@ -219,8 +245,8 @@ __global__ __launch_bounds__(kBlock) void dot_kernel(int64_t n, const T *__restr
         E a[4], b[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            a[u] = ve[i + u * inner];
-            if constexpr (!SAME) b[u] = we[i + u * inner];
+            a[u] = ld<NT>(ve + i + u * inner);
+            if constexpr (!SAME) b[u] = ld<NT>(we + i + u * inner);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) acc[u] = dot_v<T>(a[u], SAME ? a[u] : b[u], acc[u]);
@@ -229,9 +255,9 @@ __global__ __launch_bounds__(kBlock) void dot_kernel(int64_t n, const T *__restr
     for (int u = 0; u < 4; ++u) {
         const int64_t j = i + u * inner;
         if (j < ne) {
-            E a = ve[j];
+            E a = ld<NT>(ve + j);
             E b = a;
-            if constexpr (!SAME) b = we[j];
+            if constexpr (!SAME) b = ld<NT>(we + j);
             acc[u] = dot_v<T>(a, b, acc[u]);
         }
     }
@@ -288,7 +314,10 @@ int launch_dot(const char *name, int64_t n, const T *v, const T *w, T *result, v
             partials = static_cast<T *>(st->scratch);
         }
     }
-    if (vec) {
+    if (vec && stream_past_caches(n, sizeof(T))) {
+        if (same) dot_kernel<T, V, VN, true, true><<<blocks, kBlock, 0, s>>>(n, v, w, partials, fin, form);
+        else dot_kernel<T, V, VN, false, true><<<blocks, kBlock, 0, s>>>(n, v, w, partials, fin, form);
+    } else if (vec) {
         if (same) dot_kernel<T, V, VN, true><<<blocks, kBlock, 0, s>>>(n, v, w, partials, fin, form);
         else dot_kernel<T, V, VN, false><<<blocks, kBlock, 0, s>>>(n, v, w, partials, fin, form);
     } else {
@@ -311,7 +340,7 @@ int launch_dot(const char *name, int64_t n, const T *v, const T *w, T *result, v
 // sum_partials when (and if) the caller wants the norm.
 // OTHER: out[block] <- share of sum(y_new * w) for a third vector w instead (GMRES's modified
 // Gram-Schmidt: w' <- w' - h v_k, then v_{k+1}.w').
-template <typename T, typename E, int EN, bool OTHER = false>
+template <typename T, typename E, int EN, bool OTHER = false, bool NT = false>
 __global__ __launch_bounds__(kBlock) void axpy_sqnorm_kernel(int64_t n, Alpha<T> a, const T *x, T *y,
                                                              T *__restrict__ out, int form,
                                                              const T *w = nullptr) {
@@ -331,16 +360,16 @@ __global__ __launch_bounds__(kBlock) void axpy_sqnorm_kernel(int64_t n, Alpha<T>
         E xv[4], yv[4], wv[OTHER ? 4 : 1];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            xv[u] = xe[i + u * inner];
-            yv[u] = ye[i + u * inner];
-            if constexpr (OTHER) wv[u] = we[i + u * inner];
+            xv[u] = ld<NT>(xe + i + u * inner);
+            yv[u] = ld<NT>(ye + i + u * inner);
+            if constexpr (OTHER) wv[u] = ld<NT>(we + i + u * inner);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             E r;
             if constexpr (EN == 1) r = apply<T, OP_AXPY>(alpha, xv[u], yv[u]);
             else r = apply_v<T, OP_AXPY>(alpha, xv[u], yv[u]);
-            ye[i + u * inner] = r;
+            st<NT>(ye + i + u * inner, r);
             if constexpr (OTHER) acc[u] = dot_v<T>(r, wv[u], acc[u]);
             else acc[u] = dot_v<T>(r, r, acc[u]);
         }
@@ -350,10 +379,10 @@ __global__ __launch_bounds__(kBlock) void axpy_sqnorm_kernel(int64_t n, Alpha<T>
         const int64_t j = i + u * inner;
         if (j < ne) {
             E r;
-            if constexpr (EN == 1) r = apply<T, OP_AXPY>(alpha, xe[j], ye[j]);
-            else r = apply_v<T, OP_AXPY>(alpha, xe[j], ye[j]);
-            ye[j] = r;
-            if constexpr (OTHER) acc[u] = dot_v<T>(r, we[j], acc[u]);
+            if constexpr (EN == 1) r = apply<T, OP_AXPY>(alpha, ld<NT>(xe + j), ld<NT>(ye + j));
+            else r = apply_v<T, OP_AXPY>(alpha, ld<NT>(xe + j), ld<NT>(ye + j));
+            st<NT>(ye + j, r);
+            if constexpr (OTHER) acc[u] = dot_v<T>(r, ld<NT>(we + j), acc[u]);
             else acc[u] = dot_v<T>(r, r, acc[u]);
         }
     }
@@ -390,10 +419,13 @@ int launch_axpy_sqnorm(const char *name, int64_t n, Alpha<T> a, const T *x, T *y
         return lsk::fail(LSK_ERR_ARG, "%s: room for %lld partial sums, %d needed", name, (long long)capacity, blocks);
     hipStream_t s = lsk::as_stream(stream);
     const int form = lsk::options().blas1_form;
+    const bool nt = vec && stream_past_caches(n, sizeof(T));
     if (w) {
-        if (vec) axpy_sqnorm_kernel<T, V, VN, true><<<blocks, kBlock, 0, s>>>(n, a, x, y, partials, form, w);
+        if (nt) axpy_sqnorm_kernel<T, V, VN, true, true><<<blocks, kBlock, 0, s>>>(n, a, x, y, partials, form, w);
+        else if (vec) axpy_sqnorm_kernel<T, V, VN, true><<<blocks, kBlock, 0, s>>>(n, a, x, y, partials, form, w);
         else axpy_sqnorm_kernel<T, T, 1, true><<<blocks, kBlock, 0, s>>>(n, a, x, y, partials, form, w);
-    } else if (vec) axpy_sqnorm_kernel<T, V, VN><<<blocks, kBlock, 0, s>>>(n, a, x, y, partials, form);
+    } else if (nt) axpy_sqnorm_kernel<T, V, VN, false, true><<<blocks, kBlock, 0, s>>>(n, a, x, y, partials, form);
+    else if (vec) axpy_sqnorm_kernel<T, V, VN><<<blocks, kBlock, 0, s>>>(n, a, x, y, partials, form);
     else axpy_sqnorm_kernel<T, T, 1><<<blocks, kBlock, 0, s>>>(n, a, x, y, partials, form);
     LSK_LAUNCH_CHECK();
     *count = blocks;
@@ -403,7 +435,7 @@ int launch_axpy_sqnorm(const char *name, int64_t n, Alpha<T> a, const T *x, T *y
 // Two updates that read the same vector in one pass: z <- fma(a, p, z) and p <- fma(b, p, r), both
 // from the OLD p (CG's x <- x + alpha p followed by p <- r + beta p, src/CGSolver.hpp:48,54, where the
 // first does not depend on anything computed in between).  5 instead of 6 vector passes.
-template <typename T, typename E, int EN>
+template <typename T, typename E, int EN, bool NT = false>
 __global__ __launch_bounds__(kBlock) void axpy_xpay_kernel(int64_t n, Alpha<T> a, Alpha<T> b, const T *r, T *p,
                                                            T *z, int form) {
     const T alpha = resolve_alpha(a), beta = resolve_alpha(b);
@@ -430,16 +462,16 @@ __global__ __launch_bounds__(kBlock) void axpy_xpay_kernel(int64_t n, Alpha<T> a
         E rv[4], pv[4], zv[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            rv[u] = re[i + u * inner];
-            pv[u] = pe[i + u * inner];
-            zv[u] = ze[i + u * inner];
+            rv[u] = ld<NT>(re + i + u * inner);
+            pv[u] = ld<NT>(pe + i + u * inner);
+            zv[u] = ld<NT>(ze + i + u * inner);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             E po, zo;
             both(rv[u], pv[u], zv[u], po, zo);
-            ze[i + u * inner] = zo;
-            pe[i + u * inner] = po;
+            st<NT>(ze + i + u * inner, zo);
+            st<NT>(pe + i + u * inner, po);
         }
     }
 #pragma unroll
@@ -447,9 +479,9 @@ __global__ __launch_bounds__(kBlock) void axpy_xpay_kernel(int64_t n, Alpha<T> a
         const int64_t j = i + u * inner;
         if (j < ne) {
             E po, zo;
-            both(re[j], pe[j], ze[j], po, zo);
-            ze[j] = zo;
-            pe[j] = po;
+            both(ld<NT>(re + j), ld<NT>(pe + j), ld<NT>(ze + j), po, zo);
+            st<NT>(ze + j, zo);
+            st<NT>(pe + j, po);
         }
     }
     if (EN > 1 && first) {
@@ -480,7 +512,8 @@ int launch_axpy_xpay(const char *name, int64_t n, Alpha<T> a, Alpha<T> b, const 
     const int blocks = vec ? stream_grid(n / VN + 1) : stream_grid(n);
     hipStream_t s = lsk::as_stream(stream);
     const int form = lsk::options().blas1_form;
-    if (vec) axpy_xpay_kernel<T, V, VN><<<blocks, kBlock, 0, s>>>(n, a, b, r, p, z, form);
+    if (vec && stream_past_caches(n, sizeof(T))) axpy_xpay_kernel<T, V, VN, true><<<blocks, kBlock, 0, s>>>(n, a, b, r, p, z, form);
+    else if (vec) axpy_xpay_kernel<T, V, VN><<<blocks, kBlock, 0, s>>>(n, a, b, r, p, z, form);
     else axpy_xpay_kernel<T, T, 1><<<blocks, kBlock, 0, s>>>(n, a, b, r, p, z, form);
     LSK_LAUNCH_CHECK();
     return LSK_OK;

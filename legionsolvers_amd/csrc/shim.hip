@@ -114,6 +114,9 @@ int lsk_set_option(const char *key, int value) {
         o.csr_max_units = value;
     } else if (!std::strcmp(key, "blas1.form")) {
         o.blas1_form = value != 0;
+    } else if (!std::strcmp(key, "blas1.nontemporal")) {
+        if (value < -1 || value > 1) return lsk::fail(LSK_ERR_ARG, "blas1.nontemporal must be -1, 0 or 1");
+        o.blas1_nontemporal = value;
     } else if (!std::strcmp(key, "coo.variant")) {
         if (value != 0 && value != 1) return lsk::fail(LSK_ERR_ARG, "coo.variant must be 0 or 1");
         o.coo_variant = value;
@@ -134,6 +137,7 @@ int lsk_get_option(const char *key, int *value) {
     else if (!std::strcmp(key, "csr.log_rows_per_wave")) *value = o.csr_log_rw;
     else if (!std::strcmp(key, "csr.max_units")) *value = o.csr_max_units;
     else if (!std::strcmp(key, "blas1.form")) *value = o.blas1_form;
+    else if (!std::strcmp(key, "blas1.nontemporal")) *value = o.blas1_nontemporal;
     else if (!std::strcmp(key, "coo.variant")) *value = o.coo_variant;
     else if (!std::strcmp(key, "comm.skip_single_rank")) *value = o.comm_skip_single_rank;
     else return lsk::fail(LSK_ERR_ARG, "lsk_get_option: unknown key '%s'", key);

@@ -455,3 +455,47 @@ def test_random_fill_bit_exact_and_partition_independent(gpu_ctx, suf):
         whole = h if whole is None else whole
         assert torch.equal(h, whole)
     assert 0.45 < float(whole.double().mean()) < 0.55
+
+
+@pytest.mark.parametrize("suf", ["f32", "f64"])
+def test_nontemporal_streams_give_the_same_bits(suf):
+    """Option blas1.nontemporal = 1 (what vectors of 256 MiB and more get by default): every stream
+    kernel's nontemporal instance gives the bits of the plain one."""
+    npdt, tdt = DT[suf]
+    rng = np.random.default_rng(31)
+    lib = _lib.lib()
+    results = {}
+    for mode in (0, 1):
+        _lib.check(lib.lsk_set_option(b"blas1.nontemporal", mode))
+        try:
+            got = []
+            for n in (0, 5, 1024, 4099, (1 << 20) + 3):
+                print(f"case nontemporal={mode} {suf} n={n}", flush=True)
+                g = np.random.default_rng(n)
+                x, y, z = (g.standard_normal(n).astype(npdt) for _ in range(3))
+                f = dev(np.array([0.75, 1.5], dtype=npdt))
+                xd, yd, zd = dev(x), dev(y), dev(z)
+                _lib.call(f"lsk_axpy_{suf}", n, 0.5, P(xd), P(yd), stream())
+                _lib.call(f"lsk_xpay_{suf}", n, -0.25, P(xd), P(yd), stream())
+                _lib.call(f"lsk_scal_{suf}", n, 1.25, P(yd), stream())
+                _lib.call(f"lsk_copy_{suf}", n, P(yd), P(zd), stream())
+                out = torch.zeros(4, dtype=tdt, device="cuda")
+                _lib.call(f"lsk_dot_{suf}", n, P(xd), P(yd), P(out[0:1]), None, 0, stream())
+                _lib.call(f"lsk_nrm2_{suf}", n, P(yd), P(out[1:2]), None, 0, stream())
+                partials = torch.zeros(2048, dtype=tdt, device="cuda")
+                count = ctypes.c_int(0)
+                _lib.call(f"lsk_axpy_dot_dev_{suf}", n, 2, P(f[0:1]), P(f[1:2]), None, None, P(xd), P(yd), P(zd),
+                          P(partials), 2048, ctypes.byref(count), stream())
+                _lib.call(f"lsk_sum_partials_{suf}", count.value, P(partials), P(out[2:3]), None, 0, stream())
+                if n:
+                    r = dev(g.standard_normal(n).astype(npdt))
+                    _lib.call(f"lsk_axpy_xpay_dev_{suf}", n, 1, P(f[0:1]), None, None, None, 1, P(f[1:2]), None, None,
+                              None, P(r), P(yd), P(zd), stream())
+                got.append((yd.cpu().numpy().tobytes(), zd.cpu().numpy().tobytes(), out.cpu().numpy().tobytes()))
+            results[mode] = got
+        finally:
+            _lib.check(lib.lsk_set_option(b"blas1.nontemporal", -1))
+    assert results[0] == results[1]
+    v = ctypes.c_int(7)
+    _lib.check(lib.lsk_get_option(b"blas1.nontemporal", ctypes.byref(v)))
+    assert v.value == -1 and lib.lsk_set_option(b"blas1.nontemporal", 2) == _lib.LSK_ERR_ARG

@@ -35,7 +35,14 @@ def main():
     f, w = means(fetch, "FETCH_SIZE"), means(write, "WRITE_SIZE")
     dot_true = 2 * rows * 8
     ratio = dot_true / (f["dot"] * 1024)
-    factor = 2 if 1.9 < ratio < 2.1 else 1
+    # 2.0 for wide coalesced reads on gfx950 (a 128-byte request tallied as 64 bytes), 1.0 where the
+    # counter reads true; anything else means the calibration stream is not understood: stop
+    if 1.9 < ratio < 2.1:
+        factor = 2
+    elif 0.95 < ratio < 1.05:
+        factor = 1
+    else:
+        raise SystemExit(f"FETCH_SIZE calibration ratio {ratio:.3f} is neither 1 nor 2")
     traffic = factor * f["spmv"] * 1024 + w["spmv"] * 1024
     algo = nnz * 16 + rows * 32
     c32 = {}
