@@ -260,6 +260,29 @@ int lsk_axpy_xpay_dev_f64(int64_t n, int nfa, const double *a0, const double *a1
                           const double *a3, int nfb, const double *b0, const double *b1, const double *b2,
                           const double *b3, const double *r, double *p, double *z, lsk_stream_t stream);
 
+/* Several dot products with one vector, and several updates of one vector, in one pass each: for
+ * GMRES's orthogonalisation in its CLASSICAL Gram-Schmidt form, where every h_k = v_k . w comes from
+ * the same w (the reference runs the modified form, h_k and w <- w - h_k v_k alternating, two passes
+ * over w per basis vector: src/GMRESSolver.hpp:92-100; the classical form is different arithmetic,
+ * an option of the caller, never a silent replacement).  No counterpart in the reference.
+ *   lsk_multi_dot_*: results_dev[j] <- sum_i v[j][i] * w[i] for j < k (k <= 64; v: HOST array of k
+ *     device pointers), deterministic; the vectors go in groups of 8 per launch, so w is read
+ *     ceil(k / 8) times instead of k.  workspace: lsk_multi_dot_workspace_bytes(k) bytes of device
+ *     memory (required).
+ *   lsk_multi_axpy_*: y <- fma(c_{k-1}, x[k-1], ... fma(c_0, x[0], y)) with c_j = coef_dev[j], or
+ *     -coef_dev[j] when negate != 0: element for element the chain of AxpyTasks y <- y + c_j x[j],
+ *     j ascending (bit-identical to k calls of lsk_axpy_dev_*).  partials != NULL: also partials[0 ..
+ *     *count) <- per-workgroup shares of sum(y_new^2) (at most 2048), as lsk_axpy_sqnorm_*. */
+size_t lsk_multi_dot_workspace_bytes(int k);
+int lsk_multi_dot_f32(int64_t n, int k, const float *const *v, const float *w, float *results_dev,
+                      void *workspace, size_t workspace_bytes, lsk_stream_t stream);
+int lsk_multi_dot_f64(int64_t n, int k, const double *const *v, const double *w, double *results_dev,
+                      void *workspace, size_t workspace_bytes, lsk_stream_t stream);
+int lsk_multi_axpy_f32(int64_t n, int k, const float *const *x, const float *coef_dev, int negate,
+                       float *y, float *partials, int64_t capacity, int *count, lsk_stream_t stream);
+int lsk_multi_axpy_f64(int64_t n, int k, const double *const *x, const double *coef_dev, int negate,
+                       double *y, double *partials, int64_t capacity, int *count, lsk_stream_t stream);
+
 /* *result_dev <- partials[0] + ... + partials[count-1], in an order fixed by `count` alone (so
  * bit-reproducible): the second stage of the fused forms (lsk_axpy_sqnorm_*, lsk_csr_spmv_dot_*).
  * Counts above 8192 take two kernel stages through `workspace` (lsk_dot_workspace_bytes(0)

@@ -69,6 +69,7 @@ PROTOTYPES = {
     "lsk_memcpy_d2h": (_i, [_p, _p, _sz, _p]),
     "lsk_memcpy_d2d": (_i, [_p, _p, _sz, _p]),
     "lsk_dot_workspace_bytes": (_sz, [_i64]),
+    "lsk_multi_dot_workspace_bytes": (_sz, [_i]),
     "lsk_dot_noalloc_f64": (_i, [_i64, _p, _p, _p, _p]),
     "lsk_csr_spmv_dot_partials": (_i64, [_i64, _i64, _i]),
     "lsk_rects_to_indptr_i64": (_i, [_i64, _p, _p, _p]),
@@ -131,6 +132,8 @@ PROTOTYPES.update(_typed(_FT, lambda s, t: {
     f"lsk_axpy_dot_dev_{s}": (_i, [_i64, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i64, ctypes.POINTER(_i), _p]),
     f"lsk_axpy_xpay_dev_{s}": (_i, [_i64, _i, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p]),
     f"lsk_sum_partials_{s}": (_i, [_i64, _p, _p, _p, _sz, _p]),
+    f"lsk_multi_dot_{s}": (_i, [_i64, _i, _p, _p, _p, _p, _sz, _p]),
+    f"lsk_multi_axpy_{s}": (_i, [_i64, _i, _p, _p, _i, _p, _p, _i64, ctypes.POINTER(_i), _p]),
     f"lsk_csr_spmv_tune_{s}": (_i, [_i64, _i64, _p, _i64, _p, _p, _p, _i64, _i64, _p, _p,
                                     ctypes.POINTER(_i), ctypes.POINTER(ctypes.c_float)]),
     f"lsk_csr_spmv_c32_{s}": (_i, [_i64, _i64, _p, _p, _p, _p, _i64, _p, _i, _p]),

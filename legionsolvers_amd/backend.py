@@ -140,6 +140,30 @@ class HipBackend:
                   ctypes.byref(count), self.stream())
         return count.value
 
+    MULTI_MAX = 64  # vectors per lsk_multi_dot_* / lsk_multi_axpy_* call
+
+    def multi_dot(self, vs: Sequence[torch.Tensor], w: torch.Tensor, out: torch.Tensor) -> None:
+        """out[j] <- vs[j] . w for every j, in one pass over w per group of 8 vectors."""
+        k = len(vs)
+        need = int(self.lib.lsk_multi_dot_workspace_bytes(k))
+        if getattr(self, "_multi_ws", None) is None or self._multi_ws.numel() < need:
+            self._multi_ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        ptrs = (ctypes.c_void_p * max(k, 1))(*[v.data_ptr() for v in vs])
+        _lib.call(f"lsk_multi_dot_{_lib.suffix(w.dtype)}", w.numel(), k, ptrs, _ptr(w), _ptr(out),
+                  _ptr(self._multi_ws), self._multi_ws.numel(), self.stream())
+
+    def multi_axpy(self, y: torch.Tensor, coef: torch.Tensor, xs: Sequence[torch.Tensor], negate: bool,
+                   partials=None) -> int:
+        """y <- y + sum_j (+-coef[j]) xs[j], as the chain of axpys in ascending j (bit-identical to it);
+        with `partials`, also the shares of sum(y_new^2).  Returns their count (0 without)."""
+        k = len(xs)
+        ptrs = (ctypes.c_void_p * max(k, 1))(*[x.data_ptr() for x in xs])
+        count = ctypes.c_int(0)
+        _lib.call(f"lsk_multi_axpy_{_lib.suffix(y.dtype)}", y.numel(), k, ptrs, _ptr(coef), 1 if negate else 0, _ptr(y),
+                  _ptr(partials), partials.numel() if partials is not None else 0,
+                  ctypes.byref(count) if partials is not None else None, self.stream())
+        return count.value
+
     def sum_partials(self, count: int, partials, out: torch.Tensor) -> None:
         """out[0] <- partials[0] + ... + partials[count-1] (count may be 0)."""
         _lib.call(f"lsk_sum_partials_{_lib.suffix(out.dtype)}", count, _ptr(partials), _ptr(out),

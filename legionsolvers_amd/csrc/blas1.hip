@@ -569,6 +569,245 @@ int launch_sum_partials(const char *name, int64_t count, const T *partials, T *r
     return LSK_OK;
 }
 
+// ------------------------------------------------- several dot products / updates in one pass ---
+//
+// GMRES orthogonalises w against v_0 .. v_j.  The reference's modified Gram-Schmidt sweep
+// (src/GMRESSolver.hpp:92-100) alternates h_k = v_k . w and w <- w - h_k v_k, two passes over w per
+// basis vector.  In the classical variant every h_k comes from the same w, so all of them can be
+// formed in ONE pass over w (multi_dot), and all updates applied in one more (multi_axpy): a group of
+// up to kGroup vectors per launch, w read once per group.
+constexpr int kGroup = 8;
+template <typename T> struct PtrGroup { const T *p[kGroup]; };
+
+// out[j * gridDim.x + block] <- this block's share of sum_i v_j[i] * w[i], j < k.
+template <typename T, typename E, int EN, bool NT>
+__global__ __launch_bounds__(kBlock) void multi_dot_kernel(int64_t n, PtrGroup<T> v, int k, const T *__restrict__ w,
+                                                           T *__restrict__ out) {
+    __shared__ T s_wave[kGroup][kBlock / lsk::kWave];
+    const int64_t ne = n / EN;
+    const E *we = reinterpret_cast<const E *>(w);
+    const int64_t gstride = int64_t(gridDim.x) * kBlock;
+    T acc[kGroup];
+#pragma unroll
+    for (int j = 0; j < kGroup; ++j) acc[j] = T(0);
+    // two accesses of w per lane in flight, and with each the k accesses of the v_j
+    int64_t i = int64_t(blockIdx.x) * (2 * kBlock) + threadIdx.x;
+    for (; i < ne; i += 2 * gstride) {
+        const bool second = i + kBlock < ne;
+        E wv[2], vv[2][kGroup];
+        wv[0] = ld<NT>(we + i);
+        if (second) wv[1] = ld<NT>(we + i + kBlock);
+#pragma unroll
+        for (int j = 0; j < kGroup; ++j)
+            if (j < k) {
+                const E *ve = reinterpret_cast<const E *>(v.p[j]);
+                vv[0][j] = ld<NT>(ve + i);
+                if (second) vv[1][j] = ld<NT>(ve + i + kBlock);
+            }
+#pragma unroll
+        for (int j = 0; j < kGroup; ++j)
+            if (j < k) {
+                acc[j] = dot_v<T>(vv[0][j], wv[0], acc[j]);
+                if (second) acc[j] = dot_v<T>(vv[1][j], wv[1], acc[j]);
+            }
+    }
+    if (EN > 1 && blockIdx.x == 0 && threadIdx.x == 0) { // the n % EN trailing elements
+        for (int64_t t = ne * EN; t < n; ++t)
+#pragma unroll
+            for (int j = 0; j < kGroup; ++j)
+                if (j < k) acc[j] = fma_t(v.p[j][t], w[t], acc[j]);
+    }
+    const int lane = threadIdx.x % lsk::kWave, wave = threadIdx.x / lsk::kWave;
+#pragma unroll
+    for (int j = 0; j < kGroup; ++j) {
+        const T total = lsk::wave_sum(acc[j]);
+        if (lane == 0) s_wave[j][wave] = total;
+    }
+    __syncthreads();
+    if (static_cast<int>(threadIdx.x) < k) {
+        T total = T(0);
+#pragma unroll
+        for (int q = 0; q < kBlock / lsk::kWave; ++q) total += s_wave[threadIdx.x][q];
+        out[int64_t(threadIdx.x) * gridDim.x + blockIdx.x] = total;
+    }
+}
+
+// results[j] <- the sum of row j of partials (count values each, rows `stride` apart), one workgroup
+// per row, in fold_kernel's fixed order.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void multi_fold_kernel(int count, int64_t stride, const T *__restrict__ partials,
+                                                            T *__restrict__ results) {
+    const T *row = partials + int64_t(blockIdx.x) * stride;
+    T acc = T(0);
+    for (int i = threadIdx.x; i < count; i += kBlock) acc += row[i];
+    const T total = block_sum(acc);
+    if (threadIdx.x == 0) results[blockIdx.x] = total;
+}
+
+// w <- fma(c_{k-1}, v_{k-1}, ... fma(c_1, v_1, fma(c_0, v_0, w))), c_j = coef[j] (negated when
+// `negate`): element for element the chain of AxpyTasks w <- w + c_j v_j, j ascending.  SQ: out[block]
+// <- this block's share of sum(w_new^2) as well.
+template <typename T, typename E, int EN, bool NT, bool SQ>
+__global__ __launch_bounds__(kBlock) void multi_axpy_kernel(int64_t n, PtrGroup<T> v, int k, const T *__restrict__ coef,
+                                                            int negate, T *w, T *__restrict__ out) {
+    T c[kGroup];
+#pragma unroll
+    for (int j = 0; j < kGroup; ++j) c[j] = j < k ? (negate ? -coef[j] : coef[j]) : T(0);
+    const int64_t ne = n / EN;
+    E *we = reinterpret_cast<E *>(w);
+    const int64_t gstride = int64_t(gridDim.x) * kBlock;
+    T acc = T(0);
+    int64_t i = int64_t(blockIdx.x) * (2 * kBlock) + threadIdx.x;
+    for (; i < ne; i += 2 * gstride) {
+        const bool second = i + kBlock < ne;
+        E wv[2], vv[2][kGroup];
+        wv[0] = ld<NT>(we + i);
+        if (second) wv[1] = ld<NT>(we + i + kBlock);
+#pragma unroll
+        for (int j = 0; j < kGroup; ++j)
+            if (j < k) {
+                const E *ve = reinterpret_cast<const E *>(v.p[j]);
+                vv[0][j] = ld<NT>(ve + i);
+                if (second) vv[1][j] = ld<NT>(ve + i + kBlock);
+            }
+#pragma unroll
+        for (int j = 0; j < kGroup; ++j)
+            if (j < k) {
+                if constexpr (EN == 1) {
+                    wv[0] = apply<T, OP_AXPY>(c[j], vv[0][j], wv[0]);
+                    if (second) wv[1] = apply<T, OP_AXPY>(c[j], vv[1][j], wv[1]);
+                } else {
+                    wv[0] = apply_v<T, OP_AXPY>(c[j], vv[0][j], wv[0]);
+                    if (second) wv[1] = apply_v<T, OP_AXPY>(c[j], vv[1][j], wv[1]);
+                }
+            }
+        st<NT>(we + i, wv[0]);
+        if (second) st<NT>(we + i + kBlock, wv[1]);
+        if constexpr (SQ) {
+            acc = dot_v<T>(wv[0], wv[0], acc);
+            if (second) acc = dot_v<T>(wv[1], wv[1], acc);
+        }
+    }
+    if (EN > 1 && blockIdx.x == 0 && threadIdx.x == 0) {
+        for (int64_t t = ne * EN; t < n; ++t) {
+            T r = w[t];
+#pragma unroll
+            for (int j = 0; j < kGroup; ++j)
+                if (j < k) r = fma_t(c[j], v.p[j][t], r);
+            w[t] = r;
+            if constexpr (SQ) acc = fma_t(r, r, acc);
+        }
+    }
+    if constexpr (SQ) {
+        const T total = block_sum(acc);
+        if (threadIdx.x == 0) out[blockIdx.x] = total;
+    }
+}
+
+inline int multi_grid(int64_t accesses) {
+    int64_t blocks = lsk::ceil_div(accesses, int64_t(kBlock) * 2);
+    if (blocks < 1) blocks = 1;
+    if (blocks > lsk::kMaxGridBlocks) blocks = lsk::kMaxGridBlocks;
+    return static_cast<int>(blocks);
+}
+
+constexpr int kMaxMulti = 64; // vectors per call
+
+template <typename T>
+int check_multi(const char *name, int64_t n, int k, const T *const *v, const T *w) {
+    if (n < 0) return lsk::fail(LSK_ERR_ARG, "%s: negative length %lld", name, (long long)n);
+    if (k < 0 || k > kMaxMulti) return lsk::fail(LSK_ERR_ARG, "%s: %d vectors (0..%d allowed)", name, k, kMaxMulti);
+    if (k > 0 && !v) return lsk::fail(LSK_ERR_ARG, "%s: null vector list", name);
+    if (n > 0) {
+        if (!w) return lsk::fail(LSK_ERR_ARG, "%s: null vector", name);
+        for (int j = 0; j < k; ++j)
+            if (!v[j]) return lsk::fail(LSK_ERR_ARG, "%s: vector %d is null", name, j);
+    }
+    return LSK_OK;
+}
+
+template <typename T>
+int launch_multi_dot(const char *name, int64_t n, int k, const T *const *v, const T *w, T *results, void *workspace,
+                     size_t workspace_bytes, lsk_stream_t stream) {
+    int rc = check_multi<T>(name, n, k, v, w);
+    if (rc != LSK_OK) return rc;
+    if (k == 0) return LSK_OK;
+    if (!results) return lsk::fail(LSK_ERR_ARG, "%s: null results", name);
+    hipStream_t s = lsk::as_stream(stream);
+    if (n == 0) {
+        for (int j = 0; j < k; ++j) store_scalar_kernel<T><<<1, 1, 0, s>>>(results + j, T(0));
+        LSK_LAUNCH_CHECK();
+        return LSK_OK;
+    }
+    using V = typename Vec<T>::type;
+    constexpr int VN = Vec<T>::N;
+    bool vec = lsk::aligned16(w);
+    for (int j = 0; j < k; ++j) vec = vec && lsk::aligned16(v[j]);
+    const int blocks = vec ? multi_grid(n / VN + 1) : multi_grid(n);
+    const size_t need = size_t(k) * size_t(blocks) * sizeof(T);
+    if (!workspace || workspace_bytes < need)
+        return lsk::fail(LSK_ERR_ARG, "%s: workspace of %zu bytes, %zu needed", name, workspace ? workspace_bytes : size_t(0),
+                         need);
+    T *partials = static_cast<T *>(workspace);
+    const bool nt = vec && stream_past_caches(n, sizeof(T));
+    for (int j0 = 0; j0 < k; j0 += kGroup) {
+        const int kk = k - j0 < kGroup ? k - j0 : kGroup;
+        PtrGroup<T> g{};
+        for (int j = 0; j < kk; ++j) g.p[j] = v[j0 + j];
+        T *out = partials + size_t(j0) * blocks;
+        if (nt) multi_dot_kernel<T, V, VN, true><<<blocks, kBlock, 0, s>>>(n, g, kk, w, out);
+        else if (vec) multi_dot_kernel<T, V, VN, false><<<blocks, kBlock, 0, s>>>(n, g, kk, w, out);
+        else multi_dot_kernel<T, T, 1, false><<<blocks, kBlock, 0, s>>>(n, g, kk, w, out);
+        LSK_LAUNCH_CHECK();
+    }
+    multi_fold_kernel<T><<<k, kBlock, 0, s>>>(blocks, blocks, partials, results);
+    LSK_LAUNCH_CHECK();
+    return LSK_OK;
+}
+
+template <typename T>
+int launch_multi_axpy(const char *name, int64_t n, int k, const T *const *v, const T *coef, int negate, T *w, T *partials,
+                      int64_t capacity, int *count, lsk_stream_t stream) {
+    int rc = check_multi<T>(name, n, k, v, w);
+    if (rc != LSK_OK) return rc;
+    if (count) *count = 0;
+    if (partials && !count) return lsk::fail(LSK_ERR_ARG, "%s: partials without a count", name);
+    if (n == 0 || (k == 0 && !partials)) return LSK_OK;
+    if (k > 0 && !coef) return lsk::fail(LSK_ERR_ARG, "%s: null coefficients", name);
+    for (int j = 0; j < k; ++j)
+        if (v[j] == w) return lsk::fail(LSK_ERR_ARG, "%s: vector %d is the destination", name, j);
+    using V = typename Vec<T>::type;
+    constexpr int VN = Vec<T>::N;
+    bool vec = lsk::aligned16(w);
+    for (int j = 0; j < k; ++j) vec = vec && lsk::aligned16(v[j]);
+    const int blocks = vec ? multi_grid(n / VN + 1) : multi_grid(n);
+    if (partials && capacity < blocks)
+        return lsk::fail(LSK_ERR_ARG, "%s: room for %lld partial sums, %d needed", name, (long long)capacity, blocks);
+    hipStream_t s = lsk::as_stream(stream);
+    const bool nt = vec && stream_past_caches(n, sizeof(T));
+    const int groups = k == 0 ? 1 : (k + kGroup - 1) / kGroup;
+    for (int gi = 0; gi < groups; ++gi) {
+        const int j0 = gi * kGroup;
+        const int kk = k - j0 < kGroup ? k - j0 : kGroup;
+        PtrGroup<T> g{};
+        for (int j = 0; j < kk; ++j) g.p[j] = v[j0 + j];
+        const bool sq = partials && gi == groups - 1; // the norm of the final values only
+        const T *cf = coef ? coef + j0 : nullptr;
+#define LSK_MULTI_AXPY(E, EN, NT)                                                                            \
+    do {                                                                                                     \
+        if (sq) multi_axpy_kernel<T, E, EN, NT, true><<<blocks, kBlock, 0, s>>>(n, g, kk, cf, negate, w, partials); \
+        else multi_axpy_kernel<T, E, EN, NT, false><<<blocks, kBlock, 0, s>>>(n, g, kk, cf, negate, w, partials);   \
+    } while (0)
+        if (nt) LSK_MULTI_AXPY(V, VN, true);
+        else if (vec) LSK_MULTI_AXPY(V, VN, false);
+        else LSK_MULTI_AXPY(T, 1, false);
+#undef LSK_MULTI_AXPY
+        LSK_LAUNCH_CHECK();
+    }
+    if (partials) *count = blocks;
+    return LSK_OK;
+}
+
 template <typename T>
 int dot_host(const char *name, int64_t n, const T *v, const T *w, T *result_host,
              lsk_stream_t stream) {
@@ -739,6 +978,10 @@ int lsk_dot_noalloc_f64(int64_t n, const double *v, const double *w, double *res
                               stream);
 }
 
+size_t lsk_multi_dot_workspace_bytes(int k) {
+    return size_t(k < 0 ? 0 : k) * size_t(lsk::kMaxGridBlocks) * sizeof(double);
+}
+
 size_t lsk_dot_workspace_bytes(int64_t n) {
     (void)n;
     return size_t(lsk::kMaxGridBlocks) * sizeof(double);
@@ -820,6 +1063,15 @@ size_t lsk_dot_workspace_bytes(int64_t n) {
                                    const T *r, T *p, T *z, lsk_stream_t s) {                      \
         return launch_axpy_xpay<T>("lsk_axpy_xpay_dev_" #SUFFIX, n, dev_alpha<T>(nfa, a0, a1, a2, a3), \
                                    dev_alpha<T>(nfb, b0, b1, b2, b3), r, p, z, s);                \
+    }                                                                                             \
+    int lsk_multi_dot_##SUFFIX(int64_t n, int k, const T *const *v, const T *w, T *results, void *ws, \
+                               size_t wsb, lsk_stream_t s) {                                      \
+        return launch_multi_dot<T>("lsk_multi_dot_" #SUFFIX, n, k, v, w, results, ws, wsb, s);    \
+    }                                                                                             \
+    int lsk_multi_axpy_##SUFFIX(int64_t n, int k, const T *const *x, const T *coef, int negate,   \
+                                T *y, T *partials, int64_t capacity, int *count, lsk_stream_t s) { \
+        return launch_multi_axpy<T>("lsk_multi_axpy_" #SUFFIX, n, k, x, coef, negate, y, partials, \
+                                    capacity, count, s);                                          \
     }                                                                                             \
     int lsk_sum_partials_##SUFFIX(int64_t count, const T *partials, T *result, void *ws,          \
                                   size_t wsb, lsk_stream_t s) {                                   \

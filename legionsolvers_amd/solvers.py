@@ -83,7 +83,16 @@ class GMRESSolver:
     there yet: the solution update uses DummyTask's coefficient 1 for every basis vector
     (:109-126, src/UtilityTasks.cpp:96-99)."""
 
-    def __init__(self, planner: SquarePlanner, restart: int):
+    def __init__(self, planner: SquarePlanner, restart: int, orthogonalization: str = "modified"):
+        """orthogonalization: "modified" is the reference's Gram-Schmidt sweep (src/GMRESSolver.hpp:
+        92-100: h_k = v_k . w and w <- w - h_k v_k alternating); "classical" forms every h_k from the
+        same w, which lets all of them share one pass over w and all updates another
+        (SquarePlanner.multi_dot / multi_axpy): about half the vector traffic of a restart cycle, one
+        all-reduce per Krylov vector instead of one per inner product, and DIFFERENT arithmetic (less
+        robust against loss of orthogonality) -- an option, never the default."""
+        if orthogonalization not in ("modified", "classical"):
+            raise ValueError("orthogonalization must be 'modified' or 'classical'")
+        self.orthogonalization = orthogonalization
         self.planner = planner
         self.restart = int(restart)
         ctx, dt = planner.get_context(), planner.dtype
@@ -106,9 +115,16 @@ class GMRESSolver:
         pl.scal(kb(0), residual_norm)
         for j in range(self.restart):
             pl.matvec(kb(j + 1), kb(j))
-            for k in range(j + 1):
-                self.inner_products[k][j] = pl.dot(kb(k), kb(j + 1))
-                pl.axpy(kb(j + 1), -self.inner_products[k][j], kb(k))
+            if self.orthogonalization == "classical":
+                basis = [kb(k) for k in range(j + 1)]
+                h = pl.multi_dot(basis, kb(j + 1))
+                for k in range(j + 1):
+                    self.inner_products[k][j] = Scalar(pl.get_context(), h[k:k + 1])
+                pl.multi_axpy(kb(j + 1), h, basis, negate=True)
+            else:
+                for k in range(j + 1):
+                    self.inner_products[k][j] = pl.dot(kb(k), kb(j + 1))
+                    pl.axpy(kb(j + 1), -self.inner_products[k][j], kb(k))
             d = pl.dot(kb(j + 1), kb(j + 1))
             self.inner_products[j + 1][j] = d.sqrt()
             if j + 1 < self.restart:

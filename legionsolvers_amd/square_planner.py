@@ -235,6 +235,72 @@ class SquarePlanner:
         be.sum_scalars(slots, out)
         return Scalar(self.ctx, out)
 
+    def multi_dot(self, v_indices, w_idx: int) -> torch.Tensor:
+        """k dot products with one vector in one pass over it: out[j] = dot(v_indices[j], w_idx), the
+        sum over spaces and ranks included (one all-reduce of k scalars).  Returns the k device
+        scalars as one tensor; Scalar(ctx, out[j:j+1]) wraps one.  The reference's planner has no such
+        method (its GMRES takes its inner products one by one, src/GMRESSolver.hpp:92-100)."""
+        be = self.ctx.backend
+        k, n = len(v_indices), self.get_num_spaces()
+        if not 1 <= k <= be.MULTI_MAX:
+            raise ValueError(f"multi_dot takes 1..{be.MULTI_MAX} vectors")
+        self._fused_dot_pending = None
+        def fold(rows):
+            """Row of k sums over the given rows of k values, added left to right."""
+            if len(rows) == 1:
+                return rows[0]
+            stacked = torch.stack(rows, dim=1).contiguous()   # (k, len(rows))
+            folded = be.empty(k, self.dtype)
+            for j in range(k):
+                be.sum_scalars(stacked[j], folded[j:j + 1])
+            return folded
+
+        per_space = []  # as dot(): the pieces of a space folded in colour order ...
+        for i in range(n):
+            w = self.get_vector(w_idx, i)
+            vs = [self.get_vector(v, i) for v in v_indices]
+            for v in vs:
+                w._check_same_shape(v)
+            rows = []
+            for p in range(len(w.piece_sizes)):
+                row = be.empty(k, self.dtype)
+                be.multi_dot([v._piece(p) for v in vs], w._piece(p), row)
+                rows.append(row)
+            per_space.append(fold(rows) if rows else torch.zeros(k, dtype=self.dtype, device=self.ctx.device))
+        if n == 1:
+            out = per_space[0]
+            self.ctx.comm.all_reduce_sum(out)
+            return out
+        # ... the spaces' results summed over the ranks in ONE all-reduce, then added left to right
+        slots = torch.stack(per_space, dim=0).contiguous()       # (spaces, k)
+        self.ctx.comm.all_reduce_sum(slots)
+        return fold([slots[i] for i in range(n)])
+
+    def multi_axpy(self, dst_index: int, coef: torch.Tensor, src_indices, negate: bool = False) -> None:
+        """dst <- dst + sum_j (+-coef[j]) src_j as the chain of axpys in ascending j, in one pass over dst
+        per group of 8 vectors; leaves the shares of dot(dst, dst) for a dot product that follows."""
+        be = self.ctx.backend
+        if coef.numel() != len(src_indices):
+            raise ValueError("one coefficient per source vector")
+        for i in range(self.get_num_spaces()):
+            dst = self.get_vector(dst_index, i)
+            srcs = [self.get_vector(v, i) for v in src_indices]
+            for v in srcs:
+                dst._check_same_shape(v)
+                if v is dst:
+                    raise ValueError("a source vector is the destination")
+            views = [[v._piece(p) for v in srcs] for p in range(len(dst.piece_sizes))]
+            dst._settle()
+            dst._touch()
+            pieces = []
+            for p in range(len(dst.piece_sizes)):
+                if not dst.piece_sizes[p]:
+                    pieces.append((None, 0))
+                    continue
+                buf = dst._partials("sq", p, be.SQNORM_SLOTS)
+                pieces.append((buf, be.multi_axpy(dst._piece(p), coef, views[p], negate, buf)))
+            dst._note_ready(dst, pieces)
+
     # -- matvec (src/SquarePlanner.hpp:340-357) ---------------------------------------------
     def _gather_ghost(self, e: _MatrixEntry, src: PartitionedVector):
         """Returns (x tensor, x_lo, x_hi, handle): the ghost instance of `src` for matrix entry

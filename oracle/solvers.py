@@ -228,7 +228,13 @@ class GMRESSolver:
     """src/GMRESSolver.hpp:32-127, including the unfinished least-squares solve: the update
     coefficient is DummyTask's constant 1 (:109-126, src/UtilityTasks.cpp:96-99)."""
 
-    def __init__(self, planner, restart):
+    def __init__(self, planner, restart, orthogonalization="modified"):
+        """orthogonalization "classical": every h_k = v_k . w of a sweep from the SAME w, then the
+        updates w <- fma(-h_k, v_k, w) in ascending k; no counterpart in the reference, which runs the
+        modified sweep (src/GMRESSolver.hpp:92-100); restated here as the checker of the planner's
+        multi_dot / multi_axpy."""
+        assert orthogonalization in ("modified", "classical")
+        self.orthogonalization = orthogonalization
         self.planner = pl = planner
         self.restart = restart
         self.dt = pl.dtype
@@ -251,9 +257,15 @@ class GMRESSolver:
         pl.scal(kb(0), residual_norm)
         for j in range(self.restart):
             pl.matvec(kb(j + 1), kb(j))
-            for k in range(j + 1):
-                self.inner_products[k][j] = pl.dot(kb(k), kb(j + 1))
-                pl.axpy(kb(j + 1), self._op("neg", self.inner_products[k][j]), kb(k))
+            if self.orthogonalization == "classical":
+                for k in range(j + 1):
+                    self.inner_products[k][j] = pl.dot(kb(k), kb(j + 1))
+                for k in range(j + 1):
+                    pl.axpy(kb(j + 1), self._op("neg", self.inner_products[k][j]), kb(k))
+            else:
+                for k in range(j + 1):
+                    self.inner_products[k][j] = pl.dot(kb(k), kb(j + 1))
+                    pl.axpy(kb(j + 1), self._op("neg", self.inner_products[k][j]), kb(k))
             d = pl.dot(kb(j + 1), kb(j + 1))
             self.inner_products[j + 1][j] = self._op("sqrt", d)
             if j + 1 < self.restart:

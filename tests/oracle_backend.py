@@ -76,6 +76,21 @@ class OracleBackend:
         self.axpy(z, futs_a, p)   # z from the old p ...
         self.xpay(p, futs_b, r)   # ... then p
 
+    MULTI_MAX = 64
+
+    def multi_dot(self, vs, w, out):
+        for j, v in enumerate(vs):
+            out[j] = float(oracle.dot(_np(v), _np(w))) if w.numel() else 0.0
+
+    def multi_axpy(self, y, coef, xs, negate, partials=None):
+        c = _np(coef)
+        for j, x in enumerate(xs):
+            oracle.axpy(-c[j] if negate else c[j], _np(x), _np(y))
+        if partials is None:
+            return 0
+        partials[0] = float(oracle.dot(_np(y), _np(y)))
+        return 1
+
     def csr_spmv_dot_slots(self, rows, nnz, dtype):
         return 1
 

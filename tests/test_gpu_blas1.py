@@ -499,3 +499,62 @@ def test_nontemporal_streams_give_the_same_bits(suf):
     v = ctypes.c_int(7)
     _lib.check(lib.lsk_get_option(b"blas1.nontemporal", ctypes.byref(v)))
     assert v.value == -1 and lib.lsk_set_option(b"blas1.nontemporal", 2) == _lib.LSK_ERR_ARG
+
+
+@pytest.mark.parametrize("suf", ["f32", "f64"])
+@pytest.mark.parametrize("offset", [0, 1])
+def test_multi_dot_and_multi_axpy(suf, offset):
+    """lsk_multi_dot_*: k dot products with one vector in one pass (groups of 8), each within the dot
+    tolerance of the exactly rounded value and bit-reproducible; lsk_multi_axpy_*: bit for bit the
+    chain of k axpys of the oracle, with the shares of the result's squared norm."""
+    npdt, tdt = DT[suf]
+    tol = 1e-13 if suf == "f64" else 2e-6
+    rng = np.random.default_rng(41)
+    lib = _lib.lib()
+    for n in (0, 1, 3, 255, 1024, 4099, (1 << 20) + 3):
+        for k in (1, 2, 7, 8, 9, 17, 31):
+            if n > 5000 and k not in (1, 9, 31):
+                continue
+            print(f"case multi {suf} n={n} k={k} offset={offset}", flush=True)
+            vs = [rng.standard_normal(n + offset).astype(npdt) for _ in range(k)]
+            w = rng.standard_normal(n + offset).astype(npdt)
+            vds, wd = [dev(v) for v in vs], dev(w)
+            ptrs = (ctypes.c_void_p * k)(*[v[offset:].data_ptr() for v in vds])
+            ws = torch.empty(int(lib.lsk_multi_dot_workspace_bytes(k)), dtype=torch.uint8, device="cuda")
+            outs = []
+            for _ in range(2):
+                out = torch.full((k + 1,), 5.0, dtype=tdt, device="cuda")
+                _lib.call(f"lsk_multi_dot_{suf}", n, k, ptrs, P(wd[offset:]), P(out), P(ws), ws.numel(), stream())
+                outs.append(out.cpu().numpy())
+            assert outs[0].tobytes() == outs[1].tobytes() and outs[0][k] == 5.0
+            for j in range(k):
+                a, b = vs[j][offset:].astype(np.float64), w[offset:].astype(np.float64)
+                assert abs(float(outs[0][j]) - float(a @ b)) <= tol * float(np.abs(a * b).sum()) + 1e-300, (n, k, j)
+            # the updates: y <- y - sum_j h_j v_j, h = the dots just computed
+            y = rng.standard_normal(n + offset).astype(npdt)
+            want = y.copy()
+            for j in range(k):
+                oracle.axpy(npdt(-outs[0][j]), np.ascontiguousarray(vs[j][offset:]), want[offset:])
+            for with_norm in (False, True):
+                yd = dev(y)
+                partials = torch.full((2048,), 7.0, dtype=tdt, device="cuda") if with_norm else None
+                count = ctypes.c_int(-1)
+                coef = dev(outs[0][:k].copy())
+                _lib.call(f"lsk_multi_axpy_{suf}", n, k, ptrs, P(coef), 1, P(yd[offset:]),
+                          P(partials) if with_norm else None, 2048 if with_norm else 0,
+                          ctypes.byref(count) if with_norm else None, stream())
+                assert np.array_equal(bits(yd.cpu().numpy()), bits(want)), (n, k, with_norm)
+                if with_norm:
+                    res = torch.zeros(1, dtype=tdt, device="cuda")
+                    _lib.call(f"lsk_sum_partials_{suf}", count.value, P(partials), P(res), None, 0, stream())
+                    exact = float(np.sum(want[offset:].astype(np.float64) ** 2))
+                    assert abs(float(res) - exact) <= tol * max(exact, 1e-300) + 1e-300
+    # refusals
+    v = dev(np.ones(16, npdt))
+    ptrs = (ctypes.c_void_p * 1)(v.data_ptr())
+    out = torch.zeros(1, dtype=tdt, device="cuda")
+    fn = getattr(lib, f"lsk_multi_dot_{suf}")
+    assert fn(16, 1, ptrs, P(v), P(out), None, 0, stream()) == _lib.LSK_ERR_ARG          # no workspace
+    assert fn(16, 65, ptrs, P(v), P(out), None, 0, stream()) == _lib.LSK_ERR_ARG         # too many vectors
+    fa = getattr(lib, f"lsk_multi_axpy_{suf}")
+    assert fa(16, 1, ptrs, P(out), 0, P(v), None, 0, None, stream()) == _lib.LSK_ERR_ARG  # a source is the destination

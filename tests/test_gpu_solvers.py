@@ -527,3 +527,27 @@ def test_write_through_a_view_is_seen_by_the_next_dot(gpu_ctx):
     fresh = PartitionedVector(gpu_ctx, "f", ip)
     fresh.assign(y)
     assert y.dot(y).get_value() == fresh.dot(fresh).get_value()
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("pieces", [1, 3])
+def test_classical_gram_schmidt_gmres_follows_its_oracle(gpu_ctx, dtype, pieces):
+    """GMRES with the classical Gram-Schmidt option (one pass over w for all inner products of a
+    sweep, one for all updates) against the oracle's restatement of that variant; parity unpinned by
+    the reference, which has only the modified sweep."""
+    rects, row, col, val, n = hc.stencil_problem(3, (12, 10, 11), dtype)
+    rhs = np.random.default_rng(70).standard_normal(n).astype(dtype)
+    print(f"case classical GMRES {np.dtype(dtype).name} pieces={pieces}", flush=True)
+    opl = hc.oracle_planner("csr", rects, row, col, val, n, pieces, dtype, rhs)
+    mpl = hc.mirror_planner(gpu_ctx, "csr", rects, row, col, val, n, pieces, dtype, rhs)
+    so, sm = S.GMRESSolver(opl, 12, "classical"), GMRESSolver(mpl, 12, "classical")
+    for _ in range(2):
+        so.step()
+        sm.step()
+    tol = 1e-9 if dtype == np.float64 else 2e-3
+    want_h = np.array([[float(v) for v in r] for r in so.inner_products])
+    got_h = np.array([[s.get_value() for s in r] for r in sm.inner_products])
+    assert np.abs(got_h - want_h).max() <= tol * np.abs(want_h).max()
+    want = opl.get_vector(0, 0).astype(np.float64)
+    got = mpl.get_vector(0, 0).to_host().numpy().astype(np.float64)
+    assert np.abs(got - want).max() <= tol * np.abs(want).max()

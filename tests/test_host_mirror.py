@@ -130,6 +130,35 @@ def test_solver_sequences_match_oracle(ctx, solver_name, dtype):
         assert [s.get_value() for s in sm.omega] == [float(v) for v in so.omega]
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("spaces", [1, 2])
+def test_classical_gram_schmidt_gmres_matches_its_oracle(ctx, dtype, spaces):
+    """GMRESSolver(orthogonalization="classical"): every inner product of a sweep from the same w
+    (SquarePlanner.multi_dot), the updates in one chain (multi_axpy), against the oracle's restatement
+    of that variant: identical results on one process (same leaf operations, same order); and not the
+    modified sweep's results."""
+    rects, row, col, val, n = hc.stencil_problem(2, (6, 7), dtype)
+    rhs = np.random.default_rng(3).standard_normal(n)
+    opl = hc.oracle_planner("csr", rects, row, col, val, n, 3, dtype, rhs, spaces=spaces)
+    mpl = hc.mirror_planner(ctx, "csr", rects, row, col, val, n, 3, dtype, rhs, spaces=spaces)
+    so, sm = S.GMRESSolver(opl, 4, "classical"), GMRESSolver(mpl, 4, "classical")
+    for _ in range(3):
+        so.step()
+        sm.step()
+    for sp in range(spaces):
+        np.testing.assert_array_equal(hc.gather_vector(ctx, mpl.get_vector(0, sp)), opl.get_vector(0, sp))
+    got = [[s.get_value() for s in r] for r in sm.inner_products]
+    want = [[float(v) for v in r] for r in so.inner_products]
+    assert got == want
+    opl2 = hc.oracle_planner("csr", rects, row, col, val, n, 3, dtype, rhs, spaces=spaces)
+    modified = S.GMRESSolver(opl2, 4)
+    for _ in range(3):
+        modified.step()
+    assert [[float(v) for v in r] for r in modified.inner_products] != want
+    with pytest.raises(ValueError):
+        GMRESSolver(mpl, 4, "householder")
+
+
 @pytest.mark.parametrize("kind", ["csr", "coo"])
 @pytest.mark.parametrize("pieces", [1, 3])
 def test_transposed_product_matches_oracle(ctx, kind, pieces, monkeypatch):
@@ -220,6 +249,12 @@ def _worker(rank, world, port, out_dir):
         solver.step()
         solver.step()
         results["gmres_sol"] = hc.gather_vector(ctx, pl.get_vector(0, 0))
+        # (c') the classical Gram-Schmidt variant: k inner products per all-reduce
+        pl = hc.mirror_planner(ctx, "csr", rects, row, col, val, n, 4, np.float64, rhs)
+        solver = GMRESSolver(pl, 3, "classical")
+        solver.step()
+        solver.step()
+        results["gmres_classical_sol"] = hc.gather_vector(ctx, pl.get_vector(0, 0))
         # (d) transposed product of an unsymmetric matrix: the halo exchange run backwards
         val_u = np.random.default_rng(7).standard_normal(val.size)
         for kind in ("csr", "coo"):
@@ -253,6 +288,11 @@ def test_two_rank_gloo_matches_oracle(tmp_path, krylov_golden):
     so.step()
     so.step()
     np.testing.assert_allclose(res["gmres_sol"], opl.get_vector(0, 0), rtol=1e-9, atol=1e-12)
+    opl = hc.oracle_planner("csr", rects, row, col, val, n, 4, np.float64, rhs)
+    so = S.GMRESSolver(opl, 3, "classical")
+    so.step()
+    so.step()
+    np.testing.assert_allclose(res["gmres_classical_sol"], opl.get_vector(0, 0), rtol=1e-9, atol=1e-12)
     val_u = np.random.default_rng(7).standard_normal(val.size)
     want = np.zeros(n)
     oracle.csr_rmatvec(rects, 0, col, val_u, rhs, 0, want, 0, n - 1)

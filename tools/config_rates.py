@@ -7,7 +7,10 @@ configuration is bench.py's):
   gmres     GMRES(30) on the 3-D 7-point stencil 768^3, fp32 CSR (a step = one restart cycle:
             31 SpMV, 496 dot, 465 axpy, 30 scal, 1 xpay, 30 axpy into the solution)
 
-    python tools/config_rates.py [cg2d] [bicgstab] [gmres]
+    python tools/config_rates.py [cg2d] [bicgstab] [gmres] [gmres_classical]
+
+(gmres_classical: the same cycle with GMRESSolver's classical Gram-Schmidt option, every inner product
+of a sweep in one pass over w: different arithmetic, the reference's sequence is `gmres`.)
 
 Prints one JSON line per configuration: steps/s, ms per step, algorithmic GB moved per step and
 the fraction of the 8 TB/s HBM peak that is."""
@@ -78,19 +81,22 @@ def main():
             # 2 SpMV (each + zero fill) + 4 dots (one of a vector with itself) + 6 axpy/xpay
             algo = 2 * (nnz * (16 + s) + rows * 3 * s + rows * s) + (3 * 2 + 1) * rows * s + 6 * 3 * rows * s
             what = f"BiCGStab, random row-sorted COO {rows} x {per}/row fp64, 1 shard"
-        elif name == "gmres":
+        elif name in ("gmres", "gmres_classical"):
             n1, s, m = 768, 4, 30
             rows = n1 ** 3
             ip = IndexPartition.equal(IndexSpace(0, rows - 1), 1)
             _, offs, cfs = sg.benchmark_stencil(3)
             A = sg.create_linearized_csr_stencil_matrix(ctx, (n1, n1, n1), offs, cfs, ip, torch.float32)
-            solver = GMRESSolver(planner_for(ctx, A, ip, torch.float32), m)
+            solver = GMRESSolver(planner_for(ctx, A, ip, torch.float32), m,
+                                 "classical" if name == "gmres_classical" else "modified")
             sec = rate(ctx, solver, 1, 3)
             spmv = A.nnz * (8 + s) + rows * (16 + 2 * s)
             dots = m * (m + 1) // 2 * 2 + (m + 1) * 1      # k-j dots read two vectors, norms one
             ew = (m * (m + 1) // 2 + m) * 3 + m * 2 + 3      # axpys, scal, xpay
             algo = (m + 1) * spmv + (dots + ew) * rows * s
-            what = f"GMRES({m}) restart cycle, 3-D 7-pt {n1}^3 fp32 CSR, 1 shard"
+            what = f"GMRES({m}) restart cycle, 3-D 7-pt {n1}^3 fp32 CSR, 1 shard" + (
+                "; classical Gram-Schmidt option (bytes counted for the reference's sequence)"
+                if name == "gmres_classical" else "")
         else:
             raise SystemExit(f"unknown configuration {name}")
         print(json.dumps({"config": name, "what": what, "steps_per_s": 1.0 / sec, "ms_per_step": sec * 1e3,
