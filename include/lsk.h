@@ -460,6 +460,42 @@ int lsk_gather_u32(int64_t n, const uint32_t *src, const uint32_t *order, uint32
 int lsk_gather_f32(int64_t n, const float *src, const uint32_t *order, float *dst, lsk_stream_t stream);
 int lsk_gather_f64(int64_t n, const double *src, const uint32_t *order, double *dst, lsk_stream_t stream);
 
+/* The binned COO product, for matrices whose columns have no locality, so that the x gathers of
+ * lsk_coo_spmv_* (a cache line through L2 per entry), not the entry stream, bound the product.
+ * Computes what COOMatvecTask computes (src/COOMatrixTasks.cpp:58-76, src/COOMatrixTasks.cu:12-43)
+ * for the entries inside the windows, on a set-up-time copy ordered by (block of columns, tile of
+ * rows), in two streaming passes: (1) a workgroup holds a block of x in LDS and writes the products
+ * val * x[col] of a run of the block's entries to a workspace; (2) a workgroup holds a tile of y in
+ * LDS and adds the tile's segments of the workspace into it.  No gathers from memory, no global
+ * atomics; 3 s + 4 bytes per entry cross HBM as contiguous streams.  Sums agree with the CPU
+ * loop to rounding (the order of the LDS additions is the hardware's, as with the reference's
+ * atomicAdd kernel).
+ *
+ * create: row32 / col32 / val as for lsk_coo_spmv_c32_* (any entry order; entries with row32
+ * outside y_first..y_last or col32 >= x_extent, or 0xffffffff, are left out).  block_cols /
+ * tile_rows: 0 for the default (128 KiB of LDS: 16384 fp64, 32768 fp32), else multiples of 8 up
+ * to that.  Set-up time: sorts, allocates the copy (padded entries x (2 s + 8) bytes, the workspace
+ * included), returns when done.  LSK_ERR_UNSUPPORTED (never an abort): nnz >= 2^31, more than
+ * 2^24 (block, tile) pairs, or no entry inside the windows.
+ * spmv: y <- A x (beta = 0) or y <- y + A x (beta = 1); `x` points at the x window's first
+ * element, `y` at row y_first.  Calls on one handle share its workspace: they must not overlap.
+ * update_values: the caller rewrote val in place (same rows and columns); one pass.
+ * info: out8 = entries inside the windows, padded entries, block_cols, tile_rows, blocks, tiles,
+ * workgroups of pass 1, non-empty segments.  No counterpart in the reference. */
+typedef struct lsk_coo_binned lsk_coo_binned_t;
+int lsk_coo_binned_create_f32(int64_t nnz, const uint32_t *row32, const uint32_t *col32, const float *val,
+                              int64_t y_first, int64_t y_last, int64_t x_extent, int block_cols, int tile_rows,
+                              lsk_stream_t stream, lsk_coo_binned_t **out);
+int lsk_coo_binned_create_f64(int64_t nnz, const uint32_t *row32, const uint32_t *col32, const double *val,
+                              int64_t y_first, int64_t y_last, int64_t x_extent, int block_cols, int tile_rows,
+                              lsk_stream_t stream, lsk_coo_binned_t **out);
+int lsk_coo_binned_spmv_f32(const lsk_coo_binned_t *m, const float *x, float *y, int beta, lsk_stream_t stream);
+int lsk_coo_binned_spmv_f64(const lsk_coo_binned_t *m, const double *x, double *y, int beta, lsk_stream_t stream);
+int lsk_coo_binned_update_values_f32(lsk_coo_binned_t *m, int64_t nnz, const float *val, lsk_stream_t stream);
+int lsk_coo_binned_update_values_f64(lsk_coo_binned_t *m, int64_t nnz, const double *val, lsk_stream_t stream);
+int lsk_coo_binned_info(const lsk_coo_binned_t *m, int64_t *out8);
+int lsk_coo_binned_destroy(lsk_coo_binned_t *m);
+
 /* The transposed product (CSRRmatvecTask / COORmatvecTask: registered by the reference,
  * src/Initialize.cpp:464-479, with bodies that are assert(false) on CPU and GPU alike,
  * src/CSRMatrixTasks.cpp:95-100, src/COOMatrixTasks.cpp:78-83, src/CSRMatrixTasks.cu:159-164) is

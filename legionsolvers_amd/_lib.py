@@ -95,6 +95,14 @@ PROTOTYPES = {
     "lsk_csr_sliced_info": (_i, [_p, _p]),
     "lsk_csr_sliced_dot_partials": (_i64, [_p, _i64, _i64]),
     "lsk_csr_sliced_destroy": (_i, [_p]),
+    "lsk_coo_binned_create_f32": (_i, [_i64, _p, _p, _p, _i64, _i64, _i64, _i, _i, _p, _p]),
+    "lsk_coo_binned_create_f64": (_i, [_i64, _p, _p, _p, _i64, _i64, _i64, _i, _i, _p, _p]),
+    "lsk_coo_binned_spmv_f32": (_i, [_p, _p, _p, _i, _p]),
+    "lsk_coo_binned_spmv_f64": (_i, [_p, _p, _p, _i, _p]),
+    "lsk_coo_binned_update_values_f32": (_i, [_p, _i64, _p, _p]),
+    "lsk_coo_binned_update_values_f64": (_i, [_p, _i64, _p, _p]),
+    "lsk_coo_binned_info": (_i, [_p, _p]),
+    "lsk_coo_binned_destroy": (_i, [_p]),
     "lsk_csr_entry_rows_u32": (_i, [_i64, _i64, _p, _i64, _p, _p]),
     "lsk_sorted_key_offsets_u32": (_i, [_i64, _p, _i64, _p, _p]),
     "lsk_inclusive_sum_i64": (_i, [_i64, _p, _p, _p]),

@@ -293,6 +293,30 @@ class HipBackend:
         _lib.check(code)
         return order
 
+    def coo_binned_create(self, row32: torch.Tensor, col32: torch.Tensor, val: torch.Tensor, y_first: int,
+                          y_last: int, x_extent: int, block_cols: int = 0, tile_rows: int = 0):
+        """The binned copy of a COO piece (a BinnedCoo) for products of the rows y_first..y_last (offsets
+        in row32's window) against the first x_extent columns of col32's window, or None when the
+        library declines (too many entries or bins, nothing inside the windows).  Synchronises."""
+        handle = ctypes.c_void_p(0)
+        code = getattr(self.lib, f"lsk_coo_binned_create_{_lib.suffix(val.dtype)}")(
+            val.numel(), _ptr(row32), _ptr(col32), _ptr(val), y_first, y_last, x_extent, block_cols, tile_rows,
+            self.stream(), ctypes.byref(handle))
+        if code == _lib.LSK_ERR_UNSUPPORTED:
+            return None
+        _lib.check(code)
+        return BinnedCoo(self.lib, handle, val.dtype, val.numel())
+
+    def coo_binned_spmv(self, binned: "BinnedCoo", x: torch.Tensor, y: torch.Tensor, beta: int) -> None:
+        """y <- A x + beta y through the binned copy; x[0] is the window's first column, y[0] row y_first."""
+        _lib.call(f"lsk_coo_binned_spmv_{_lib.suffix(binned.dtype)}", binned.handle, _ptr(x), _ptr(y), beta,
+                  self.stream())
+
+    def coo_binned_update_values(self, binned: "BinnedCoo", val: torch.Tensor) -> None:
+        """Copies the entry values into the binned copy again (same rows and columns, new values)."""
+        _lib.call(f"lsk_coo_binned_update_values_{_lib.suffix(binned.dtype)}", binned.handle, val.numel(), _ptr(val),
+                  self.stream())
+
     def gather(self, src: torch.Tensor, order: torch.Tensor) -> torch.Tensor:
         """src[order] for the 32-bit index fields and the entry values."""
         kind = "u32" if src.dtype == torch.int32 else _lib.suffix(src.dtype)
@@ -356,6 +380,34 @@ class HipBackend:
         if not bool(live.any()):
             return (0, -1)
         return int(lo[live].min().item()), int(hi[live].max().item())
+
+
+class BinnedCoo:
+    """Owner of one lsk_coo_binned_t (device memory held by the library, freed with this object)."""
+
+    def __init__(self, lib, handle, dtype, nnz):
+        self.lib, self.handle, self.dtype, self.nnz = lib, handle, dtype, nnz
+        out = (ctypes.c_int64 * 8)()
+        _lib.check(lib.lsk_coo_binned_info(handle, out))
+        (self.live, self.padded_entries, self.block_cols, self.tile_rows, self.blocks, self.tiles, self.units,
+         self.segments) = (int(v) for v in out)
+
+    def own_bytes(self, rows: int, x_extent: int, elem_size: int) -> int:
+        """Bytes one product moves on this layout: pass 1 reads value + column offset and writes the
+        product, pass 2 reads product + row offset; x and y once each, 8 per segment, 12 per unit."""
+        return (self.padded_entries * (3 * elem_size + 4) + (rows + x_extent) * elem_size + self.segments * 8
+                + self.units * 12)
+
+    def close(self) -> None:
+        if self.handle:
+            self.lib.lsk_coo_binned_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class SlicedStructure:

@@ -16,7 +16,7 @@ CSRC_DIR = os.path.join(PKG_DIR, "csrc")
 INCLUDE_DIR = os.path.join(REPO_DIR, "include")
 LIB_PATH = os.path.join(PKG_DIR, "liblsk.so")
 
-SOURCES = ["shim.hip", "blas1.hip", "csr_spmv.hip", "sliced_spmv.hip", "coo_spmv.hip", "setup.hip", "comm.hip"]
+SOURCES = ["shim.hip", "blas1.hip", "csr_spmv.hip", "sliced_spmv.hip", "coo_spmv.hip", "coo_binned.hip", "setup.hip", "comm.hip"]
 HEADERS = [os.path.join(CSRC_DIR, "lsk_common.hpp"), os.path.join(INCLUDE_DIR, "lsk.h")]
 
 ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")

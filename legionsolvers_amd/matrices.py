@@ -664,6 +664,9 @@ class COOMatrix(AbstractMatrix, _SlicedCopies):
         self.row32 = self.col32 = None  # compress(): 32-bit copies of the index fields ...
         self.col32_window = None        # ... for this x window (x_lo, x_hi) ...
         self.row_origin = 0             # ... and rows counted from this global row
+        self.binned = None              # the binned copy (lsk_coo_binned_*) of the one local piece ...
+        self.binned_window = None       # ... for this x window
+        self.binned_color = None
         self._init_sliced()
 
     def compress(self, x_lo: int, x_hi: int, kernel_partition, range_partition) -> bool:
@@ -728,15 +731,20 @@ class COOMatrix(AbstractMatrix, _SlicedCopies):
 
     BLOCK_BYTES = 4 << 20        # of x per column block: what one XCD's L2 holds beside the stream
     BLOCK_MIN_WINDOW = 16 << 20  # smaller x windows are not worth re-ordering for
+    BINNED_BLOCK_COLS = 0        # columns per block / rows per tile of the binned copy: 0 = the library's choice
+    BINNED_TILE_ROWS = 0
 
     def _try_column_blocks(self, x_lo, x_hi, kernel_partition, range_partition) -> None:
         """For a matrix whose x gathers have no locality (sampled: nearly every entry of a run
         touches a cache line of its own) and whose x window is far larger than L2, time the
-        product once more with the entries re-ordered by blocks of columns (a block of x then
-        stays in L2 while its entries stream by) and keep the faster order.  Measured on the
-        random 32-per-row matrix of 15.6 M rows: 9.7 -> 5.6 ms.  Only with one local piece (a
-        re-ordered matrix has no contiguous run of entries per piece).  LSK_COO_BLOCK=0 turns it
-        off, =1 skips the probe and the timing."""
+        product in two more forms and keep the fastest: the binned copy (two streaming passes with
+        a block of x, then a tile of y, in LDS; lsk_coo_binned_*) and the scan kernel on entries
+        re-ordered by blocks of columns (a block of x then stays in L2 while its entries stream
+        by).  Measured on the random 32-per-row matrix of 15.6 M rows: 9.7 ms in row order, 5.1 ms
+        column-blocked, 2.6 ms binned.  Only with one local piece (a re-ordered matrix has no
+        contiguous run of entries per piece).  LSK_COO_BLOCK=0 turns both off, =1 skips the probe
+        and the timing of the row order; LSK_COO_BINNED=0 leaves the binned copy out, =2 takes it
+        without timing anything."""
         be = self.ctx.backend
         mode = os.environ.get("LSK_COO_BLOCK", "auto")
         esz = self.val.element_size()
@@ -750,35 +758,56 @@ class COOMatrix(AbstractMatrix, _SlicedCopies):
             lines = torch.unique(sample // (128 // esz)).numel()
             if lines < 0.5 * sample.numel():
                 return  # neighbouring entries share cache lines of x: the row order is fine
-        order = be.coo_block_order(self.col32, x_hi - x_lo + 1, self.BLOCK_BYTES // esz)
-        if order is None:
-            return
-        blocked = tuple(be.gather(t, order) for t in (self.row32, self.col32, self.val))
         c = kernel_partition.colors[0]
         p = range_partition.pieces[c]
         y_lo, y_hi = p.lo[0] - self.row_origin, p.hi[0] - self.row_origin
+        x = torch.zeros(x_hi - x_lo + 1, dtype=self.dtype, device=self.val.device)
+        y = torch.zeros(p.volume, dtype=self.dtype, device=self.val.device)
 
-        def timed(row32, col32, val) -> float:
-            x = torch.zeros(x_hi - x_lo + 1, dtype=self.dtype, device=self.val.device)
-            y = torch.zeros(p.volume, dtype=self.dtype, device=self.val.device)
+        def timed(launch) -> float:
             t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            be.coo_spmv(self.nnz, row32, col32, val, x, x_lo, x_hi, y, y_lo, y_hi)
+            launch()
             t0.record()
             for _ in range(3):
-                be.coo_spmv(self.nnz, row32, col32, val, x, x_lo, x_hi, y, y_lo, y_hi)
+                launch()
             t1.record()
             t1.synchronize()
             return t0.elapsed_time(t1) / 3
 
-        t_blocked = timed(*blocked)
-        t_rows = timed(self.row32, self.col32, self.val) if mode != "1" else float("inf")
+        def scan(row32, col32, val):
+            return lambda: be.coo_spmv(self.nnz, row32, col32, val, x, x_lo, x_hi, y, y_lo, y_hi)
+
+        times = {}
+        if mode != "1":
+            times["rows"] = timed(scan(self.row32, self.col32, self.val))
+        binned = None
+        binned_mode = os.environ.get("LSK_COO_BINNED", "1")
+        if binned_mode != "0" and getattr(be, "coo_binned_create", None) is not None:
+            binned = be.coo_binned_create(self.row32, self.col32, self.val, y_lo, y_hi, x_hi - x_lo + 1,
+                                          self.BINNED_BLOCK_COLS, self.BINNED_TILE_ROWS)
+            if binned is not None:
+                times["binned"] = 0.0 if binned_mode == "2" else timed(lambda: be.coo_binned_spmv(binned, x, y, 0))
+        order = None
+        if not (binned is not None and binned_mode == "2"):
+            order = be.coo_block_order(self.col32, x_hi - x_lo + 1, self.BLOCK_BYTES // esz)
+        blocked = None
+        if order is not None:
+            blocked = tuple(be.gather(t, order) for t in (self.row32, self.col32, self.val))
+            times["column blocks"] = timed(scan(*blocked))
         if os.environ.get("LSK_TUNE_VERBOSE"):
-            print(f"[lsk] COO entry order: rows {t_rows:.3f} ms, column blocks {t_blocked:.3f} ms",
+            print("[lsk] COO forms: " + ", ".join(f"{k} {v:.3f} ms" for k, v in times.items()),
                   file=sys.stderr, flush=True)
-        if t_blocked < t_rows:
+        best = min(times, key=times.get) if times else "rows"
+        if best == "binned":
+            self.binned = binned
+            self.binned_window = (int(x_lo), int(x_hi))
+            self.binned_color = c
+        elif best == "column blocks":
             self.row32, self.col32, self.val_blocked = blocked
             self.blocked = True
             self._block_order = order  # kept for values_changed(): 4 bytes per entry
+        if best != "binned" and binned is not None:
+            binned.close()
 
     def values_changed(self) -> None:
         """To be called after the entries were rewritten in place in the `val` tensor (same rows and
@@ -787,6 +816,8 @@ class COOMatrix(AbstractMatrix, _SlicedCopies):
         The reference's task reads the region on every call (src/COOMatrixTasks.cu:86-145)."""
         if self.blocked:
             self.val_blocked = self.ctx.backend.gather(self.val, self._block_order)
+        if self.binned is not None:
+            self.ctx.backend.coo_binned_update_values(self.binned, self.val)
         self._refill_sliced_copies()
         self._transposed = None
 
@@ -815,8 +846,10 @@ class COOMatrix(AbstractMatrix, _SlicedCopies):
         """Whether matvec(beta = 0) is available: every local piece that has rows is multiplied
         through its sliced-pattern copy, which can start a row's sum from zero (the zero fill the
         reference does before an accumulating product, src/SquarePlanner.hpp:341, then falls away)."""
-        return self.sliced_window == (x_lo, x_hi) and all(
-            c in self.sliced for c in kernel_partition.colors if range_partition.pieces[c].volume > 0)
+        live = [c for c in kernel_partition.colors if range_partition.pieces[c].volume > 0]
+        if self.binned is not None and self.binned_window == (x_lo, x_hi) and live == [self.binned_color]:
+            return True  # (the binned copy's second pass writes every row of the piece)
+        return self.sliced_window == (x_lo, x_hi) and all(c in self.sliced for c in live)
 
     def matvec(self, dst, x, x_lo, x_hi, kernel_partition, beta=1, range_partition=None):
         """COOMatrix::matvec (src/COOMatrix.cpp:144-191): accumulates; dst must hold the
@@ -836,6 +869,9 @@ class COOMatrix(AbstractMatrix, _SlicedCopies):
             if c in self.sliced and self.sliced_window == (x_lo, x_hi):
                 self.ctx.backend.csr_sliced_spmv(self.sliced[c], 0, p.volume, x, dst._piece(i), beta,
                                                  self.sliced_placement.get(c, 0))
+                continue
+            if self.binned is not None and self.binned_window == (x_lo, x_hi) and c == self.binned_color:
+                self.ctx.backend.coo_binned_spmv(self.binned, x, dst._piece(i), beta)
                 continue
             if self.blocked and self.col32_window == (x_lo, x_hi):
                 # (one local piece) every entry is visited; the row window selects, as always

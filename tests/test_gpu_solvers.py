@@ -278,6 +278,7 @@ def test_column_blocked_coo_follows_the_oracle(gpu_ctx, monkeypatch):
     set-up (forced here; normally probed and timed): BiCGStab still follows the oracle."""
     from legionsolvers_amd import COOMatrix
     monkeypatch.setenv("LSK_COO_BLOCK", "1")
+    monkeypatch.setenv("LSK_COO_BINNED", "0")
     monkeypatch.setattr(COOMatrix, "BLOCK_MIN_WINDOW", 0)
     monkeypatch.setattr(COOMatrix, "BLOCK_BYTES", 1 << 12)
     rng = np.random.default_rng(36)
@@ -300,6 +301,51 @@ def test_column_blocked_coo_follows_the_oracle(gpu_ctx, monkeypatch):
     want = opl.get_vector(0, 0)
     got = mpl.get_vector(0, 0).to_host().numpy()
     assert np.abs(got - want).max() <= 1e-9 * np.abs(want).max()
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("shuffled", [False, True])
+def test_binned_coo_follows_the_oracle(gpu_ctx, monkeypatch, dtype, shuffled):
+    """An unstructured COO matrix multiplied through the binned copy (forced here; normally timed
+    against the other forms at set-up), with blocks and tiles small enough that the matrix has
+    dozens of each: BiCGStab follows the oracle, and the planner drops the zero fill in front of the
+    product (the second pass writes every row)."""
+    from legionsolvers_amd import COOMatrix
+    monkeypatch.setenv("LSK_COO_BLOCK", "1")
+    monkeypatch.setenv("LSK_COO_BINNED", "2")
+    monkeypatch.setattr(COOMatrix, "BLOCK_MIN_WINDOW", 0)
+    monkeypatch.setattr(COOMatrix, "BINNED_BLOCK_COLS", 256)
+    monkeypatch.setattr(COOMatrix, "BINNED_TILE_ROWS", 512)
+    rng = np.random.default_rng(37)
+    n, per = 6000, 12
+    row = np.repeat(np.arange(n), per).astype(np.int64)
+    col = rng.integers(0, n, size=n * per).astype(np.int64)
+    col[::per] = np.arange(n)                      # a dominant diagonal keeps the system well posed
+    val = rng.uniform(-1, 1, size=n * per).astype(dtype)
+    val[::per] = 2.0 * per
+    if shuffled:
+        order = rng.permutation(val.size)
+        row, col, val = row[order], col[order], val[order]
+    rhs = rng.standard_normal(n).astype(dtype)
+    print(f"case binned coo {np.dtype(dtype).name} shuffled={shuffled}", flush=True)
+    opl = hc.oracle_planner("coo", None, row, col, val, n, 1, dtype, rhs)
+    mpl = hc.mirror_planner(gpu_ctx, "coo", None, row, col, val, n, 1, dtype, rhs)
+    matrix = mpl.row_partitioned_matrices[0].matrix
+    assert matrix.binned is not None and not matrix.blocked
+    assert matrix.binned.blocks == -(-n // 256) and matrix.binned.tiles == -(-n // 512)
+    so, sm = S.BiCGStabSolver(opl), BiCGStabSolver(mpl)
+    for _ in range(5):
+        so.step()
+        sm.step()
+    rtol = 1e-9 if dtype == np.float64 else 2e-3
+    # (in fp32 the later rho are differences of nearly equal numbers six orders below the largest:
+    # an absolute bar of a few ulps of that one beside the relative bar)
+    rho_want = [float(v) for v in so.rho]
+    np.testing.assert_allclose([s.get_value() for s in sm.rho], rho_want, rtol=rtol,
+                               atol=0.0 if dtype == np.float64 else 2e-6 * max(abs(v) for v in rho_want))
+    want = opl.get_vector(0, 0)
+    got = mpl.get_vector(0, 0).to_host().numpy()
+    assert np.abs(got - want).max() <= rtol * np.abs(want).max()
 
 
 @pytest.mark.parametrize("kind", ["csr", "coo"])
@@ -448,7 +494,7 @@ def test_row_sorted_coo_stencil_gets_the_sliced_copy(gpu_ctx, monkeypatch, piece
         np.testing.assert_allclose(h, [float(v) for v in so.residual_norm_squared], rtol=1e-10)
 
 
-@pytest.mark.parametrize("kind,sliced", [("csr", "1"), ("csr", "0"), ("coo", "1"), ("coo", "blocked")])
+@pytest.mark.parametrize("kind,sliced", [("csr", "1"), ("csr", "0"), ("coo", "1"), ("coo", "blocked"), ("coo", "binned")])
 def test_values_changed_brings_every_copy_up_to_date(gpu_ctx, monkeypatch, kind, sliced):
     """Set-up may move the arrays (placement redraws) and keeps copies of the values (sliced-pattern
     copy, column-blocked COO order, the transpose); the reference's tasks read the region on every call
@@ -459,10 +505,13 @@ def test_values_changed_brings_every_copy_up_to_date(gpu_ctx, monkeypatch, kind,
     monkeypatch.setattr(COOMatrix, "TUNE_MIN_ROWS", 1)
     monkeypatch.setenv("LSK_TUNE_REDRAWS", "2")
     rng = np.random.default_rng(60)
-    if sliced == "blocked":
+    if sliced in ("blocked", "binned"):
         monkeypatch.setenv("LSK_COO_BLOCK", "1")
+        monkeypatch.setenv("LSK_COO_BINNED", "2" if sliced == "binned" else "0")
         monkeypatch.setattr(COOMatrix, "BLOCK_MIN_WINDOW", 0)
         monkeypatch.setattr(COOMatrix, "BLOCK_BYTES", 1 << 12)
+        monkeypatch.setattr(COOMatrix, "BINNED_BLOCK_COLS", 512)
+        monkeypatch.setattr(COOMatrix, "BINNED_TILE_ROWS", 256)
         n, per = 6000, 12
         rects = None
         row = np.repeat(np.arange(n), per).astype(np.int64)
@@ -480,6 +529,8 @@ def test_values_changed_brings_every_copy_up_to_date(gpu_ctx, monkeypatch, kind,
     matrix = mpl.row_partitioned_matrices[0].matrix
     if sliced == "blocked":
         assert matrix.blocked
+    elif sliced == "binned":
+        assert matrix.binned is not None
     else:
         assert bool(matrix.sliced) == (sliced == "1")
     given = matrix._val_given if kind == "csr" else matrix.val
