@@ -473,8 +473,9 @@ int lsk_gather_f64(int64_t n, const double *src, const uint32_t *order, double *
  *
  * create: row32 / col32 / val as for lsk_coo_spmv_c32_* (any entry order; entries with row32
  * outside y_first..y_last or col32 >= x_extent, or 0xffffffff, are left out).  block_cols /
- * tile_rows: 0 for the default (128 KiB of LDS: 16384 fp64, 32768 fp32), else multiples of 8 up
- * to that.  Set-up time: sorts, allocates the copy (padded entries x (2 s + 8) bytes, the workspace
+ * tile_rows: 0 for the library's choice (blocks of 128 KiB of x; the largest tiles that make a
+ * whole number of rounds over the CUs), else multiples of 8 up to 20472 (fp32 blocks: 40952).  The
+ * tile of y is held and summed in fp64 for both types and rounded once at the end.  Set-up time: sorts, allocates the copy (padded entries x (2 s + 8) bytes, the workspace
  * included), returns when done.  LSK_ERR_UNSUPPORTED (never an abort): nnz >= 2^31, more than
  * 2^24 (block, tile) pairs, or no entry inside the windows.
  * spmv: y <- A x (beta = 0) or y <- y + A x (beta = 1); `x` points at the x window's first

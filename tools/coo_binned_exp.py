@@ -67,6 +67,15 @@ if os.environ.get("LSK_EXP_SCAN", "1") != "0":
 else:
     y_scan = None
 
+n_cal = 1 << 27      # a stream of known size beside the products, to calibrate hardware counters against
+cal_a = torch.rand(n_cal, dtype=torch.float64, device="cuda")
+cal_b = torch.rand(n_cal, dtype=torch.float64, device="cuda")
+cal_out = torch.empty(1, dtype=torch.float64, device="cuda")
+for _ in range(3):
+    be.dot(cal_a, cal_b, cal_out)
+print(f"dot_bytes={2 * n_cal * 8}", flush=True)
+del cal_a, cal_b
+
 for bc, tr in shapes:
     t0 = time.perf_counter()
     b = be.coo_binned_create(row32, col32, val, 0, rows - 1, rows, bc, tr)
@@ -84,6 +93,10 @@ for bc, tr in shapes:
           f"{c32_bytes / t / 1e9:.2f} TB/s of the 32-bit layout's {c32_bytes / 1e9:.2f} GB, "
           f"{own / t / 1e9:.2f} TB/s of its own {own / 1e9:.2f} GB; set-up {setup:.2f} s; "
           f"max rel diff vs scan {diff:.2e}", flush=True)
+    p1 = b.padded_entries * (2 * esz + 2) + rows * esz + b.units * 16
+    p2 = b.padded_entries * (esz + 2) + rows * esz + b.segments * 8
+    print(f"binned_bytes pass1={p1} pass2={p2} c32_layout={c32_bytes} rows={rows} nnz={nnz} padded={b.padded_entries}",
+          flush=True)
     b.close()
     del b
     torch.cuda.empty_cache()

@@ -16,7 +16,7 @@ for n in "$@"; do
     timeout -k 10 200 python -u -m pytest tests/test_gpu_coo_binned.py -x -q --timeout 120 --timeout-method thread > gpurun_out/binned_variant_$n.log 2>&1 || { echo "tests failed on $n"; tail -20 gpurun_out/binned_variant_$n.log; exit 1; }
   fi
   rm -rf /tmp/bprof_$n; cd /tmp
-  timeout -s KILL 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/bprof_$n -- python3 $R/tools/coo_binned_exp.py f64 $SHAPE > /tmp/bprof_$n.log 2>&1 || { echo "timing failed on $n"; tail -5 /tmp/bprof_$n.log; exit 1; }
+  timeout -s KILL 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/bprof_$n -- python3 $R/tools/coo_binned_exp.py ${DT:-f64} $SHAPE > /tmp/bprof_$n.log 2>&1 || { echo "timing failed on $n"; tail -5 /tmp/bprof_$n.log; exit 1; }
   grep binned /tmp/bprof_$n.log | sed 's/(.*padded [0-9.%]*)//; s/of the 32-bit.*//'
   python3 - "$n" <<'PY'
 import csv, glob, sys
