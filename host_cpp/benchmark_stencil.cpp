@@ -7,7 +7,9 @@
 // -compress 0 / -sliced 0 / -fuse 0 / -redraws 0 turn the 32-bit structure, the sliced-pattern copy,
 // the held-back updates and the set-up-time array redraws off, -adjoint N (after the solve) multiplies the solution by the
 // transpose and prints it against the product itself (the stencil matrices are symmetric) and both
-// sides of <A x, b> = <x, A^T b>; N > 1 transposes in runs of N entries.
+// sides of <A x, b> = <x, A^T b>; N > 1 transposes in runs of N entries; -binned 1 (with -coo 1) multiplies
+// through the binned copy of the COO matrix, in blocks of -bincols columns and tiles of -binrows rows
+// (0: the library's choice); -cgs 1 gives GMRES the classical Gram-Schmidt option.
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -24,6 +26,7 @@ namespace {
 struct Args {
     long dim = 1, solver = 1, nx = 16, ny = 16, nz = 16, vp = 4, it = 20, pt = 1;
     long systems = 2, coo = 0, f32 = 0, restart = 10, history = 0, compress = 1, fuse = 1, redraws = 4, adjoint = 0, sliced = 1;
+    long binned = 0, bincols = 0, binrows = 0, cgs = 0;
 };
 
 Args parse(int argc, char **argv) {
@@ -34,7 +37,8 @@ Args parse(int argc, char **argv) {
         {"-systems", &Args::systems}, {"-coo", &Args::coo}, {"-f32", &Args::f32}, {"-restart", &Args::restart},
         {"-history", &Args::history}, {"-compress", &Args::compress}, {"-fuse", &Args::fuse},
         {"-redraws", &Args::redraws}, {"-adjoint", &Args::adjoint},
-        {"-sliced", &Args::sliced}};
+        {"-sliced", &Args::sliced}, {"-binned", &Args::binned}, {"-bincols", &Args::bincols},
+        {"-binrows", &Args::binrows}, {"-cgs", &Args::cgs}};
     for (int i = 1; i + 1 < argc; i += 2) {
         bool known = false;
         for (const auto &t : table)
@@ -111,9 +115,12 @@ template <typename T> int main_typed(const Args &a) {
     const EqualPartition partition(rows, static_cast<int>(a.vp));
 
     std::unique_ptr<AbstractMatrix<T>> matrix;
-    if (a.coo)
-        matrix = std::make_unique<COOMatrix<T>>(create_linearized_coo_stencil_matrix<T>(ctx, extent, st, partition));
-    else {
+    if (a.coo) {
+        auto coo = std::make_unique<COOMatrix<T>>(create_linearized_coo_stencil_matrix<T>(ctx, extent, st, partition));
+        if (a.binned && !coo->bin(static_cast<int>(a.bincols), static_cast<int>(a.binrows)))
+            throw std::runtime_error("the binned copy was declined");
+        matrix = std::move(coo);
+    } else {
         auto csr = std::make_unique<CSRMatrix<T>>(create_linearized_csr_stencil_matrix<T>(
             ctx, extent, st, partition, a.compress != 0, static_cast<int>(a.redraws), a.sliced != 0));
         if (a.adjoint > 1) csr->transpose_chunk = a.adjoint;
@@ -142,7 +149,7 @@ template <typename T> int main_typed(const Args &a) {
         BiCGStabSolver<T> solver(planner);
         run<T>(ctx, a, solver, planner);
     } else if (a.solver == 3) {
-        GMRESSolver<T> solver(planner, static_cast<int>(a.restart));
+        GMRESSolver<T> solver(planner, static_cast<int>(a.restart), a.cgs != 0);
         run<T>(ctx, a, solver, planner);
     } else {
         std::cout << "INVALID SOLVER" << std::endl;

@@ -49,6 +49,11 @@ template <typename T> struct Abi;
         static constexpr auto csr_spmv_c32_tune = lsk_csr_spmv_c32_tune_##SUF;                     \
         static constexpr auto csr_spmv_tune = lsk_csr_spmv_tune_##SUF;                             \
         static constexpr auto coo_spmv = lsk_coo_spmv_##SUF;                                       \
+        static constexpr auto coo_binned_create = lsk_coo_binned_create_##SUF;                     \
+        static constexpr auto coo_binned_spmv = lsk_coo_binned_spmv_##SUF;                         \
+        static constexpr auto coo_binned_update_values = lsk_coo_binned_update_values_##SUF;       \
+        static constexpr auto multi_dot = lsk_multi_dot_##SUF;                                     \
+        static constexpr auto multi_axpy = lsk_multi_axpy_##SUF;                                   \
         static constexpr auto gather = lsk_gather_##SUF;                                           \
         static constexpr auto csr_sliced_create = lsk_csr_sliced_create_##SUF;                     \
         static constexpr auto csr_sliced_spmv = lsk_csr_sliced_spmv_##SUF;                         \
@@ -326,6 +331,44 @@ public:
                               ctx_->workspace_bytes(), ctx_->stream()));
         check(Abi<T>::sum_scalars(part_.colors(), slots_.get(), out.writable(), ctx_->stream()));
         return out;
+    }
+
+    // k dot products with this vector in one pass over it per 8 vectors: out[j] (device) <- v[j] . this,
+    // each equal, bit for bit, to v[j]->dot(*this).  `rows` is scratch of k * colours values.
+    void multi_dot_into(const std::vector<const PartitionedVector *> &v, T *out, T *rows, void *workspace,
+                        size_t workspace_bytes) const {
+        const int k = static_cast<int>(v.size());
+        std::vector<const T *> ptrs(k);
+        int live = 0;
+        for (int c = 0; c < part_.colors(); ++c) {
+            if (part_.volume(c) <= 0) continue;
+            for (int j = 0; j < k; ++j) {
+                same_partition(*v[j]);
+                ptrs[j] = v[j]->piece(c);
+            }
+            check(Abi<T>::multi_dot(part_.volume(c), k, ptrs.data(), piece(c), live == 0 ? out : rows + static_cast<int64_t>(live) * k,
+                                    workspace, workspace_bytes, ctx_->stream()));
+            // the pieces' results are added in colour order, as dot() adds them
+            if (live > 0)
+                for (int j = 0; j < k; ++j)
+                    check(Abi<T>::scalar_op(LSK_SOP_ADD, out + j, rows + static_cast<int64_t>(live) * k + j, out + j, ctx_->stream()));
+            ++live;
+        }
+        if (live == 0) check(Abi<T>::fill(k, T(0), out, ctx_->stream()));
+    }
+    // this <- this -+ sum_j coef[j] x[j], element for element the chain of axpys in ascending j.
+    void multi_axpy(const std::vector<const PartitionedVector *> &x, const T *coef_dev, bool negate) {
+        const int k = static_cast<int>(x.size());
+        std::vector<const T *> ptrs(k);
+        each([&](int c) {
+            for (int j = 0; j < k; ++j) {
+                same_partition(*x[j]);
+                if (x[j] == this) throw std::invalid_argument("a source vector is the destination");
+                ptrs[j] = x[j]->piece(c);
+            }
+            check(Abi<T>::multi_axpy(part_.volume(c), k, ptrs.data(), coef_dev, negate ? 1 : 0, piece(c), nullptr, 0, nullptr,
+                                     ctx_->stream()));
+        });
     }
 
 private:
@@ -737,8 +780,41 @@ public:
               DeviceArray<int64_t> col, DeviceArray<T> val, std::vector<std::pair<int64_t, int64_t>> piece_entries)
         : ctx_(&ctx), range_(range), domain_(domain_size), row_(std::move(row)), col_(std::move(col)),
           val_(std::move(val)), entries_(std::move(piece_entries)) {}
-    bool accumulates_only() const override { return true; }
+    ~COOMatrix() override {
+        if (binned_) lsk_coo_binned_destroy(binned_);
+    }
+    COOMatrix(COOMatrix &&o) noexcept
+        : ctx_(o.ctx_), range_(std::move(o.range_)), domain_(o.domain_), row_(std::move(o.row_)), col_(std::move(o.col_)),
+          val_(std::move(o.val_)), entries_(std::move(o.entries_)), transposed_(std::move(o.transposed_)), binned_(o.binned_) {
+        o.binned_ = nullptr;
+    }
+    // The set-up-time binned copy (lsk_coo_binned_*) over all rows: for matrices whose columns have no
+    // locality.  Products then go through it and may overwrite (beta = 0).  False: the library declined.
+    bool bin(int block_cols = 0, int tile_rows = 0) {
+        DeviceArray<uint32_t> row32(row_.size()), col32(col_.size());
+        check(lsk_csr_compress_cols_u32(row_.size(), row_.get(), 0, range_.n - 1, row32.get(), ctx_->stream()));
+        check(lsk_csr_compress_cols_u32(col_.size(), col_.get(), 0, domain_ - 1, col32.get(), ctx_->stream()));
+        lsk_coo_binned_t *handle = nullptr;
+        const int status = Abi<T>::coo_binned_create(val_.size(), row32.get(), col32.get(), val_.get(), 0, range_.n - 1,
+                                                     domain_, block_cols, tile_rows, ctx_->stream(), &handle);
+        if (status == LSK_ERR_UNSUPPORTED) return false;
+        check(status);
+        if (binned_) lsk_coo_binned_destroy(binned_);
+        binned_ = handle;
+        return true;
+    }
+    // After the entries were rewritten in place (same rows and columns): refresh the copies.
+    void values_changed() {
+        if (binned_) check(Abi<T>::coo_binned_update_values(binned_, val_.size(), val_.get(), ctx_->stream()));
+        transposed_.reset();
+    }
+    T *values() { return val_.get(); }
+    bool accumulates_only() const override { return binned_ == nullptr; }
     void matvec(PartitionedVector<T> &dst, const PartitionedVector<T> &src, int beta) const override {
+        if (binned_) {
+            check(Abi<T>::coo_binned_spmv(binned_, src.data(), dst.data(), beta, ctx_->stream()));
+            return;
+        }
         if (beta != 1) throw std::invalid_argument("COO matvec accumulates (beta = 1)");
         for (int c = 0; c < range_.colors(); ++c) {
             if (range_.volume(c) <= 0 || entries_[c].second <= 0) continue;
@@ -769,6 +845,7 @@ private:
     DeviceArray<T> val_;
     std::vector<std::pair<int64_t, int64_t>> entries_;
     mutable std::unique_ptr<Transposed<T>> transposed_;
+    lsk_coo_binned_t *binned_ = nullptr;
 };
 
 // SquarePlanner<T> (src/SquarePlanner.hpp): the solution / right-hand-side / workspace vectors of
@@ -856,6 +933,43 @@ public:
         for (size_t s = 1; s < vectors_[v].size(); ++s) acc = acc + one(s);
         return acc;
     }
+    // k dot products with one vector in one pass over it per 8 vectors: out[j] = dot(vs[j], w), bit for
+    // bit.  The results are k device scalars in a buffer of the planner that the next multi_dot
+    // reuses (everything is ordered on one stream); `coefficients()` is that buffer, for multi_axpy.
+    // The reference's planner has no such method (its GMRES takes its inner products one by one,
+    // src/GMRESSolver.hpp:92-100).
+    const T *multi_dot(const std::vector<int> &vs, int w) {
+        pending_.reset();
+        const int k = static_cast<int>(vs.size());
+        if (k < 1 || k > 64) throw std::invalid_argument("multi_dot takes 1..64 vectors");
+        const size_t spaces = vectors_.at(w).size();
+        int colours = 1;
+        for (auto *v : vectors_[w]) colours = std::max(colours, v->partition().colors());
+        if (multi_out_.size() < k) multi_out_ = DeviceArray<T>(64);
+        if (multi_rows_.size() < static_cast<int64_t>(64) * (colours + 1)) multi_rows_ = DeviceArray<T>(64 * (colours + 1));
+        const size_t bytes = lsk_multi_dot_workspace_bytes(64);
+        if (multi_workspace_.size() < static_cast<int64_t>(bytes)) multi_workspace_ = DeviceArray<unsigned char>(bytes);
+        for (size_t s = 0; s < spaces; ++s) {
+            std::vector<const PartitionedVector<T> *> v(k);
+            for (int j = 0; j < k; ++j) v[j] = vectors_.at(vs[j])[s];
+            // space 0 writes the result, the others are added to it in order, as dot() adds the spaces
+            T *out = s == 0 ? multi_out_.get() : multi_rows_.get();
+            vectors_[w][s]->multi_dot_into(v, out, multi_rows_.get() + 64, multi_workspace_.get(), bytes);
+            if (s > 0)
+                for (int j = 0; j < k; ++j)
+                    check(Abi<T>::scalar_op(LSK_SOP_ADD, multi_out_.get() + j, out + j, multi_out_.get() + j, ctx_->stream()));
+        }
+        return multi_out_.get();
+    }
+    // dst <- dst -+ sum_j coef[j] vs[j] (coef: k device scalars, e.g. what multi_dot returned).
+    void multi_axpy(int dst, const T *coef_dev, const std::vector<int> &vs, bool negate) {
+        pending_.reset();
+        for (size_t s = 0; s < vectors_.at(dst).size(); ++s) {
+            std::vector<const PartitionedVector<T> *> x(vs.size());
+            for (size_t j = 0; j < vs.size(); ++j) x[j] = vectors_.at(vs[j])[s];
+            vectors_[dst][s]->multi_axpy(x, coef_dev, negate);
+        }
+    }
     void matvec(int dst, int src) {
         pending_.reset();
         const size_t spaces = vectors_.at(dst).size();
@@ -916,6 +1030,8 @@ private:
     std::vector<Entry> matrices_;
     mutable std::optional<Pending> pending_;
     mutable std::vector<DeviceArray<T>> share_buffers_;
+    DeviceArray<T> multi_out_, multi_rows_;
+    DeviceArray<unsigned char> multi_workspace_;
 };
 
 // CGSolver<T> (src/CGSolver.hpp:13-57).
@@ -991,8 +1107,11 @@ private:
 template <typename T> class GMRESSolver {
 public:
     static constexpr int SOL = 0, RHS = 1;
-    GMRESSolver(SquarePlanner<T> &planner, int restart_length)
-        : pl(planner), restart(restart_length), negative_one(planner.get_context(), T(-1)),
+    // classical = false: the reference's modified Gram-Schmidt sweep (:92-100).  true: every inner
+    // product of a step from the same vector (SquarePlanner::multi_dot / multi_axpy): about half the
+    // vector traffic, different arithmetic -- an option, never the default.
+    GMRESSolver(SquarePlanner<T> &planner, int restart_length, bool classical = false)
+        : pl(planner), restart(restart_length), classical_(classical), negative_one(planner.get_context(), T(-1)),
           dummy_coefficient(planner.get_context(), T(1)) {
         pl.allocate_workspace(restart + 1);
     }
@@ -1003,9 +1122,16 @@ public:
         pl.scal(krylov_basis(0), {pl.dot(krylov_basis(0), krylov_basis(0)).rsqrt()});
         for (int j = 0; j < restart; ++j) {
             pl.matvec(krylov_basis(j + 1), krylov_basis(j));
-            for (int k = 0; k <= j; ++k) {
-                const Scalar<T> h = pl.dot(krylov_basis(k), krylov_basis(j + 1));
-                pl.axpy(krylov_basis(j + 1), {-h}, krylov_basis(k));
+            if (classical_) {
+                std::vector<int> basis(j + 1);
+                for (int k = 0; k <= j; ++k) basis[k] = krylov_basis(k);
+                const T *h = pl.multi_dot(basis, krylov_basis(j + 1));
+                pl.multi_axpy(krylov_basis(j + 1), h, basis, /*negate=*/true);
+            } else {
+                for (int k = 0; k <= j; ++k) {
+                    const Scalar<T> h = pl.dot(krylov_basis(k), krylov_basis(j + 1));
+                    pl.axpy(krylov_basis(j + 1), {-h}, krylov_basis(k));
+                }
             }
             const Scalar<T> d = pl.dot(krylov_basis(j + 1), krylov_basis(j + 1));
             if (j + 1 < restart) pl.scal(krylov_basis(j + 1), {d.rsqrt()});
@@ -1016,6 +1142,7 @@ public:
 private:
     SquarePlanner<T> &pl;
     int restart;
+    bool classical_;
     Scalar<T> negative_one, dummy_coefficient;
 };
 

@@ -98,3 +98,40 @@ def test_transposed_product(coo, f32, chunk):
     tol = 1e-5 if f32 else 1e-13
     assert float(scale) > 0.5 and float(diff) <= tol * float(scale)
     assert abs(lhs - rhs) <= 100 * tol * abs(lhs)
+
+
+@pytest.mark.parametrize("solver", [1, 2])
+@pytest.mark.parametrize("f32", [0, 1])
+def test_binned_coo_follows_the_oracle(solver, f32):
+    """-binned 1: the COO matrix multiplied through the binned copy (lsk_coo_binned_*: blocks of 64
+    columns, tiles of 128 rows here, so the 720 rows make a dozen of each), in 3 pieces, two systems."""
+    dtype = np.float32 if f32 else np.float64
+    steps = {1: 8, 2: 6}[solver]
+    rects, row, col, val, n = hc.stencil_problem(4, (10, 9, 8), dtype)
+    opl = hc.oracle_planner("coo", rects, row, col, val, n, 3, dtype, spaces=2)
+    so = {1: S.CGSolver, 2: S.BiCGStabSolver}[solver](opl)
+    for _ in range(steps):
+        so.step()
+    hist, sums, _ = run("-dim", 4, "-nx", 10, "-ny", 9, "-nz", 8, "-vp", 3, "-solver", solver, "-it", steps,
+                        "-history", 1, "-coo", 1, "-f32", f32, "-binned", 1, "-bincols", 64, "-binrows", 128)
+    rtol = 2e-3 if f32 else 1e-9
+    want = so.residual_norm_squared if solver == 1 else so.rho
+    np.testing.assert_allclose(hist, [float(v) for v in want], rtol=rtol)
+    x = opl.get_vector(0, 0).astype(np.float64)
+    np.testing.assert_allclose(sums["solution_sum_of_squares"], float(np.sum(x * x)), rtol=rtol * 10)
+
+
+@pytest.mark.parametrize("vp", [1, 3])
+def test_classical_gram_schmidt_option_follows_the_oracle(vp):
+    """-cgs 1: GMRES with every inner product of a step taken from the same vector
+    (SquarePlanner::multi_dot / multi_axpy) against the oracle's restatement of that variant."""
+    rects, row, col, val, n = hc.stencil_problem(4, (10, 9, 8), np.float64)
+    opl = hc.oracle_planner("csr", rects, row, col, val, n, vp, np.float64, spaces=2)
+    so = S.GMRESSolver(opl, 5, "classical")
+    for _ in range(6):
+        so.step()
+    _, sums, _ = run("-dim", 4, "-nx", 10, "-ny", 9, "-nz", 8, "-vp", vp, "-solver", 3, "-it", 6, "-restart", 5,
+                     "-history", 1, "-cgs", 1)
+    x = opl.get_vector(0, 0).astype(np.float64)
+    np.testing.assert_allclose(sums["solution_sum_of_squares"], float(np.sum(x * x)), rtol=1e-8)
+    assert abs(sums["solution_sum"] - float(np.sum(x))) <= 1e-8 * float(np.sum(np.abs(x)))
