@@ -275,8 +275,11 @@ def main():
     del solver, planner
     _, planner2, solver2 = bs.build_problem(ctx, 4, n1, n1, n1, world, 1, torch.float64, num_systems=2,
                                             matrix=matrix)
-    seconds2 = bs.timed_steps(ctx, solver2, 2, max(args.steps // 5, 2))
-    two_system = max(args.steps // 5, 2) / seconds2
+    steps2 = max(args.steps // 5, 2)
+    two_system = steps2 / bs.timed_steps(ctx, solver2, 2, steps2)
+    os.environ["LSK_PAIR"] = "0"   # the same steps with one product per system, as the reference launches them
+    two_system_separate = steps2 / bs.timed_steps(ctx, solver2, 2, steps2)
+    os.environ.pop("LSK_PAIR")
     del solver2, planner2
     # (LSK_BENCH_HOST_COST=0 leaves it out: a profile of this run then holds launches of one problem size only)
     host_ms = host_ms_per_step(ctx, world) if os.environ.get("LSK_BENCH_HOST_COST", "1") != "0" else None
@@ -304,11 +307,15 @@ def main():
         },
         "spmv_gbps": spmv_gbps_job,
         "two_system_iters_per_s": two_system,
+        "two_system_iters_per_s_separate_products": two_system_separate,
         "value_untuned": iters_untuned,
         "value_reference_layout": iters_reference_layout,
         "setup_s": {k: round(v, 3) for k, v in setup_s.items()},
         "host_ms_per_step": host_ms,
         "notes": {
+            "two_system_iters_per_s": "the reference's BenchmarkStencil as it runs: two systems on one matrix per step; "
+                                      "both products share one pass over the matrix values (lsk_csr_sliced_spmv2_*), each "
+                                      "bit for bit what its own product gives; ..._separate_products: one product per system",
             "value_untuned": "the same steps before the set-up-time speed tuning (workgroup placement chosen by timing, "
                              "the copy re-made up to 6 times keeping the fastest, wait for the driver's scrubbing of freed "
                              "memory): LSK_TUNE=0",

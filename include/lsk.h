@@ -65,7 +65,11 @@ void lsk_set_abort_on_error(int enable);
  * -1 = for vectors of 256 MiB and more, the default), "coo.variant" (0 workgroup chunks through LDS | 1 wave-wide segmented
  * scan, default 1), "comm.skip_single_rank" (1, the default: lsk_allreduce_sum_* / lsk_allgather_* on a
  * one-rank communicator answer without calling RCCL | 0: they enqueue the RCCL collective all the
- * same).  No counterpart in the reference
+ * same), "sliced.form" (sliced-pattern product: 0 block-staged windows of x, the default | 1 every wave
+ * stages its own windows and the block meets only to write y), "sliced.runs" (1, the default: the
+ * wave-staged form reads lists of runs of three run by run | 0 entry by entry), "sliced.pair_form"
+ * (lsk_csr_sliced_spmv2_*: 0 both vectors' windows in LDS at once | 1 wave-staged, one vector after the
+ * other | -1, the default: 0 for lists of more than 20 entries, else 1).  No counterpart in the reference
  * (cuSPARSE picks its own algorithm behind CUSPARSE_SPMV_ALG_DEFAULT).  All other options
  * are process-wide and read at launch time without synchronisation: set them between launches. */
 int lsk_set_option(const char *key, int value);
@@ -571,6 +575,27 @@ int lsk_csr_sliced_spmv_f64(const lsk_csr_sliced_t *m, int64_t row_begin, int64_
  * lsk_sum_partials_* gives the dot product (CG's p.Ap, src/CGSolver.hpp:46-47, without a pass over y
  * and w).  capacity >= lsk_csr_sliced_dot_partials(m, row_begin, row_end), the number of blocks those
  * rows touch; *count (that number) is written on the host. */
+/* Two products with one pass over the values: y_a <- A x_a (+ beta y_a), y_b <- A x_b (+ beta y_b), for
+ * callers that step two systems on one matrix, as the reference's BenchmarkStencil does
+ * (test/BenchmarkStencil.cpp:181-199: sol/rhs and sol1/rhs1 on one matrix; its planner launches one
+ * CSRMatvecTask per system).  Each result is, bit for bit, what lsk_csr_sliced_spmv_* gives for it
+ * alone; the values are read once, so the pair moves `padded entries * s + 4 rows * s` bytes instead
+ * of twice `padded entries * s + 2 rows * s`.  Both x windows and both y pieces have the layout of
+ * the single product.  The _dot form leaves the shares of y_a . w_a in partials_a and of y_b . w_b in
+ * partials_b (*count each, as lsk_csr_sliced_spmv_dot_*).  LSK_ERR_UNSUPPORTED (never an abort) for a
+ * structure with blocks that do not run on one staged list: launch the two products one by one. */
+int lsk_csr_sliced_spmv2_f32(const lsk_csr_sliced_t *m, int64_t row_begin, int64_t row_end, const float *xa,
+                             const float *xb, float *ya, float *yb, int beta, lsk_stream_t stream);
+int lsk_csr_sliced_spmv2_f64(const lsk_csr_sliced_t *m, int64_t row_begin, int64_t row_end, const double *xa,
+                             const double *xb, double *ya, double *yb, int beta, lsk_stream_t stream);
+int lsk_csr_sliced_spmv2_dot_f32(const lsk_csr_sliced_t *m, int64_t row_begin, int64_t row_end, const float *xa,
+                                 const float *xb, float *ya, float *yb, int beta, const float *wa, const float *wb,
+                                 float *partials_a, float *partials_b, int64_t capacity, int64_t *count,
+                                 lsk_stream_t stream);
+int lsk_csr_sliced_spmv2_dot_f64(const lsk_csr_sliced_t *m, int64_t row_begin, int64_t row_end, const double *xa,
+                                 const double *xb, double *ya, double *yb, int beta, const double *wa, const double *wb,
+                                 double *partials_a, double *partials_b, int64_t capacity, int64_t *count,
+                                 lsk_stream_t stream);
 int64_t lsk_csr_sliced_dot_partials(const lsk_csr_sliced_t *m, int64_t row_begin, int64_t row_end);
 int lsk_csr_sliced_spmv_dot_f32(const lsk_csr_sliced_t *m, int64_t row_begin, int64_t row_end, const float *x, float *y,
                                 int beta, const float *w, float *partials, int64_t capacity, int64_t *count,

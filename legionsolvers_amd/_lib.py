@@ -90,6 +90,10 @@ PROTOTYPES = {
     "lsk_csr_sliced_spmv_f64": (_i, [_p, _i64, _i64, _p, _p, _i, _p]),
     "lsk_csr_sliced_spmv_dot_f32": (_i, [_p, _i64, _i64, _p, _p, _i, _p, _p, _i64, _p, _p]),
     "lsk_csr_sliced_spmv_dot_f64": (_i, [_p, _i64, _i64, _p, _p, _i, _p, _p, _i64, _p, _p]),
+    "lsk_csr_sliced_spmv2_f32": (_i, [_p, _i64, _i64, _p, _p, _p, _p, _i, _p]),
+    "lsk_csr_sliced_spmv2_f64": (_i, [_p, _i64, _i64, _p, _p, _p, _p, _i, _p]),
+    "lsk_csr_sliced_spmv2_dot_f32": (_i, [_p, _i64, _i64, _p, _p, _p, _p, _i, _p, _p, _p, _p, _i64, _p, _p]),
+    "lsk_csr_sliced_spmv2_dot_f64": (_i, [_p, _i64, _i64, _p, _p, _p, _p, _i, _p, _p, _p, _p, _i64, _p, _p]),
     "lsk_csr_sliced_tune_f32": (_i, [_p, _p, _p, _p, _p, _p]),
     "lsk_csr_sliced_tune_f64": (_i, [_p, _p, _p, _p, _p, _p]),
     "lsk_csr_sliced_info": (_i, [_p, _p]),

@@ -66,6 +66,14 @@ struct Options {
     int blas1_nontemporal = -1; // BLAS-1 streams past the caches: 1, 0, -1 = for vectors of 256 MiB and more
     int coo_variant = 1;     // 0: workgroup chunks through LDS, 1: wave-wide segmented scan
     int comm_skip_single_rank = 1; // one-rank communicators: answer without calling RCCL
+    // Sliced-pattern product: 0 block-staged windows of x (one barrier before the sums), 1 wave-staged
+    // (every wave its own windows, no barrier but the last; measured within 3 % of each other on every
+    // stencil of the benchmark, so the older form stays the default).
+    int sliced_form = 0;
+    int sliced_runs = 1;      // the wave-staged form takes lists of runs of three run by run (0: entry by entry)
+    // Two right-hand sides: 0 both vectors' windows in LDS at once, 1 wave-staged, one vector after the
+    // other; -1 by measurement: 0 for lists of more than 20 entries, else 1.
+    int sliced_pair_form = -1;
 };
 Options &options();
 

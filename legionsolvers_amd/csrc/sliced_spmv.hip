@@ -62,6 +62,14 @@ struct PatternInfo {
     int ntail;
     int tail_dist[kMaxLength];
     int tail_off[kMaxLength];
+    // The same plan for ONE WAVE's 64 R rows (sliced_wave_kernel: every wave stages its own windows and
+    // needs no barrier): window q is 64 R + run_len - 1 elements at w_run_off[q].
+    int w_lds_elems;
+    int w_ntail;
+    int w_run_off[kMaxRuns];
+    unsigned w_lds_off_packed[kMaxLength / 2];
+    int w_tail_dist[kMaxLength];
+    int w_tail_off[kMaxLength];
 };
 
 } // namespace
@@ -73,6 +81,8 @@ struct lsk_csr_sliced {
     int patterns = 0, max_len = 0;
     bool all_staged = true;        // every pattern's x windows fit the staging area
     size_t lds_bytes = 0;          // dynamic LDS of a launch: the largest staging area of any pattern
+    size_t wave_lds_bytes = 0;     // ... of one wave's windows in the wave-staged form
+    bool runs_of_three = true;     // every list is runs of exactly three consecutive distances (27-point stencils)
     void *val = nullptr;           // padded_entries values, block by block
     void *meta = nullptr;          // per block {int64 base; int32 maxlen; int32 pattern | flags, or -1}
     unsigned char *row_pattern = nullptr; // per row
@@ -599,6 +609,418 @@ __global__ __launch_bounds__(kBlock, (sliced_waves_per_simd<T, CAP, GENERAL>()))
     }
 }
 
+// The wave-staged form: every wave stages the windows of x of its OWN 64 R rows (64 R + length - 1
+// elements per run) in its own part of LDS and multiplies without waiting for the block's other
+// waves; the block meets once, at the end, to write y together (and to add the waves' dot shares).
+// K = 2: two right-hand sides, one after the other through the same LDS area, on values that were
+// loaded once (two systems on one matrix, what the reference's BenchmarkStencil steps,
+// test/BenchmarkStencil.cpp:181-199); each is summed in entry order, bit for bit what the one-vector
+// product gives for it.  Staged lists only (every block on one staged list).
+#ifndef LSK_WAVE_K2_WAVES
+#define LSK_WAVE_K2_WAVES 2
+#endif
+template <int K, int CAP> constexpr int sliced_wave_waves_per_simd() {
+    return CAP > 27 ? 2 : (K == 1 && CAP <= 20) ? 4 : (K == 2 && CAP > 20) ? LSK_WAVE_K2_WAVES : 3; // (what each holds without spilling)
+}
+// RUN3: every list is runs of three consecutive distances.  The R rows of a lane then need R + 2
+// consecutive elements of a run's window, taken with two aligned 16-byte LDS reads per run instead of
+// three unaligned ones per entry -- a third of the LDS time -- and used in the same entry order.
+template <typename T, int CAP, bool DOT, int K, bool RUN3>
+__global__ __launch_bounds__(kBlock, (sliced_wave_waves_per_simd<K, CAP>())) void sliced_wave_kernel(
+    int64_t block_begin, int64_t row_begin, int64_t row_end, const BlockMeta *__restrict__ meta,
+    const T *__restrict__ val, const unsigned *__restrict__ row_mask, const PatternInfo *__restrict__ table,
+    const T *__restrict__ xa, const T *__restrict__ xb, long long x_shift, long long x_extent, T *__restrict__ ya,
+    T *__restrict__ yb, int beta, int remap, const T *__restrict__ wa, const T *__restrict__ wb, T *__restrict__ pa,
+    T *__restrict__ pb, int lds_wave_elems, int yw_aligned) {
+    constexpr int R = Lane<T>::R;
+    using V = typename Lane<T>::V;
+    constexpr int kBlockRows = kBlock * R, kWaveRows = kWave * R;
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    __shared__ T wave_share[K][kWavesPerBlock];
+
+    const unsigned wg = lsk::xcd_remap(blockIdx.x, gridDim.x, remap);
+    const int64_t block = block_begin + wg;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave), lane = threadIdx.x % kWave;
+    T *xs = reinterpret_cast<T *>(lds_raw) + wave * lds_wave_elems;
+    const BlockMeta m = meta[block];
+    const long long base = lsk::wave_first(m.base);
+    const int maxlen = __builtin_amdgcn_readfirstlane(m.maxlen);
+    const int pattern = __builtin_amdgcn_readfirstlane(m.pattern);
+    const int64_t r0 = block * kBlockRows + int64_t(wave) * kWaveRows; // the wave's first row
+    const int64_t r = r0 + int64_t(lane) * R;
+    const T *vp = val + base + int64_t(wave) * maxlen * kWaveRows + lane * R;
+
+    bool live[R];
+    bool all_live = true;
+#pragma unroll
+    for (int h = 0; h < R; ++h) {
+        live[h] = r + h >= row_begin && r + h < row_end;
+        all_live = all_live && live[h];
+    }
+    const PatternInfo &info = table[pattern & 0xff]; // wave-uniform address
+    unsigned mask[R];
+    const bool masked = (pattern >> (kWaveMaskedShift + wave)) & 1;
+#pragma unroll
+    for (int h = 0; h < R; ++h) mask[h] = !live[h] ? 0u : masked ? row_mask[r + h] : 0xffffffffu;
+    const int nruns = info.nruns;
+    const long long xbase = r0 + x_shift + lane;
+    const long long xlast = x_extent - 1;
+    const unsigned lenmask = maxlen >= 32 ? 0xffffffffu : (1u << maxlen) - 1u;
+    const bool plain = !masked && __all(all_live);
+    const T *lane_xs = xs + lane * R;
+    V v[CAP];
+    unsigned packed[(CAP + 1) / 2];
+    T result[K][R];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const T *x = k == 0 ? xa : xb;
+        const T *yin = k == 0 ? ya : yb;
+        auto fetch = [&](long long xi) {
+            const long long c = xi < 0 ? 0 : (xi > xlast ? xlast : xi);
+            const T got = x[c];
+            return c == xi ? got : T(0);
+        };
+        // All of a list's windows are requested at once (a 27-point list has 9; a batch that is not
+        // full repeats its last run, harmlessly), and the few elements by which they are wider than
+        // the wave's rows with them: one trip to memory, not one per batch of four.
+#ifndef LSK_WAVE_QB
+#define LSK_WAVE_QB (CAP > 20 ? 9 : CAP > 8 ? 6 : 5)
+#endif
+        constexpr int QB = LSK_WAVE_QB;
+        const bool has_tail = lane < info.w_ntail;
+        T tail = T(0);
+        if (has_tail) tail = fetch(r0 + x_shift + info.w_tail_dist[lane]);
+        for (int q0 = 0; q0 < nruns; q0 += QB) {
+            T got[QB][R];
+            int start[QB], off[QB];
+#pragma unroll
+            for (int qi = 0; qi < QB; ++qi) {
+                const int q = q0 + qi < kMaxRuns ? q0 + qi : kMaxRuns - 1; // (slots past the last run repeat it)
+                start[qi] = info.run_start[q];
+                off[qi] = info.w_run_off[q];
+            }
+#pragma unroll
+            for (int qi = 0; qi < QB; ++qi) {
+                const long long first = xbase + start[qi];
+#pragma unroll
+                for (int i = 0; i < R; ++i) got[qi][i] = fetch(first + i * kWave);
+            }
+#pragma unroll
+            for (int qi = 0; qi < QB; ++qi) {
+                T *dst = xs + off[qi] + lane;
+#pragma unroll
+                for (int i = 0; i < R; ++i) dst[i * kWave] = got[qi][i];
+            }
+        }
+        if (has_tail) xs[info.w_tail_off[lane]] = tail;
+        if (k == 0) {
+            // every entry's place in LDS into scalar registers now: a scalar load between the LDS reads
+            // below would make each of them wait for the one before
+#pragma unroll
+            for (int i = 0; i < (CAP + 1) / 2; ++i) packed[i] = info.w_lds_off_packed[i];
+            __builtin_amdgcn_sched_barrier(0); // (the value loads stay behind the staging, whose registers they take)
+#pragma unroll
+            for (int j = 0; j < CAP; ++j) {
+                if (j < maxlen) v[j] = __builtin_nontemporal_load(reinterpret_cast<const V *>(vp + int64_t(j) * kWaveRows));
+                else v[j] = V(0);
+            }
+        }
+        // the wave's own LDS writes are in place before its reads: LDS serves a wave's accesses in order,
+        // and the fence keeps the compiler from moving the reads up
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        T acc[R];
+#pragma unroll
+        for (int h = 0; h < R; ++h) acc[h] = (beta && live[h]) ? yin[r + h] : T(0);
+        auto entry = [&](int j, auto plain_tag) {
+            if (j < maxlen) { // (wave-uniform)
+                const T *src = lane_xs + ((packed[j / 2] >> (16 * (j % 2))) & 0xffffu);
+                T xv[R];
+#pragma unroll
+                for (int h = 0; h < R; ++h) xv[h] = src[h];
+                if constexpr (decltype(plain_tag)::value) {
+#pragma unroll
+                    for (int h = 0; h < R; ++h) acc[h] = acc[h] + v[j][h] * xv[h];
+                } else {
+#pragma unroll
+                    for (int h = 0; h < R; ++h) asm volatile("" : "+v"(xv[h]));
+#pragma unroll
+                    for (int h = 0; h < R; ++h) {
+                        const T sum = acc[h] + v[j][h] * xv[h];
+                        acc[h] = ((mask[h] & lenmask) >> j) & 1u ? sum : acc[h];
+                    }
+                }
+            }
+        };
+        auto run_of_three = [&](int q, auto plain_tag) {
+            if (3 * q < maxlen) { // (wave-uniform; the list is whole runs)
+                // packed[] holds the place of every entry: that of the run's first is the window's start
+                const T *src = lane_xs + ((packed[(3 * q) / 2] >> (16 * ((3 * q) % 2))) & 0xffffu);
+                constexpr int NV = (R + 2 + R - 1) / R; // 16-byte reads that cover R + 2 elements
+                V xw[NV];
+#pragma unroll
+                for (int i = 0; i < NV; ++i) xw[i] = *reinterpret_cast<const V *>(src + i * R);
+                if constexpr (!decltype(plain_tag)::value) {
+#pragma unroll
+                    for (int i = 0; i < NV; ++i) asm volatile("" : "+v"(xw[i]));
+                }
+#pragma unroll
+                for (int e = 0; e < 3; ++e) {
+                    const int j = 3 * q + e;
+#pragma unroll
+                    for (int h = 0; h < R; ++h) {
+                        const T xv = xw[(e + h) / R][(e + h) % R];
+                        const T sum = acc[h] + v[j][h] * xv;
+                        if constexpr (decltype(plain_tag)::value) acc[h] = sum;
+                        else acc[h] = ((mask[h] & lenmask) >> j) & 1u ? sum : acc[h];
+                    }
+                }
+            }
+        };
+        if constexpr (RUN3) {
+            static_assert(CAP % 3 == 0, "lists of runs of three");
+            if (plain) {
+#pragma unroll
+                for (int q = 0; q < CAP / 3; ++q) run_of_three(q, std::true_type{});
+            } else {
+#pragma unroll
+                for (int q = 0; q < CAP / 3; ++q) run_of_three(q, std::false_type{});
+            }
+        } else if (plain) {
+#pragma unroll
+            for (int j = 0; j < CAP; ++j) entry(j, std::true_type{});
+        } else {
+#pragma unroll
+            for (int j = 0; j < CAP; ++j) entry(j, std::false_type{});
+        }
+        if (k + 1 < K) { // the reads are done before the next vector's windows overwrite the area
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+#pragma unroll
+        for (int h = 0; h < R; ++h) result[k][h] = acc[h];
+        if constexpr (DOT) {
+            const T *w = k == 0 ? wa : wb;
+            T share = T(0);
+            if (all_live && yw_aligned) {
+                const V wv = *reinterpret_cast<const V *>(w + r);
+#pragma unroll
+                for (int h = 0; h < R; ++h) share = share + acc[h] * wv[h];
+            } else {
+#pragma unroll
+                for (int h = 0; h < R; ++h)
+                    if (live[h]) share = share + acc[h] * w[r + h];
+            }
+            share = lsk::wave_sum(share);
+            if (lane == 0) wave_share[k][wave] = share;
+        }
+    }
+    // the block's only barrier: its stores leave together, 4 KiB per vector
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        T *y = k == 0 ? ya : yb;
+        if (all_live && yw_aligned) {
+            V out;
+#pragma unroll
+            for (int h = 0; h < R; ++h) out[h] = result[k][h];
+            store16_nontemporal(y + r, out);
+        } else {
+#pragma unroll
+            for (int h = 0; h < R; ++h)
+                if (live[h]) y[r + h] = result[k][h];
+        }
+    }
+    if constexpr (DOT) {
+        if (threadIdx.x < K) {
+            T *pk = threadIdx.x == 0 ? pa : pb;
+            T total = wave_share[threadIdx.x][0];
+#pragma unroll
+            for (int i = 1; i < kWavesPerBlock; ++i) total = total + wave_share[threadIdx.x][i];
+            pk[wg] = total;
+        }
+    }
+}
+
+// Two products with one pass over the values: y_a <- A x_a, y_b <- A x_b (two systems on one matrix,
+// what the reference's BenchmarkStencil steps, test/BenchmarkStencil.cpp:181-199).  The staged form
+// only (every block on one staged list); both windows of x in LDS (twice the space, so two
+// workgroups per CU and no register limit to speak of); each right-hand side summed in entry order,
+// bit for bit what sliced_spmv_kernel gives for it alone.
+template <typename T, int CAP, bool DOT>
+__global__ __launch_bounds__(kBlock, 2) void sliced_spmv2_kernel(
+    int64_t block_begin, int64_t row_begin, int64_t row_end, const BlockMeta *__restrict__ meta,
+    const T *__restrict__ val, const unsigned *__restrict__ row_mask, const PatternInfo *__restrict__ table,
+    const T *__restrict__ xa, const T *__restrict__ xb, long long x_shift, long long x_extent, T *__restrict__ ya,
+    T *__restrict__ yb, int beta, int remap, const T *__restrict__ wa, const T *__restrict__ wb, T *__restrict__ pa,
+    T *__restrict__ pb, int lds_stride, int yw_aligned) {
+    constexpr int R = Lane<T>::R;
+    constexpr int K = 2;
+    using V = typename Lane<T>::V;
+    constexpr int kBlockRows = kBlock * R, kWaveRows = kWave * R;
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    T *xs = reinterpret_cast<T *>(lds_raw);
+    __shared__ T wave_share[K][kWavesPerBlock];
+
+    const unsigned wg = lsk::xcd_remap(blockIdx.x, gridDim.x, remap);
+    const int64_t block = block_begin + wg;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave), lane = threadIdx.x % kWave;
+    const BlockMeta m = meta[block];
+    const long long base = lsk::wave_first(m.base);
+    const int maxlen = __builtin_amdgcn_readfirstlane(m.maxlen);
+    const int pattern = __builtin_amdgcn_readfirstlane(m.pattern);
+    const int64_t r0 = block * kBlockRows;
+    const int64_t r = r0 + int64_t(threadIdx.x) * R;
+    const T *vp = val + base + int64_t(wave) * maxlen * kWaveRows + lane * R;
+    const T *xk[K] = {xa, xb};
+    T *yk[K] = {ya, yb};
+
+    bool live[R];
+    bool all_live = true;
+    T acc[K][R];
+#pragma unroll
+    for (int h = 0; h < R; ++h) {
+        live[h] = r + h >= row_begin && r + h < row_end;
+        all_live = all_live && live[h];
+#pragma unroll
+        for (int k = 0; k < K; ++k) acc[k][h] = (beta && live[h]) ? yk[k][r + h] : T(0);
+    }
+    const PatternInfo &info = table[pattern & 0xff]; // wave-uniform address
+    unsigned mask[R];
+    const bool masked = (pattern >> (kWaveMaskedShift + wave)) & 1;
+#pragma unroll
+    for (int h = 0; h < R; ++h) mask[h] = !live[h] ? 0u : masked ? row_mask[r + h] : 0xffffffffu;
+    const int nruns = info.nruns;
+    const long long xbase = r0 + x_shift + threadIdx.x;
+    const long long xlast = x_extent - 1;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const T *x = xk[k];
+        T *xsk = xs + k * lds_stride;
+        auto fetch = [&](long long xi) {
+            const long long c = xi < 0 ? 0 : (xi > xlast ? xlast : xi);
+            const T got = x[c];
+            return c == xi ? got : T(0);
+        };
+        constexpr int QB = 4;
+        for (int q0 = 0; q0 < nruns; q0 += QB) {
+            T got[QB][R];
+            int start[QB], off[QB];
+#pragma unroll
+            for (int qi = 0; qi < QB; ++qi) {
+                start[qi] = info.run_start[q0 + qi];
+                off[qi] = info.run_off[q0 + qi];
+            }
+#pragma unroll
+            for (int qi = 0; qi < QB; ++qi) {
+                const long long first = xbase + start[qi];
+#pragma unroll
+                for (int i = 0; i < R; ++i) got[qi][i] = fetch(first + i * kBlock);
+            }
+#pragma unroll
+            for (int qi = 0; qi < QB; ++qi) {
+                T *dst = xsk + off[qi] + threadIdx.x;
+#pragma unroll
+                for (int i = 0; i < R; ++i) dst[i * kBlock] = got[qi][i];
+            }
+        }
+        if (static_cast<int>(threadIdx.x) < info.ntail)
+            xsk[info.tail_off[threadIdx.x]] = fetch(r0 + x_shift + info.tail_dist[threadIdx.x]);
+    }
+    unsigned packed[(CAP + 1) / 2];
+#pragma unroll
+    for (int k = 0; k < (CAP + 1) / 2; ++k) packed[k] = info.lds_off_packed[k];
+    __builtin_amdgcn_sched_barrier(0);
+    V v[CAP];
+#pragma unroll
+    for (int j = 0; j < CAP; ++j) {
+        if (j < maxlen) v[j] = __builtin_nontemporal_load(reinterpret_cast<const V *>(vp + int64_t(j) * kWaveRows));
+        else v[j] = V(0);
+    }
+    __syncthreads();
+    const unsigned lenmask = maxlen >= 32 ? 0xffffffffu : (1u << maxlen) - 1u;
+    const bool plain = !masked && __all(all_live);
+    const T *lane_xs = xs + threadIdx.x * R;
+    auto entry = [&](int j, auto plain_tag) {
+        if (j < maxlen) { // (wave-uniform)
+            const unsigned off = (packed[j / 2] >> (16 * (j % 2))) & 0xffffu;
+            T xv[K][R];
+#pragma unroll
+            for (int k = 0; k < K; ++k)
+#pragma unroll
+                for (int h = 0; h < R; ++h) xv[k][h] = lane_xs[k * lds_stride + off + h];
+            if constexpr (decltype(plain_tag)::value) {
+#pragma unroll
+                for (int k = 0; k < K; ++k)
+#pragma unroll
+                    for (int h = 0; h < R; ++h) acc[k][h] = acc[k][h] + v[j][h] * xv[k][h];
+            } else {
+#pragma unroll
+                for (int k = 0; k < K; ++k)
+#pragma unroll
+                    for (int h = 0; h < R; ++h) asm volatile("" : "+v"(xv[k][h]));
+#pragma unroll
+                for (int k = 0; k < K; ++k)
+#pragma unroll
+                    for (int h = 0; h < R; ++h) {
+                        const T sum = acc[k][h] + v[j][h] * xv[k][h];
+                        acc[k][h] = ((mask[h] & lenmask) >> j) & 1u ? sum : acc[k][h];
+                    }
+            }
+        }
+    };
+    if (plain) {
+#pragma unroll
+        for (int j = 0; j < CAP; ++j) entry(j, std::true_type{});
+    } else {
+#pragma unroll
+        for (int j = 0; j < CAP; ++j) entry(j, std::false_type{});
+    }
+
+    if constexpr (DOT) {
+        const T *wk[K] = {wa, wb};
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            T share = T(0);
+            if (all_live && yw_aligned) {
+                const V wv = *reinterpret_cast<const V *>(wk[k] + r);
+#pragma unroll
+                for (int h = 0; h < R; ++h) share = share + acc[k][h] * wv[h];
+            } else {
+#pragma unroll
+                for (int h = 0; h < R; ++h)
+                    if (live[h]) share = share + acc[k][h] * wk[k][r + h];
+            }
+            share = lsk::wave_sum(share);
+            if (lane == 0) wave_share[k][wave] = share;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        if (all_live && yw_aligned) {
+            V out;
+#pragma unroll
+            for (int h = 0; h < R; ++h) out[h] = acc[k][h];
+            store16_nontemporal(yk[k] + r, out);
+        } else {
+#pragma unroll
+            for (int h = 0; h < R; ++h)
+                if (live[h]) yk[k][r + h] = acc[k][h];
+        }
+    }
+    if constexpr (DOT) {
+        if (threadIdx.x < K) {
+            T *pk = threadIdx.x == 0 ? pa : pb;
+            T total = wave_share[threadIdx.x][0];
+#pragma unroll
+            for (int i = 1; i < kWavesPerBlock; ++i) total = total + wave_share[threadIdx.x][i];
+            pk[wg] = total;
+        }
+    }
+}
+
 // Runs of consecutive distances of a list, and where each entry's x value sits in the staging area
 // of a block of `block_rows` rows.  Returns false (nruns = 0) when the list needs more than
 // kMaxRuns runs or more than kMaxStageBytes.
@@ -643,6 +1065,35 @@ bool plan_staging(PatternInfo &p, int block_rows, size_t elem_bytes) {
     p.nruns = nruns;
     p.lds_elems = off;
     return true;
+}
+
+// The wave-level plan of a list whose block-level plan exists (same runs, windows of wave_rows rows).
+void plan_wave_staging(PatternInfo &p, int wave_rows) {
+    int off = 0, run_of[kMaxLength], lds_off[kMaxLength];
+    {
+        int q = -1;
+        for (int j = 0; j < p.len; ++j) {
+            if (j == 0 || p.dist[j] != p.dist[j - 1] + 1) ++q;
+            run_of[j] = q;
+        }
+    }
+    for (int q = 0; q < p.nruns; ++q) {
+        p.w_run_off[q] = off;
+        off += (wave_rows + p.run_len[q] - 1 + 3) & ~3;
+    }
+    for (int q = p.nruns; q < kMaxRuns; ++q) p.w_run_off[q] = p.w_run_off[p.nruns - 1];
+    for (int j = 0; j < kMaxLength; ++j)
+        lds_off[j] = j < p.len ? p.w_run_off[run_of[j]] + (p.dist[j] - p.run_start[run_of[j]]) : 0;
+    for (int k = 0; k < kMaxLength / 2; ++k)
+        p.w_lds_off_packed[k] = static_cast<unsigned>(lds_off[2 * k]) | (static_cast<unsigned>(lds_off[2 * k + 1]) << 16);
+    p.w_ntail = 0;
+    for (int q = 0; q < p.nruns; ++q)
+        for (int e = 0; e + 1 < p.run_len[q]; ++e) {
+            p.w_tail_dist[p.w_ntail] = p.run_start[q] + wave_rows + e;
+            p.w_tail_off[p.w_ntail] = p.w_run_off[q] + wave_rows + e;
+            ++p.w_ntail;
+        }
+    p.w_lds_elems = off;
 }
 
 template <typename T>
@@ -739,10 +1190,16 @@ int create(const char *name, int64_t rows, int64_t nnz, const int64_t *rects, in
                 if (info.len >= 0) {
                     m->patterns += 1;
                     m->max_len = std::max(m->max_len, info.len);
-                    if (plan_staging(info, kBlockRows, sizeof(T)))
+                    if (plan_staging(info, kBlockRows, sizeof(T))) {
                         m->lds_bytes = std::max(m->lds_bytes, static_cast<size_t>(info.lds_elems) * sizeof(T));
-                    else if (info.len > 0)
+                        plan_wave_staging(info, kBlockRows / kWavesPerBlock);
+                        m->wave_lds_bytes = std::max(m->wave_lds_bytes, static_cast<size_t>(info.w_lds_elems) * sizeof(T));
+                        for (int q = 0; q < info.nruns; ++q)
+                            if (info.run_len[q] != 3) m->runs_of_three = false;
+                    } else if (info.len > 0) {
                         m->all_staged = false;
+                        m->runs_of_three = false;
+                    }
                 }
             }
             LSK_TRY(hipMemcpyAsync(m->table, infos.data(), kMaxPatterns * sizeof(PatternInfo), hipMemcpyHostToDevice, s));
@@ -831,6 +1288,45 @@ int update_values(const char *name, lsk_csr_sliced *m, int64_t rows, int64_t nnz
     return LSK_OK;
 }
 
+// Whether the wave-staged kernel serves the structure: every block on one staged list, and the four
+// waves' windows within the 64 KiB a launch gets without asking.
+inline bool wave_form_serves(const lsk_csr_sliced *m) {
+    return m->all_staged && m->mixed_blocks == 0 && m->wave_lds_bytes > 0 &&
+           m->wave_lds_bytes * kWavesPerBlock <= (size_t(64) << 10);
+}
+
+template <typename T, int K>
+int launch_wave(const lsk_csr_sliced *m, int64_t block_begin, unsigned blocks, int64_t row_begin, int64_t row_end,
+                const T *xa, const T *xb, T *ya, T *yb, int beta, const T *wa, const T *wb, T *pa, T *pb, bool dot,
+                int yw_aligned, hipStream_t s) {
+    const BlockMeta *meta = static_cast<const BlockMeta *>(m->meta);
+    const T *val = static_cast<const T *>(m->val);
+    const long long x_shift = m->row_first - m->x_lo, x_extent = m->x_hi - m->x_lo + 1;
+    const int remap = lsk::xcd_remap_option();
+    const int wave_elems = static_cast<int>(m->wave_lds_bytes / sizeof(T));
+    const size_t lds = m->wave_lds_bytes * kWavesPerBlock;
+#define LSK_WAVE_LAUNCH(CAP, DOT, RUN3)                                                                            \
+    sliced_wave_kernel<T, CAP, DOT, K, RUN3><<<blocks, kBlock, lds, s>>>(                                          \
+        block_begin, row_begin, row_end, meta, val, m->row_mask, m->table, xa, xb, x_shift, x_extent, ya, yb, beta, \
+        remap, wa, wb, pa, pb, wave_elems, yw_aligned)
+#define LSK_WAVE_CAP(CAP, RUN3)                                                                                    \
+    do {                                                                                                           \
+        if (dot) LSK_WAVE_LAUNCH(CAP, true, RUN3);                                                                 \
+        else LSK_WAVE_LAUNCH(CAP, false, RUN3);                                                                    \
+    } while (0)
+    const bool run3 = m->runs_of_three && lsk::options().sliced_runs != 0;
+    if (m->max_len <= 8) LSK_WAVE_CAP(8, false);
+    else if (m->max_len <= 16) LSK_WAVE_CAP(16, false);
+    else if (m->max_len <= 20) LSK_WAVE_CAP(20, false);
+    else if (m->max_len <= 27 && run3) LSK_WAVE_CAP(27, true);
+    else if (m->max_len <= 27) LSK_WAVE_CAP(27, false);
+    else LSK_WAVE_CAP(32, false);
+#undef LSK_WAVE_CAP
+#undef LSK_WAVE_LAUNCH
+    LSK_LAUNCH_CHECK();
+    return LSK_OK;
+}
+
 // Partial sums the fused product + dot leaves for rows row_begin .. row_end - 1: one per block touched.
 template <typename T>
 int64_t dot_partials(int64_t row_begin, int64_t row_end) {
@@ -867,6 +1363,12 @@ int spmv(const char *name, const lsk_csr_sliced *m, int64_t row_begin, int64_t r
     const int yw_aligned = lsk::aligned16(y) && (!dot || lsk::aligned16(w));
     hipStream_t s = lsk::as_stream(stream);
     const bool general = !m->all_staged || m->mixed_blocks > 0;
+    if (lsk::options().sliced_form == 1 && wave_form_serves(m)) {
+        const int rc = launch_wave<T, 1>(m, block_begin, blocks, row_begin, row_end, x, nullptr, y, nullptr, beta, w, nullptr,
+                                         partials, nullptr, dot, yw_aligned, s);
+        if (rc == LSK_OK && dot) *count = blocks;
+        return rc;
+    }
 #define LSK_SLICED_LAUNCH(CAP, DOT, GENERAL)                                                                      \
     sliced_spmv_kernel<T, CAP, DOT, GENERAL><<<blocks, kBlock, m->lds_bytes, s>>>(                                \
         block_begin, m->rows, row_begin, row_end, meta, val, m->row_pattern, m->row_mask, m->table, x, x_shift,   \
@@ -885,6 +1387,71 @@ int spmv(const char *name, const lsk_csr_sliced *m, int64_t row_begin, int64_t r
     else LSK_SLICED_CAP(32);
 #undef LSK_SLICED_CAP
 #undef LSK_SLICED_LAUNCH
+    LSK_LAUNCH_CHECK();
+    if (dot) *count = blocks;
+    return LSK_OK;
+}
+
+template <typename T>
+int spmv2(const char *name, const lsk_csr_sliced *m, int64_t row_begin, int64_t row_end, const T *xa, const T *xb, T *ya,
+          T *yb, int beta, const T *wa, const T *wb, T *pa, T *pb, int64_t capacity, int64_t *count, lsk_stream_t stream) {
+    constexpr int64_t kBlockRows = int64_t(kBlock) * Lane<T>::R;
+    const bool dot = count != nullptr;
+    if (dot) *count = 0;
+    if (!m) return lsk::fail(LSK_ERR_ARG, "%s: null structure", name);
+    if (m->elem_bytes != static_cast<int>(sizeof(T))) return lsk::fail(LSK_ERR_ARG, "%s: structure of another entry type", name);
+    if (row_begin < 0 || row_end > m->rows || row_begin > row_end)
+        return lsk::fail(LSK_ERR_ARG, "%s: rows %lld..%lld of %lld", name, (long long)row_begin, (long long)row_end,
+                         (long long)m->rows);
+    if (beta != 0 && beta != 1) return lsk::fail(LSK_ERR_ARG, "%s: beta must be 0 or 1", name);
+    if (!m->all_staged || m->mixed_blocks > 0 || 2 * m->lds_bytes > (size_t(150) << 10))
+        return lsk::decline(LSK_ERR_UNSUPPORTED, "%s: not every block of this structure runs on one staged list", name);
+    if (row_begin == row_end) return LSK_OK;
+    if (!xa || !xb || !ya || !yb) return lsk::fail(LSK_ERR_ARG, "%s: null vector", name);
+    if (ya == yb) return lsk::fail(LSK_ERR_ARG, "%s: both results in one vector", name);
+    const int64_t block_begin = row_begin / kBlockRows;
+    const unsigned blocks = static_cast<unsigned>(dot_partials<T>(row_begin, row_end));
+    if (dot) {
+        if (!wa || !wb || !pa || !pb) return lsk::fail(LSK_ERR_ARG, "%s: null w or partials", name);
+        if (capacity < static_cast<int64_t>(blocks))
+            return lsk::fail(LSK_ERR_ARG, "%s: room for %lld partial sums, %u needed", name, (long long)capacity, blocks);
+    }
+    const BlockMeta *meta = static_cast<const BlockMeta *>(m->meta);
+    const T *val = static_cast<const T *>(m->val);
+    const long long x_shift = m->row_first - m->x_lo, x_extent = m->x_hi - m->x_lo + 1;
+    const int remap = lsk::xcd_remap_option();
+    const int yw_aligned = lsk::aligned16(ya) && lsk::aligned16(yb) && (!dot || (lsk::aligned16(wa) && lsk::aligned16(wb)));
+    const int lds_stride = static_cast<int>(m->lds_bytes / sizeof(T));
+    const size_t lds = 2 * m->lds_bytes;
+    hipStream_t s = lsk::as_stream(stream);
+    const int pair_form = lsk::options().sliced_pair_form;
+    if ((pair_form == 1 || (pair_form < 0 && m->max_len <= 20)) && wave_form_serves(m)) {
+        const int rc = launch_wave<T, 2>(m, block_begin, blocks, row_begin, row_end, xa, xb, ya, yb, beta, wa, wb, pa, pb, dot,
+                                         yw_aligned, s);
+        if (rc == LSK_OK && dot) *count = blocks;
+        return rc;
+    }
+#define LSK_SLICED2_LAUNCH(CAP, DOT)                                                                                \
+    do {                                                                                                            \
+        auto kernel = sliced_spmv2_kernel<T, CAP, DOT>;                                                             \
+        LSK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                    static_cast<int>(lds)));                                                        \
+        kernel<<<blocks, kBlock, lds, s>>>(block_begin, row_begin, row_end, meta, val, m->row_mask, m->table, xa, xb, \
+                                           x_shift, x_extent, ya, yb, beta, remap, wa, wb, pa, pb, lds_stride,       \
+                                           yw_aligned);                                                             \
+    } while (0)
+#define LSK_SLICED2_CAP(CAP)                                                                                        \
+    do {                                                                                                            \
+        if (dot) LSK_SLICED2_LAUNCH(CAP, true);                                                                     \
+        else LSK_SLICED2_LAUNCH(CAP, false);                                                                        \
+    } while (0)
+    if (m->max_len <= 8) LSK_SLICED2_CAP(8);
+    else if (m->max_len <= 16) LSK_SLICED2_CAP(16);
+    else if (m->max_len <= 20) LSK_SLICED2_CAP(20);
+    else if (m->max_len <= 27) LSK_SLICED2_CAP(27);
+    else LSK_SLICED2_CAP(32);
+#undef LSK_SLICED2_CAP
+#undef LSK_SLICED2_LAUNCH
     LSK_LAUNCH_CHECK();
     if (dot) *count = blocks;
     return LSK_OK;
@@ -989,6 +1556,23 @@ int lsk_csr_sliced_spmv_dot_f64(const lsk_csr_sliced_t *m, int64_t row_begin, in
     if (!count) return lsk::fail(LSK_ERR_ARG, "lsk_csr_sliced_spmv_dot_f64: null count");
     return spmv<double>("lsk_csr_sliced_spmv_dot_f64", m, row_begin, row_end, x, y, beta, w, partials, capacity, count, stream);
 }
+
+#define LSK_SLICED2(SUF, T)                                                                                          \
+    int lsk_csr_sliced_spmv2_##SUF(const lsk_csr_sliced_t *m, int64_t row_begin, int64_t row_end, const T *xa,       \
+                                   const T *xb, T *ya, T *yb, int beta, lsk_stream_t stream) {                       \
+        return spmv2<T>("lsk_csr_sliced_spmv2_" #SUF, m, row_begin, row_end, xa, xb, ya, yb, beta, nullptr, nullptr, \
+                        nullptr, nullptr, 0, nullptr, stream);                                                      \
+    }                                                                                                                \
+    int lsk_csr_sliced_spmv2_dot_##SUF(const lsk_csr_sliced_t *m, int64_t row_begin, int64_t row_end, const T *xa,   \
+                                       const T *xb, T *ya, T *yb, int beta, const T *wa, const T *wb, T *partials_a, \
+                                       T *partials_b, int64_t capacity, int64_t *count, lsk_stream_t stream) {       \
+        if (!count) return lsk::fail(LSK_ERR_ARG, "lsk_csr_sliced_spmv2_dot_" #SUF ": null count");                  \
+        return spmv2<T>("lsk_csr_sliced_spmv2_dot_" #SUF, m, row_begin, row_end, xa, xb, ya, yb, beta, wa, wb,       \
+                        partials_a, partials_b, capacity, count, stream);                                           \
+    }
+LSK_SLICED2(f32, float)
+LSK_SLICED2(f64, double)
+#undef LSK_SLICED2
 
 int64_t lsk_csr_sliced_dot_partials(const lsk_csr_sliced_t *m, int64_t row_begin, int64_t row_end) {
     if (!m) return 0;

@@ -643,6 +643,59 @@ class CSRMatrix(AbstractMatrix, _SlicedCopies):
             dst._note_ready(dot_with, pieces)
 
 
+    def pairs(self, x_lo, x_hi, kernel_partition, range_partition) -> bool:
+        """Whether matvec_pair serves this matrix for the window: every local piece that has rows is
+        multiplied through its sliced-pattern copy."""
+        be = self.ctx.backend
+        return (getattr(be, "csr_sliced_spmv2", None) is not None and os.environ.get("LSK_PAIR", "1") != "0"
+                and self.sliced_window == (x_lo, x_hi)
+                and all(c in self.sliced for c in kernel_partition.colors if range_partition.pieces[c].volume > 0))
+
+    def matvec_pair(self, dsts, xs, x_lo, x_hi, kernel_partition, dot_with=None, range_partition=None) -> bool:
+        """dsts[k] <- A xs[k] for k = 0, 1 with ONE pass over the values (two systems on one matrix: what
+        the reference's BenchmarkStencil steps, test/BenchmarkStencil.cpp:181-199, where the planner
+        launches one CSRMatvecTask per system).  Each result is bit for bit that of matvec(..., beta = 0);
+        dot_with = (w0, w1) leaves the shares of dot(dsts[k], w_k) as matvec's dot_with does.  False when
+        a piece's structure is not served: nothing was launched for ANY piece, the caller multiplies one
+        by one."""
+        range_partition = range_partition or dsts[0].index_partition
+        be = self.ctx.backend
+        if not self.pairs(x_lo, x_hi, kernel_partition, range_partition):
+            return False
+        fused = dot_with is not None
+        launched = False
+        pieces = ([], [])
+        for i, c in enumerate(kernel_partition.colors):
+            rows = range_partition.pieces[c].volume
+            if rows == 0:
+                for k in (0, 1):
+                    pieces[k].append((None, 0))
+                continue
+            sliced = self.sliced[c]
+            ys = [d._piece(i) for d in dsts]
+            bufs = ws = None
+            if fused:
+                slots = be.csr_sliced_dot_slots(sliced, rows)
+                bufs = [d._partials("mv", i, slots) for d in dsts]
+                ws = [w._piece(i) for w in dot_with]
+            count = be.csr_sliced_spmv2(sliced, rows, xs, ys, 0, ws, bufs, self.sliced_placement.get(c, 0))
+            if count is None:
+                if launched:
+                    raise RuntimeError("the two-vector product served one piece and declined another")
+                return False
+            launched = True
+            for k in (0, 1):
+                pieces[k].append((bufs[k] if fused else None, count))
+        for d in dsts:
+            touch = getattr(d, "_touch", None)
+            if touch is not None:
+                touch()
+        if fused:
+            for k in (0, 1):
+                dsts[k]._note_ready(dot_with[k], pieces[k])
+        return True
+
+
 class COOMatrix(AbstractMatrix, _SlicedCopies):
     def __init__(self, ctx, row: torch.Tensor, col: torch.Tensor, val: torch.Tensor,
                  range_space: IndexSpace):

@@ -16,7 +16,7 @@ import torch
 
 from .comm import HaloPlan, build_halo_plan
 from .index_space import IndexPartition, IndexSpace
-from .matrices import AbstractMatrix, COOMatrix, PiecePartition
+from .matrices import AbstractMatrix, COOMatrix, CSRMatrix, PiecePartition
 from .partitioned_vector import PartitionedVector
 from .scalar import Scalar
 
@@ -342,7 +342,26 @@ class SquarePlanner:
         fuse = (self.ctx.fuse and dst_idx >= 2 and src_idx >= 2 and dst_idx != src_idx
                 and self._fused_dot_pays())
         fused_any = False
-        for e in self.row_partitioned_matrices:
+        paired = set()
+        entries = self.row_partitioned_matrices
+        for idx, e in enumerate(entries):
+            if idx in paired:
+                continue
+            # Two systems on ONE matrix (the reference's BenchmarkStencil): both products in one pass
+            # over the matrix values, where each alone produces its range space and no halo is due.
+            mate = self._pair_mate(idx, writers, touched, paired)
+            if mate is not None:
+                e2 = entries[mate]
+                dsts = [self.get_vector(dst_idx, f.range_index) for f in (e, e2)]
+                srcs = [self.get_vector(src_idx, f.domain_index) for f in (e, e2)]
+                with_dot = fuse and e.matrix.fuses_dot()
+                dot_with = [self.get_vector(src_idx, f.range_index) for f in (e, e2)] if with_dot else None
+                lo, hi = srcs[0].own_lo, srcs[0].own_hi
+                if e.matrix.matvec_pair(dsts, [v._own for v in srcs], lo, hi, e.kernel_partition, dot_with):
+                    paired.add(mate)
+                    touched.update((e.range_index, e2.range_index))
+                    fused_any = fused_any or with_dot
+                    continue
             dst = self.get_vector(dst_idx, e.range_index)
             src = self.get_vector(src_idx, e.domain_index)
             first = e.range_index not in touched
@@ -387,6 +406,31 @@ class SquarePlanner:
             self._fused_dot_pending = frozenset((dst_idx, src_idx))
         else:
             self._fused_dot_pending = None
+
+    def _pair_mate(self, idx: int, writers, touched, paired):
+        """Index of a later matrix entry that can share one pass over the values with entry idx: the
+        same CSR matrix object on the same partitions, other spaces, each the only writer of its range
+        space, no ghost cells to fetch (one rank, or rows that read only their own); None if there is none."""
+        entries = self.row_partitioned_matrices
+        e = entries[idx]
+        if (not isinstance(e.matrix, CSRMatrix) or writers[e.range_index] != 1 or e.range_index in touched
+                or e.plan.recvs or e.plan.sends or e.domain_index != e.range_index):
+            return None
+        dst = self.get_vector(0, e.range_index)
+        if not e.matrix.pairs(dst.own_lo, dst.own_hi, e.kernel_partition, dst.index_partition):
+            return None
+        for j in range(idx + 1, len(entries)):
+            f = entries[j]
+            if (j in paired or f.matrix is not e.matrix or f.range_index == e.range_index
+                    or writers[f.range_index] != 1 or f.range_index in touched or f.plan.recvs or f.plan.sends
+                    or f.domain_index != f.range_index or f.kernel_partition.intervals != e.kernel_partition.intervals
+                    or f.kernel_partition.colors != e.kernel_partition.colors):
+                continue
+            other = self.get_vector(0, f.range_index)
+            if other.index_partition != dst.index_partition or other.own_lo != dst.own_lo or other.own_hi != dst.own_hi:
+                continue
+            return j
+        return None
 
     def rmatvec(self, dst_idx: int, src_idx: int) -> None:
         """dst <- A^T src over all registered matrices: vector `src_idx` is read in every matrix's

@@ -303,6 +303,46 @@ def test_column_blocked_coo_follows_the_oracle(gpu_ctx, monkeypatch):
     assert np.abs(got - want).max() <= 1e-9 * np.abs(want).max()
 
 
+@pytest.mark.parametrize("solver_name", ["cg", "bicgstab", "gmres"])
+@pytest.mark.parametrize("pieces", [1, 3])
+def test_two_systems_on_one_matrix_share_a_pass(gpu_ctx, monkeypatch, solver_name, pieces):
+    """The reference's BenchmarkStencil solves two systems on one matrix (test/BenchmarkStencil.cpp:
+    181-199).  The planner multiplies both in one pass over the matrix values (lsk_csr_sliced_spmv2_*):
+    every scalar of the history and both solutions are bit for bit those of LSK_PAIR=0, where the
+    two products are launched one after the other; and the pair path really ran."""
+    from legionsolvers_amd import CSRMatrix
+    rects, row, col, val, n = hc.stencil_problem(4, (13, 11, 17), np.float64)
+    rng = np.random.default_rng(71)
+    rhs = rng.standard_normal(n)
+    calls = []
+    real = CSRMatrix.matvec_pair
+
+    def spy(self, *args, **kwargs):
+        served = real(self, *args, **kwargs)
+        calls.append(served)
+        return served
+
+    monkeypatch.setattr(CSRMatrix, "matvec_pair", spy)
+    outcomes = []
+    for pair in ("1", "0"):
+        monkeypatch.setenv("LSK_PAIR", pair)
+        calls.clear()
+        pl = hc.mirror_planner(gpu_ctx, "csr", rects, row, col, val, n, pieces, np.float64, rhs, spaces=2)
+        pl.get_vector(1, 1).owned.mul_(-0.5)   # the second system gets another right-hand side
+        solver = {"cg": CGSolver, "bicgstab": BiCGStabSolver}[solver_name](pl) if solver_name != "gmres" \
+            else GMRESSolver(pl, 4)
+        for _ in range(5):
+            solver.step()
+        history = {"cg": lambda: solver.residual_norm_squared, "bicgstab": lambda: solver.rho,
+                   "gmres": lambda: [h for col_ in solver.inner_products for h in col_]}[solver_name]()
+        outcomes.append(([s.get_value() for s in history], pl.get_vector(0, 0).to_host().clone(),
+                         pl.get_vector(0, 1).to_host().clone(), list(calls)))
+    (h1, a1, b1, calls1), (h0, a0, b0, calls0) = outcomes
+    assert calls1 and all(calls1) and not any(calls0)
+    assert h1 == h0 and torch.equal(a1, a0) and torch.equal(b1, b0)
+    assert not torch.equal(a1, b1)
+
+
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("shuffled", [False, True])
 def test_binned_coo_follows_the_oracle(gpu_ctx, monkeypatch, dtype, shuffled):

@@ -739,13 +739,74 @@ def sliced_case(suf, rects, k_base, col, val, x, x_lo, x_hi, row_first, tag, exp
         code = getattr(_lib.lib(), f"lsk_csr_sliced_spmv_dot_{suf}")(handle, 0, rows, P(xd), P(yd), 0, P(wd), P(partials),
                                                                    slots - 1, ctypes.byref(count), stream())
         assert code == _lib.LSK_ERR_ARG and count.value == 0, f"{tag}: short partials buffer accepted"
+        sliced_pair_case(suf, handle, rows, br, xd, x.size, y0, wd, partials[:slots].clone(), tag,
+                         must_serve=tag.startswith("stencil"))
     finally:
         _lib.call("lsk_csr_sliced_destroy", handle)
     return list(info)
 
 
+def sliced_pair_case(suf, handle, rows, br, xd, x_size, y0, wd, shares_a, tag, must_serve):
+    """lsk_csr_sliced_spmv2_*: two right-hand sides with one pass over the values; each result, and
+    each set of dot shares, bit for bit what the single product gives (shares_a: those of xd with wd)."""
+    npdt, tdt, _ = DT[suf]
+    lib = _lib.lib()
+    rng = np.random.default_rng(rows + 1)
+    xb = dev(rng.standard_normal(x_size).astype(npdt))
+    wb = dev(rng.standard_normal(rows).astype(npdt))
+    slots = -(-rows // br)
+    for beta, (ra, rb) in ((0, (0, rows)), (1, (0, rows)), (0, (rows // 3, rows - rows // 5)),
+                           (1, (min(rows, br - 3), min(rows, 2 * br + 5)))):
+        want = []
+        for xv in (xd, xb):
+            yd = dev(y0)
+            _lib.call(f"lsk_csr_sliced_spmv_{suf}", handle, ra, rb, P(xv), P(yd), beta, stream())
+            want.append(yd)
+        ya, yb = dev(y0), dev(y0)
+        code = getattr(lib, f"lsk_csr_sliced_spmv2_{suf}")(handle, ra, rb, P(xd), P(xb), P(ya), P(yb), beta, stream())
+        if code == _lib.LSK_ERR_UNSUPPORTED and not must_serve:
+            print(f"case csr_sliced_spmv2_{suf} {tag}: declined (blocks without one staged list)", flush=True)
+            return
+        assert code == _lib.LSK_OK, f"{tag}: spmv2 said {code}: {lib.lsk_last_error().decode()}"
+        assert torch.equal(ya, want[0]) and torch.equal(yb, want[1]), f"{tag}: spmv2 beta={beta} rows {ra}..{rb}"
+    # the fused form: the same results, and each system's shares those of its single product
+    yd = dev(y0)
+    pb_single = torch.zeros(slots, dtype=tdt, device="cuda")
+    count = ctypes.c_int64(-1)
+    _lib.call(f"lsk_csr_sliced_spmv_dot_{suf}", handle, 0, rows, P(xb), P(yd), 0, P(wb), P(pb_single), slots,
+              ctypes.byref(count), stream())
+    ya, yb = dev(y0), dev(y0)
+    pa = torch.full((slots + 2,), 7.0, dtype=tdt, device="cuda")
+    pb = torch.full((slots + 2,), 7.0, dtype=tdt, device="cuda")
+    _lib.call(f"lsk_csr_sliced_spmv2_dot_{suf}", handle, 0, rows, P(xd), P(xb), P(ya), P(yb), 0, P(wd), P(wb), P(pa), P(pb),
+              slots + 2, ctypes.byref(count), stream())
+    assert count.value == slots
+    assert torch.equal(yb, yd) and torch.equal(pa[:slots], shares_a) and torch.equal(pb[:slots], pb_single), f"{tag}: spmv2_dot"
+    assert bool((pa[slots:] == 7.0).all()) and bool((pb[slots:] == 7.0).all()), f"{tag}: spmv2_dot wrote past its shares"
+    assert getattr(lib, f"lsk_csr_sliced_spmv2_{suf}")(handle, 0, rows, P(xd), P(xb), P(ya), P(ya), 0, stream()) == _lib.LSK_ERR_ARG
+
+
+@pytest.fixture(params=[(0, -1, 1), (0, 1, 1), (1, 0, 1), (1, 1, 0)],
+                ids=["chosen-by-the-library", "block-staged,pair-by-waves", "wave-staged,pair-in-one-area",
+                     "wave-staged,entry-by-entry"])
+def sliced_forms(request):
+    """The forms of the sliced-pattern product (option sliced.form; sliced.runs: lists of runs of three
+    taken run by run or entry by entry) and of its two-vector variant (sliced.pair_form); the defaults
+    are restored afterwards."""
+    form, pair_form, runs = request.param
+    defaults = {}
+    for key, value in ((b"sliced.form", form), (b"sliced.pair_form", pair_form), (b"sliced.runs", runs)):
+        old = ctypes.c_int(0)
+        _lib.call("lsk_get_option", key, ctypes.byref(old))
+        defaults[key] = old.value
+        _lib.call("lsk_set_option", key, value)
+    yield request.param
+    for key, value in defaults.items():
+        _lib.call("lsk_set_option", key, value)
+
+
 @pytest.mark.parametrize("suf", ["f64", "f32"])
-def test_csr_sliced_patterns_bit_exact(suf):
+def test_csr_sliced_patterns_bit_exact(suf, sliced_forms):
     npdt = DT[suf][0]
     rng = np.random.default_rng(17)
     for flag, extent in ((1, (1000,)), (2, (37, 41)), (3, (9, 11, 13)), (4, (7, 12, 70)), (4, (3, 3, 3))):

@@ -13,7 +13,7 @@ import time
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from legionsolvers_amd import Context  # noqa: E402
+from legionsolvers_amd import Context, _lib  # noqa: E402
 from legionsolvers_amd import benchmark_stencil as bs  # noqa: E402
 
 
@@ -47,6 +47,28 @@ def main():
         out["sliced_TBps"] = round(out["sliced_bytes"] / out["sliced_ms"] / 1e9, 3)
         out.update(patterns=s.patterns, mixed_blocks=s.mixed_blocks, masked_waves=s.masked_waves, blocks=s.blocks, padded_entries=s.padded_entries,
                    placement=matrix.sliced_placement)
+        # two right-hand sides with one pass over the values (lsk_csr_sliced_spmv2_*), both forms
+        be = ctx.backend
+        xs = [planner.get_vector(2, 0)._own, planner.get_vector(2, 0)._own.clone()]
+        ys = [planner.get_vector(3, 0)._own, planner.get_vector(3, 0)._own.clone()]
+        for pair_form in (1, 0):
+            _lib.call("lsk_set_option", b"sliced.pair_form", pair_form)
+            if be.csr_sliced_spmv2(s, matrix.rows, xs, ys, 0, placement=matrix.sliced_placement.get(0, 0)) is not None:
+                for place2 in (0, 16, 64, 256, 1024):   # workgroup -> XCD placements
+                    ms = timed(ctx, lambda: be.csr_sliced_spmv2(s, matrix.rows, xs, ys, 0, placement=place2), 10)
+                    out[f"pair_form{pair_form}_place{place2}_ms"] = round(ms, 3)
+        _lib.call("lsk_set_option", b"sliced.pair_form", -1)
+        # both forms of the one-vector product, plain and with the fused dot shares, called directly
+        place = matrix.sliced_placement.get(0, 0)
+        shares = torch.empty(be.csr_sliced_dot_slots(s, matrix.rows), dtype=dtype, device="cuda")
+        for form, label in ((0, "block_form"), (1, "wave_form")):
+            _lib.call("lsk_set_option", b"sliced.form", form)
+            for place1 in (16, 64, 256):
+                out[f"{label}_place{place1}_ms"] = round(timed(ctx, lambda: be.csr_sliced_spmv(s, 0, matrix.rows, xs[0], ys[0], 0, place1), 10), 3)
+            out[f"{label}_ms"] = round(timed(ctx, lambda: be.csr_sliced_spmv(s, 0, matrix.rows, xs[0], ys[0], 0, place), 20), 3)
+            out[f"{label}_dot_ms"] = round(timed(ctx, lambda: be.csr_sliced_spmv_dot(s, matrix.rows, xs[0], ys[0], 0, xs[1],
+                                                                                   shares, place), 20), 3)
+        _lib.call("lsk_set_option", b"sliced.form", int(os.environ.get("LSK_SLICED_FORM", "0")))
         a = planner.get_vector(3, 0).owned.clone()
         held, matrix.sliced_window = matrix.sliced_window, None
         out["c32_ms"] = round(timed(ctx, lambda: planner.matvec(3, 2), 20), 3)
