@@ -9,7 +9,8 @@
 // transpose and prints it against the product itself (the stencil matrices are symmetric) and both
 // sides of <A x, b> = <x, A^T b>; N > 1 transposes in runs of N entries; -binned 1 (with -coo 1) multiplies
 // through the binned copy of the COO matrix, in blocks of -bincols columns and tiles of -binrows rows
-// (0: the library's choice); -cgs 1 gives GMRES the classical Gram-Schmidt option.
+// (0: the library's choice); -cgs 1 gives GMRES the classical Gram-Schmidt option; -pair 0 multiplies the two
+// systems one after the other instead of in one pass over the matrix.
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -26,7 +27,7 @@ namespace {
 struct Args {
     long dim = 1, solver = 1, nx = 16, ny = 16, nz = 16, vp = 4, it = 20, pt = 1;
     long systems = 2, coo = 0, f32 = 0, restart = 10, history = 0, compress = 1, fuse = 1, redraws = 4, adjoint = 0, sliced = 1;
-    long binned = 0, bincols = 0, binrows = 0, cgs = 0;
+    long binned = 0, bincols = 0, binrows = 0, cgs = 0, pair = 1;
 };
 
 Args parse(int argc, char **argv) {
@@ -38,7 +39,7 @@ Args parse(int argc, char **argv) {
         {"-history", &Args::history}, {"-compress", &Args::compress}, {"-fuse", &Args::fuse},
         {"-redraws", &Args::redraws}, {"-adjoint", &Args::adjoint},
         {"-sliced", &Args::sliced}, {"-binned", &Args::binned}, {"-bincols", &Args::bincols},
-        {"-binrows", &Args::binrows}, {"-cgs", &Args::cgs}};
+        {"-binrows", &Args::binrows}, {"-cgs", &Args::cgs}, {"-pair", &Args::pair}};
     for (int i = 1; i + 1 < argc; i += 2) {
         bool known = false;
         for (const auto &t : table)
@@ -86,6 +87,7 @@ void run(const Context &ctx, const Args &a, Solver &solver, SquarePlanner<T> &pl
             sum2 += static_cast<double>(v) * static_cast<double>(v);
         }
         std::printf("solution_sum %.17g\nsolution_sum_of_squares %.17g\n", sum, sum2);
+        std::printf("paired_products %ld\n", planner.paired_products());
     }
     if (a.adjoint) { // vector 2 is workspace of every solver and free once the steps are done
         planner.rmatvec(2, 0);
@@ -130,6 +132,7 @@ template <typename T> int main_typed(const Args &a) {
     std::vector<std::unique_ptr<PartitionedVector<T>>> sols, rhss;
     SquarePlanner<T> planner(ctx);
     planner.set_fusion(a.fuse != 0);
+    planner.set_pairing(a.pair != 0);
     for (long s = 0; s < a.systems; ++s) {
         sols.push_back(std::make_unique<PartitionedVector<T>>(ctx, s ? "sol1" : "sol", partition));
         sols.back()->zero_fill();

@@ -58,6 +58,8 @@ template <typename T> struct Abi;
         static constexpr auto csr_sliced_create = lsk_csr_sliced_create_##SUF;                     \
         static constexpr auto csr_sliced_spmv = lsk_csr_sliced_spmv_##SUF;                         \
         static constexpr auto csr_sliced_spmv_dot = lsk_csr_sliced_spmv_dot_##SUF;                 \
+        static constexpr auto csr_sliced_spmv2 = lsk_csr_sliced_spmv2_##SUF;                       \
+        static constexpr auto csr_sliced_spmv2_dot = lsk_csr_sliced_spmv2_dot_##SUF;               \
         static constexpr auto csr_sliced_tune = lsk_csr_sliced_tune_##SUF;                         \
         static constexpr auto csr_sliced_update_values = lsk_csr_sliced_update_values_##SUF;       \
         static constexpr auto stencil_fill_csr = lsk_stencil_fill_csr_##SUF;                       \
@@ -429,6 +431,14 @@ public:
     virtual void matvec_dot(PartitionedVector<T> &, const PartitionedVector<T> &, const PartitionedVector<T> &, T *) const {
         throw std::logic_error("this matrix has no fused product + dot");
     }
+    // Optional: dst_a <- A src_a and dst_b <- A src_b in one pass over the matrix (two systems on one
+    // matrix), each bit for bit what matvec(dst, src, 0) gives; with w_a / w_b also the shares of
+    // dot(dst_a, w_a) and dot(dst_b, w_b) as matvec_dot leaves them.  False: not served, nothing launched.
+    virtual bool matvec_pair(PartitionedVector<T> &, PartitionedVector<T> &, const PartitionedVector<T> &,
+                             const PartitionedVector<T> &, const PartitionedVector<T> *, const PartitionedVector<T> *, T *,
+                             T *) const {
+        return false;
+    }
 };
 
 // The CSR form of the transpose of a matrix, in the library's 32-bit structure: one row per element
@@ -599,6 +609,41 @@ public:
                                               shares_of(c, rows), &count, ctx_->stream()));
             shares += count;
         }
+    }
+    bool matvec_pair(PartitionedVector<T> &dst_a, PartitionedVector<T> &dst_b, const PartitionedVector<T> &src_a,
+                     const PartitionedVector<T> &src_b, const PartitionedVector<T> *w_a, const PartitionedVector<T> *w_b,
+                     T *shares_a, T *shares_b) const override {
+        if (!sliced()) return false;
+        if (!(dst_a.partition() == range_) || !(dst_b.partition() == range_) || src_a.partition().n != domain_ ||
+            src_b.partition().n != domain_)
+            throw std::invalid_argument("matrix and vectors do not fit");
+        for (int c = 0; c < range_.colors(); ++c) { // all pieces or none
+            if (range_.volume(c) <= 0) continue;
+            int64_t info[8] = {};
+            if (!sliced_[c].handle) return false;
+            check(lsk_csr_sliced_info(sliced_[c].handle, info));
+            if (!info[7]) return false;
+        }
+        for (int c = 0; c < range_.colors(); ++c) {
+            const int64_t rows = range_.volume(c);
+            if (rows <= 0) continue;
+            check(lsk_set_option("xcd_remap", sliced_[c].placement));
+            int status;
+            int64_t count = 0;
+            if (w_a)
+                status = Abi<T>::csr_sliced_spmv2_dot(sliced_[c].handle, 0, rows, src_a.data(), src_b.data(), dst_a.piece(c),
+                                                      dst_b.piece(c), 0, w_a->piece(c), w_b->piece(c), shares_a, shares_b,
+                                                      shares_of(c, rows), &count, ctx_->stream());
+            else
+                status = Abi<T>::csr_sliced_spmv2(sliced_[c].handle, 0, rows, src_a.data(), src_b.data(), dst_a.piece(c),
+                                                  dst_b.piece(c), 0, ctx_->stream());
+            check(status);
+            if (w_a) {
+                shares_a += count;
+                shares_b += count;
+            }
+        }
+        return true;
     }
     void rmatvec(PartitionedVector<T> &dst, const PartitionedVector<T> &src, int beta) const override {
         if (!(src.partition() == range_) || dst.partition().n != domain_)
@@ -907,6 +952,9 @@ public:
     // any other operation of the planner, only adds up.  set_fusion(false) launches every leaf as it
     // is asked for.
     void set_fusion(bool on) { fuse_ = on; }
+    // Whether two systems on one matrix are multiplied in one pass over it (same results either way).
+    void set_pairing(bool on) { pair_ = on; }
+    long paired_products() const { return paired_products_; } // how many times two products shared a pass
     void axpy(int dst, const std::vector<Scalar<T>> &alpha, int src) {
         pending_.reset();
         const bool defer = fuse_ && src >= 2 && dst != RHS && dst != src;
@@ -978,7 +1026,45 @@ public:
         for (const auto &e : matrices_) ++writers[e.range];
         Pending pending{dst, src, std::vector<int64_t>(spaces, 0)};
         bool any = false;
-        for (const auto &e : matrices_) {
+        std::vector<bool> done(matrices_.size(), false);
+        for (size_t i = 0; i < matrices_.size(); ++i) {
+            const auto &e = matrices_[i];
+            if (done[i]) continue;
+            // Two systems on ONE matrix (the reference's BenchmarkStencil, test/BenchmarkStencil.cpp:181-199):
+            // both products in one pass over the matrix values where each alone produces its range space.
+            if (pair_ && writers[e.range] == 1 && e.domain == e.range && !touched[e.range]) {
+                size_t mate = matrices_.size();
+                for (size_t j = i + 1; j < matrices_.size() && mate == matrices_.size(); ++j) {
+                    const auto &f = matrices_[j];
+                    if (!done[j] && f.matrix == e.matrix && f.range != e.range && writers[f.range] == 1 &&
+                        f.domain == f.range && !touched[f.range])
+                        mate = j;
+                }
+                if (mate < matrices_.size()) {
+                    const auto &f = matrices_[mate];
+                    const int64_t shares = e.matrix->dot_shares();
+                    const bool with_dot = fuse_ && dst >= 2 && src >= 2 && dst != src && shares > 0;
+                    if (with_dot) {
+                        if (share_buffers_.size() < spaces) share_buffers_.resize(spaces);
+                        for (int r : {e.range, f.range})
+                            if (share_buffers_[r].size() < shares) share_buffers_[r] = DeviceArray<T>(shares);
+                    }
+                    if (e.matrix->matvec_pair(*vectors_[dst][e.range], *vectors_[dst][f.range], *vectors_.at(src)[e.domain],
+                                              *vectors_[src][f.domain], with_dot ? vectors_[src][e.range] : nullptr,
+                                              with_dot ? vectors_[src][f.range] : nullptr,
+                                              with_dot ? share_buffers_[e.range].get() : nullptr,
+                                              with_dot ? share_buffers_[f.range].get() : nullptr)) {
+                        done[mate] = true;
+                        ++paired_products_;
+                        touched[e.range] = touched[f.range] = true;
+                        if (with_dot) {
+                            pending.shares[e.range] = pending.shares[f.range] = shares;
+                            any = true;
+                        }
+                        continue;
+                    }
+                }
+            }
             PartitionedVector<T> &y = *vectors_[dst][e.range];
             const int64_t shares = e.matrix->dot_shares();
             if (fuse_ && dst >= 2 && src >= 2 && dst != src && writers[e.range] == 1 && e.domain == e.range && shares > 0) {
@@ -1025,6 +1111,8 @@ private:
     }
     const Context *ctx_;
     bool fuse_ = true;
+    bool pair_ = true;
+    long paired_products_ = 0;
     std::vector<std::vector<PartitionedVector<T> *>> vectors_;
     std::vector<std::unique_ptr<PartitionedVector<T>>> owned_;
     std::vector<Entry> matrices_;

@@ -1392,6 +1392,11 @@ int spmv(const char *name, const lsk_csr_sliced *m, int64_t row_begin, int64_t r
     return LSK_OK;
 }
 
+// Whether the two-vector kernels serve the structure: every block on one staged list, both windows within a CU's LDS.
+inline bool pair_served(const lsk_csr_sliced *m) {
+    return m->all_staged && m->mixed_blocks == 0 && 2 * m->lds_bytes <= (size_t(150) << 10);
+}
+
 template <typename T>
 int spmv2(const char *name, const lsk_csr_sliced *m, int64_t row_begin, int64_t row_end, const T *xa, const T *xb, T *ya,
           T *yb, int beta, const T *wa, const T *wb, T *pa, T *pb, int64_t capacity, int64_t *count, lsk_stream_t stream) {
@@ -1404,7 +1409,7 @@ int spmv2(const char *name, const lsk_csr_sliced *m, int64_t row_begin, int64_t 
         return lsk::fail(LSK_ERR_ARG, "%s: rows %lld..%lld of %lld", name, (long long)row_begin, (long long)row_end,
                          (long long)m->rows);
     if (beta != 0 && beta != 1) return lsk::fail(LSK_ERR_ARG, "%s: beta must be 0 or 1", name);
-    if (!m->all_staged || m->mixed_blocks > 0 || 2 * m->lds_bytes > (size_t(150) << 10))
+    if (!pair_served(m))
         return lsk::decline(LSK_ERR_UNSUPPORTED, "%s: not every block of this structure runs on one staged list", name);
     if (row_begin == row_end) return LSK_OK;
     if (!xa || !xb || !ya || !yb) return lsk::fail(LSK_ERR_ARG, "%s: null vector", name);
@@ -1588,6 +1593,7 @@ int lsk_csr_sliced_info(const lsk_csr_sliced_t *m, int64_t *out) {
     out[4] = m->masked_waves;
     out[5] = int64_t(kBlock) * (16 / m->elem_bytes);
     out[6] = static_cast<int64_t>(m->lds_bytes);
+    out[7] = pair_served(m) ? 1 : 0;
     return LSK_OK;
 }
 

@@ -649,7 +649,8 @@ class CSRMatrix(AbstractMatrix, _SlicedCopies):
         be = self.ctx.backend
         return (getattr(be, "csr_sliced_spmv2", None) is not None and os.environ.get("LSK_PAIR", "1") != "0"
                 and self.sliced_window == (x_lo, x_hi)
-                and all(c in self.sliced for c in kernel_partition.colors if range_partition.pieces[c].volume > 0))
+                and all(c in self.sliced and self.sliced[c].pair_served
+                        for c in kernel_partition.colors if range_partition.pieces[c].volume > 0))
 
     def matvec_pair(self, dsts, xs, x_lo, x_hi, kernel_partition, dot_with=None, range_partition=None) -> bool:
         """dsts[k] <- A xs[k] for k = 0, 1 with ONE pass over the values (two systems on one matrix: what

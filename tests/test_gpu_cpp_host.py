@@ -135,3 +135,19 @@ def test_classical_gram_schmidt_option_follows_the_oracle(vp):
     x = opl.get_vector(0, 0).astype(np.float64)
     np.testing.assert_allclose(sums["solution_sum_of_squares"], float(np.sum(x * x)), rtol=1e-8)
     assert abs(sums["solution_sum"] - float(np.sum(x))) <= 1e-8 * float(np.sum(np.abs(x)))
+
+
+@pytest.mark.parametrize("solver", [1, 2, 3])
+def test_two_systems_in_one_pass_print_the_same(solver):
+    """The program's two systems on one matrix, multiplied in one pass over its values (the default)
+    and one after the other (-pair 0): the same history and solution sums to the last digit."""
+    for grid, vp in (((13, 11, 17), 2), ((40, 16, 24), 1)):
+        flags = ("-dim", 4, "-nx", grid[0], "-ny", grid[1], "-nz", grid[2], "-vp", vp, "-solver", solver, "-it", 7,
+                 "-restart", 4, "-history", 1)
+        paired, separate = run(*flags)[2], run(*flags, "-pair", 0)[2]
+        count = lambda lines: int([l for l in lines if l.startswith("paired_products")][0].split()[1])
+        assert count(separate) == 0
+        assert [l for l in paired if not l.startswith("paired_products")] == \
+               [l for l in separate if not l.startswith("paired_products")]
+        if vp == 1:
+            assert count(paired) > 0   # (a piece with a block of mixed rows makes the library decline the pair)

@@ -697,7 +697,7 @@ def sliced_case(suf, rects, k_base, col, val, x, x_lo, x_hi, row_first, tag, exp
         assert code == _lib.LSK_ERR_UNSUPPORTED and not handle.value, f"{tag}: create said {code}"
         return None
     assert code == _lib.LSK_OK, f"{tag}: create said {code}: {_lib.lib().lsk_last_error().decode()}"
-    info = (ctypes.c_int64 * 7)()
+    info = (ctypes.c_int64 * 8)()
     _lib.call("lsk_csr_sliced_info", handle, info)
     lens = np.maximum(rects[:, 1] - rects[:, 0] + 1, 0)
     br = BLOCK_ROWS[suf]
@@ -740,7 +740,8 @@ def sliced_case(suf, rects, k_base, col, val, x, x_lo, x_hi, row_first, tag, exp
                                                                    slots - 1, ctypes.byref(count), stream())
         assert code == _lib.LSK_ERR_ARG and count.value == 0, f"{tag}: short partials buffer accepted"
         sliced_pair_case(suf, handle, rows, br, xd, x.size, y0, wd, partials[:slots].clone(), tag,
-                         must_serve=tag.startswith("stencil"))
+                         must_serve=bool(info[7]))
+        assert info[7] == 1 or not tag.startswith("stencil"), f"{tag}: the two-vector product should serve a stencil"
     finally:
         _lib.call("lsk_csr_sliced_destroy", handle)
     return list(info)
@@ -764,7 +765,8 @@ def sliced_pair_case(suf, handle, rows, br, xd, x_size, y0, wd, shares_a, tag, m
             want.append(yd)
         ya, yb = dev(y0), dev(y0)
         code = getattr(lib, f"lsk_csr_sliced_spmv2_{suf}")(handle, ra, rb, P(xd), P(xb), P(ya), P(yb), beta, stream())
-        if code == _lib.LSK_ERR_UNSUPPORTED and not must_serve:
+        if not must_serve:   # the info call said so: the product declines, whatever the rows
+            assert code == _lib.LSK_ERR_UNSUPPORTED, f"{tag}: spmv2 said {code} for a structure it does not serve"
             print(f"case csr_sliced_spmv2_{suf} {tag}: declined (blocks without one staged list)", flush=True)
             return
         assert code == _lib.LSK_OK, f"{tag}: spmv2 said {code}: {lib.lsk_last_error().decode()}"
