@@ -147,6 +147,14 @@ def cpu_baseline(matrix, n1: int):
     }
 
 
+def library_option(key: str) -> int:
+    import ctypes
+    from legionsolvers_amd import _lib
+    value = ctypes.c_int(0)
+    _lib.call("lsk_get_option", key.encode(), ctypes.byref(value))
+    return value.value
+
+
 def host_ms_per_step(ctx, world: int) -> float:
     """What the host spends enqueueing one CG step: the same solver on a 32^3 grid, where the GPU
     finishes a step's kernels faster than the host issues them, so wall time per step is host time."""
@@ -231,7 +239,13 @@ def main():
         parts = list(matrix.sliced.values())
         algo_bytes = sum(p.algorithmic_bytes(partition.pieces[c].volume, 8) for c, p in matrix.sliced.items())
         cap = 27
-        kernel = f"sliced_spmv_kernel<double, {cap}, {'true' if planner_fuses_dot(planner) else 'false'}, false>"
+        dot = "true" if planner_fuses_dot(planner) else "false"
+        opt = {key: library_option(key) for key in ("sliced.form", "sliced.dma", "sliced.runs")}
+        if opt["sliced.form"] == 1:   # <T, CAP, DOT, K, RUN3, DMA>: wave-staged windows (the library's default)
+            kernel = (f"sliced_wave_kernel<double, {cap}, {dot}, 1, {'true' if opt['sliced.runs'] else 'false'}, "
+                      f"{'true' if opt['sliced.dma'] else 'false'}>")
+        else:
+            kernel = f"sliced_spmv_kernel<double, {cap}, {dot}, false>"
         layout = ("sliced-pattern copy made once at set-up: the values in blocks of 512 rows (16 bytes per lane and "
                   "entry), one column-pattern id per block (27 patterns), no column array and no row offsets; x "
                   "staged through LDS; every row summed in entry order, bit for bit the CPU restatement of the "

@@ -65,11 +65,12 @@ void lsk_set_abort_on_error(int enable);
  * -1 = for vectors of 256 MiB and more, the default), "coo.variant" (0 workgroup chunks through LDS | 1 wave-wide segmented
  * scan, default 1), "comm.skip_single_rank" (1, the default: lsk_allreduce_sum_* / lsk_allgather_* on a
  * one-rank communicator answer without calling RCCL | 0: they enqueue the RCCL collective all the
- * same), "sliced.form" (sliced-pattern product: 0 block-staged windows of x, the default | 1 every wave
- * stages its own windows and the block meets only to write y), "sliced.runs" (1, the default: the
- * wave-staged form reads lists of runs of three run by run | 0 entry by entry), "sliced.pair_form"
- * (lsk_csr_sliced_spmv2_*: 0 both vectors' windows in LDS at once | 1 wave-staged, one vector after the
- * other | -1, the default: 0 for lists of more than 20 entries, else 1).  No counterpart in the reference
+ * same), "sliced.form" (sliced-pattern product: 1, the default: every wave stages the windows of x of its
+ * own rows and the block meets only to write y | 0 block-staged windows, one barrier before the sums),
+ * "sliced.dma" (1, the default: the wave-staged form sends the windows from memory straight into LDS | 0
+ * through registers), "sliced.runs" (1, the default: it reads lists of runs of three run by run | 0 entry
+ * by entry), "sliced.pair_form" (lsk_csr_sliced_spmv2_*: 1 wave-staged, one vector after the other | 0
+ * both vectors' windows in LDS at once | -1, the default: 1 where that form serves the structure).  No counterpart in the reference
  * (cuSPARSE picks its own algorithm behind CUSPARSE_SPMV_ALG_DEFAULT).  All other options
  * are process-wide and read at launch time without synchronisation: set them between launches. */
 int lsk_set_option(const char *key, int value);

@@ -125,6 +125,8 @@ int lsk_set_option(const char *key, int value) {
     } else if (!std::strcmp(key, "sliced.form")) {
         if (value != 0 && value != 1) return lsk::fail(LSK_ERR_ARG, "sliced.form must be 0 or 1");
         o.sliced_form = value;
+    } else if (!std::strcmp(key, "sliced.dma")) {
+        o.sliced_dma = value != 0;
     } else if (!std::strcmp(key, "sliced.runs")) {
         o.sliced_runs = value != 0;
     } else if (!std::strcmp(key, "sliced.pair_form")) {
@@ -149,6 +151,7 @@ int lsk_get_option(const char *key, int *value) {
     else if (!std::strcmp(key, "coo.variant")) *value = o.coo_variant;
     else if (!std::strcmp(key, "comm.skip_single_rank")) *value = o.comm_skip_single_rank;
     else if (!std::strcmp(key, "sliced.form")) *value = o.sliced_form;
+    else if (!std::strcmp(key, "sliced.dma")) *value = o.sliced_dma;
     else if (!std::strcmp(key, "sliced.runs")) *value = o.sliced_runs;
     else if (!std::strcmp(key, "sliced.pair_form")) *value = o.sliced_pair_form;
     else return lsk::fail(LSK_ERR_ARG, "lsk_get_option: unknown key '%s'", key);

@@ -616,6 +616,9 @@ __global__ __launch_bounds__(kBlock, (sliced_waves_per_simd<T, CAP, GENERAL>()))
 // loaded once (two systems on one matrix, what the reference's BenchmarkStencil steps,
 // test/BenchmarkStencil.cpp:181-199); each is summed in entry order, bit for bit what the one-vector
 // product gives for it.  Staged lists only (every block on one staged list).
+#ifndef LSK_WAVE_AHEAD
+#define LSK_WAVE_AHEAD 0
+#endif
 #ifndef LSK_WAVE_K2_WAVES
 #define LSK_WAVE_K2_WAVES 2
 #endif
@@ -625,7 +628,10 @@ template <int K, int CAP> constexpr int sliced_wave_waves_per_simd() {
 // RUN3: every list is runs of three consecutive distances.  The R rows of a lane then need R + 2
 // consecutive elements of a run's window, taken with two aligned 16-byte LDS reads per run instead of
 // three unaligned ones per entry -- a third of the LDS time -- and used in the same entry order.
-template <typename T, int CAP, bool DOT, int K, bool RUN3>
+// DMA: a window that lies wholly inside the vector goes from memory straight into LDS (one
+// global_load_lds_dwordx4 per window and wave: no registers, nothing to wait for before the next
+// request), the others through registers as before.
+template <typename T, int CAP, bool DOT, int K, bool RUN3, bool DMA>
 __global__ __launch_bounds__(kBlock, (sliced_wave_waves_per_simd<K, CAP>())) void sliced_wave_kernel(
     int64_t block_begin, int64_t row_begin, int64_t row_end, const BlockMeta *__restrict__ meta,
     const T *__restrict__ val, const unsigned *__restrict__ row_mask, const PatternInfo *__restrict__ table,
@@ -667,69 +673,106 @@ __global__ __launch_bounds__(kBlock, (sliced_wave_waves_per_simd<K, CAP>())) voi
     const long long xlast = x_extent - 1;
     const unsigned lenmask = maxlen >= 32 ? 0xffffffffu : (1u << maxlen) - 1u;
     const bool plain = !masked && __all(all_live);
-    const T *lane_xs = xs + lane * R;
     V v[CAP];
     unsigned packed[(CAP + 1) / 2];
     T result[K][R];
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-        const T *x = k == 0 ? xa : xb;
-        const T *yin = k == 0 ? ya : yb;
-        auto fetch = [&](long long xi) {
-            const long long c = xi < 0 ? 0 : (xi > xlast ? xlast : xi);
-            const T got = x[c];
-            return c == xi ? got : T(0);
-        };
-        // All of a list's windows are requested at once (a 27-point list has 9; a batch that is not
-        // full repeats its last run, harmlessly), and the few elements by which they are wider than
-        // the wave's rows with them: one trip to memory, not one per batch of four.
+    // AHEAD: both vectors' windows requested before anything is summed, each into its own LDS area; else
+    // the vectors share one area, one after the other.  Measured with the windows going straight into
+    // LDS: ahead 7.5 ms, one after the other 6.3 ms for the pair on the 27-point 512^3 fp64 matrix (the
+    // second area takes the third workgroup from the CU), so it is off.
+    constexpr bool AHEAD = LSK_WAVE_AHEAD && DMA && K == 2;
 #ifndef LSK_WAVE_QB
 #define LSK_WAVE_QB (CAP > 20 ? 9 : CAP > 8 ? 6 : 5)
 #endif
-        constexpr int QB = LSK_WAVE_QB;
-        const bool has_tail = lane < info.w_ntail;
-        T tail = T(0);
-        if (has_tail) tail = fetch(r0 + x_shift + info.w_tail_dist[lane]);
-        for (int q0 = 0; q0 < nruns; q0 += QB) {
-            T got[QB][R];
-            int start[QB], off[QB];
+    constexpr int QB = LSK_WAVE_QB;
+    const bool has_tail = lane < info.w_ntail;
+    T tail[K];
+    auto fetch_from = [&](const T *x, long long xi) {
+        const long long c = xi < 0 ? 0 : (xi > xlast ? xlast : xi);
+        const T got = x[c];
+        return c == xi ? got : T(0);
+    };
+    // Requests vector k's windows: all of a list's windows at once (a 27-point list has 9), and the few
+    // elements by which they are wider than the wave's rows with them -- one trip to memory, not one per
+    // batch.  Those few elements come back in a register and are written by finish_stage.
+    auto stage = [&](int k, T *area) {
+        const T *x = k == 0 ? xa : xb;
+        tail[k] = T(0);
+        if (has_tail) tail[k] = fetch_from(x, r0 + x_shift + info.w_tail_dist[lane]);
+        if constexpr (DMA) {
+            for (int q = 0; q < nruns; ++q) {
+                const long long first = r0 + x_shift + info.run_start[q]; // (wave-uniform)
+                T *dst = area + info.w_run_off[q];
+                if (first >= 0 && first + kWaveRows <= x_extent) {
+                    __builtin_amdgcn_global_load_lds(
+                        (const __attribute__((address_space(1))) void *)(x + first + lane * R),
+                        (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+                } else { // a window that reaches past an end of the vector: element by element, clamped
 #pragma unroll
-            for (int qi = 0; qi < QB; ++qi) {
-                const int q = q0 + qi < kMaxRuns ? q0 + qi : kMaxRuns - 1; // (slots past the last run repeat it)
-                start[qi] = info.run_start[q];
-                off[qi] = info.w_run_off[q];
+                    for (int i = 0; i < R; ++i) dst[lane + i * kWave] = fetch_from(x, first + lane + i * kWave);
+                }
             }
+        } else {
+            for (int q0 = 0; q0 < nruns; q0 += QB) {
+                T got[QB][R];
+                int start[QB], off[QB];
 #pragma unroll
-            for (int qi = 0; qi < QB; ++qi) {
-                const long long first = xbase + start[qi];
+                for (int qi = 0; qi < QB; ++qi) {
+                    const int q = q0 + qi < kMaxRuns ? q0 + qi : kMaxRuns - 1; // (slots past the last run repeat it)
+                    start[qi] = info.run_start[q];
+                    off[qi] = info.w_run_off[q];
+                }
 #pragma unroll
-                for (int i = 0; i < R; ++i) got[qi][i] = fetch(first + i * kWave);
-            }
+                for (int qi = 0; qi < QB; ++qi) {
+                    const long long first = xbase + start[qi];
 #pragma unroll
-            for (int qi = 0; qi < QB; ++qi) {
-                T *dst = xs + off[qi] + lane;
+                    for (int i = 0; i < R; ++i) got[qi][i] = fetch_from(x, first + i * kWave);
+                }
 #pragma unroll
-                for (int i = 0; i < R; ++i) dst[i * kWave] = got[qi][i];
+                for (int qi = 0; qi < QB; ++qi) {
+                    T *dst = area + off[qi] + lane;
+#pragma unroll
+                    for (int i = 0; i < R; ++i) dst[i * kWave] = got[qi][i];
+                }
             }
         }
-        if (has_tail) xs[info.w_tail_off[lane]] = tail;
-        if (k == 0) {
-            // every entry's place in LDS into scalar registers now: a scalar load between the LDS reads
-            // below would make each of them wait for the one before
+    };
+    auto load_values = [&]() {
+        // every entry's place in LDS into scalar registers now: a scalar load between the LDS reads
+        // below would make each of them wait for the one before
 #pragma unroll
-            for (int i = 0; i < (CAP + 1) / 2; ++i) packed[i] = info.w_lds_off_packed[i];
-            __builtin_amdgcn_sched_barrier(0); // (the value loads stay behind the staging, whose registers they take)
+        for (int i = 0; i < (CAP + 1) / 2; ++i) packed[i] = info.w_lds_off_packed[i];
+        __builtin_amdgcn_sched_barrier(0); // (the value loads stay behind the staging, whose registers they take)
 #pragma unroll
-            for (int j = 0; j < CAP; ++j) {
-                if (j < maxlen) v[j] = __builtin_nontemporal_load(reinterpret_cast<const V *>(vp + int64_t(j) * kWaveRows));
-                else v[j] = V(0);
-            }
+        for (int j = 0; j < CAP; ++j) {
+            if (j < maxlen) v[j] = __builtin_nontemporal_load(reinterpret_cast<const V *>(vp + int64_t(j) * kWaveRows));
+            else v[j] = V(0);
         }
-        // the wave's own LDS writes are in place before its reads: LDS serves a wave's accesses in order,
-        // and the fence keeps the compiler from moving the reads up
+    };
+    if constexpr (AHEAD) {
+        stage(0, xs);
+        stage(1, xs + lds_wave_elems / 2);
+        load_values();
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const T *yin = k == 0 ? ya : yb;
+        T *area = AHEAD ? xs + k * (lds_wave_elems / 2) : xs;
+        if constexpr (!AHEAD) {
+            stage(k, area);
+            if (k == 0) load_values();
+        }
+        // A window that went straight into LDS has landed when the load counter says so.  The wave's own
+        // LDS writes are in place before its reads: LDS serves a wave's accesses in order, and the fence
+        // keeps the compiler from moving the reads up.
+        if constexpr (DMA) {
+            if (!AHEAD || k == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        if (has_tail) area[info.w_tail_off[lane]] = tail[k];
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const T *lane_xs = area + lane * R;
         T acc[R];
 #pragma unroll
         for (int h = 0; h < R; ++h) acc[h] = (beta && live[h]) ? yin[r + h] : T(0);
@@ -1303,12 +1346,25 @@ int launch_wave(const lsk_csr_sliced *m, int64_t block_begin, unsigned blocks, i
     const T *val = static_cast<const T *>(m->val);
     const long long x_shift = m->row_first - m->x_lo, x_extent = m->x_hi - m->x_lo + 1;
     const int remap = lsk::xcd_remap_option();
-    const int wave_elems = static_cast<int>(m->wave_lds_bytes / sizeof(T));
-    const size_t lds = m->wave_lds_bytes * kWavesPerBlock;
+    const bool dma = lsk::options().sliced_dma != 0;
+    const int areas = (LSK_WAVE_AHEAD && dma && K == 2) ? 2 : 1; // LDS areas per wave (see AHEAD in the kernel)
+    const int wave_elems = static_cast<int>(m->wave_lds_bytes / sizeof(T)) * areas;
+    const size_t lds = m->wave_lds_bytes * kWavesPerBlock * areas;
+#define LSK_WAVE_LAUNCH2(CAP, DOT, RUN3, DMA)                                                                      \
+    do {                                                                                                           \
+        auto kernel = sliced_wave_kernel<T, CAP, DOT, K, RUN3, DMA>;                                               \
+        if (lds > (size_t(64) << 10))                                                                              \
+            LSK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),                                    \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));       \
+        kernel<<<blocks, kBlock, lds, s>>>(block_begin, row_begin, row_end, meta, val, m->row_mask, m->table, xa, xb, \
+                                           x_shift, x_extent, ya, yb, beta, remap, wa, wb, pa, pb, wave_elems,      \
+                                           yw_aligned);                                                            \
+    } while (0)
 #define LSK_WAVE_LAUNCH(CAP, DOT, RUN3)                                                                            \
-    sliced_wave_kernel<T, CAP, DOT, K, RUN3><<<blocks, kBlock, lds, s>>>(                                          \
-        block_begin, row_begin, row_end, meta, val, m->row_mask, m->table, xa, xb, x_shift, x_extent, ya, yb, beta, \
-        remap, wa, wb, pa, pb, wave_elems, yw_aligned)
+    do {                                                                                                           \
+        if (dma) LSK_WAVE_LAUNCH2(CAP, DOT, RUN3, true);                                                           \
+        else LSK_WAVE_LAUNCH2(CAP, DOT, RUN3, false);                                                              \
+    } while (0)
 #define LSK_WAVE_CAP(CAP, RUN3)                                                                                    \
     do {                                                                                                           \
         if (dot) LSK_WAVE_LAUNCH(CAP, true, RUN3);                                                                 \
@@ -1323,6 +1379,7 @@ int launch_wave(const lsk_csr_sliced *m, int64_t block_begin, unsigned blocks, i
     else LSK_WAVE_CAP(32, false);
 #undef LSK_WAVE_CAP
 #undef LSK_WAVE_LAUNCH
+#undef LSK_WAVE_LAUNCH2
     LSK_LAUNCH_CHECK();
     return LSK_OK;
 }
@@ -1430,7 +1487,7 @@ int spmv2(const char *name, const lsk_csr_sliced *m, int64_t row_begin, int64_t 
     const size_t lds = 2 * m->lds_bytes;
     hipStream_t s = lsk::as_stream(stream);
     const int pair_form = lsk::options().sliced_pair_form;
-    if ((pair_form == 1 || (pair_form < 0 && m->max_len <= 20)) && wave_form_serves(m)) {
+    if (pair_form != 0 && wave_form_serves(m)) {
         const int rc = launch_wave<T, 2>(m, block_begin, blocks, row_begin, row_end, xa, xb, ya, yb, beta, wa, wb, pa, pb, dot,
                                          yw_aligned, s);
         if (rc == LSK_OK && dot) *count = blocks;

@@ -788,16 +788,17 @@ def sliced_pair_case(suf, handle, rows, br, xd, x_size, y0, wd, shares_a, tag, m
     assert getattr(lib, f"lsk_csr_sliced_spmv2_{suf}")(handle, 0, rows, P(xd), P(xb), P(ya), P(ya), 0, stream()) == _lib.LSK_ERR_ARG
 
 
-@pytest.fixture(params=[(0, -1, 1), (0, 1, 1), (1, 0, 1), (1, 1, 0)],
-                ids=["chosen-by-the-library", "block-staged,pair-by-waves", "wave-staged,pair-in-one-area",
-                     "wave-staged,entry-by-entry"])
+@pytest.fixture(params=[(1, -1, 1, 1), (0, 1, 1, 0), (1, 0, 1, 0), (1, 1, 0, 0), (0, 0, 1, 1)],
+                ids=["the-defaults", "block-staged,pair-by-waves-through-registers", "wave-staged-through-registers,pair-block-staged",
+                     "wave-staged,entry-by-entry", "block-staged,pair-block-staged"])
 def sliced_forms(request):
     """The forms of the sliced-pattern product (option sliced.form; sliced.runs: lists of runs of three
-    taken run by run or entry by entry) and of its two-vector variant (sliced.pair_form); the defaults
-    are restored afterwards."""
-    form, pair_form, runs = request.param
+    taken run by run or entry by entry; sliced.dma: windows of x from memory straight into LDS) and of
+    its two-vector variant (sliced.pair_form); the defaults are restored afterwards."""
+    form, pair_form, runs, dma = request.param
     defaults = {}
-    for key, value in ((b"sliced.form", form), (b"sliced.pair_form", pair_form), (b"sliced.runs", runs)):
+    for key, value in ((b"sliced.form", form), (b"sliced.pair_form", pair_form), (b"sliced.runs", runs),
+                       (b"sliced.dma", dma)):
         old = ctypes.c_int(0)
         _lib.call("lsk_get_option", key, ctypes.byref(old))
         defaults[key] = old.value

@@ -18,7 +18,7 @@ def means(path, counter):
         if r["Counter_Name"] != counter:
             continue
         name = r["Kernel_Name"]
-        key = ("spmv_sliced" if "sliced_spmv" in name else
+        key = ("spmv_sliced" if ("sliced_spmv" in name or "sliced_wave" in name) else
                "spmv_c32" if "csr_spmv" in name and "unsigned int" in name else
                "spmv" if "csr_spmv" in name else "dot" if "dot_kernel" in name else None)
         if key:

@@ -51,24 +51,28 @@ def main():
         be = ctx.backend
         xs = [planner.get_vector(2, 0)._own, planner.get_vector(2, 0)._own.clone()]
         ys = [planner.get_vector(3, 0)._own, planner.get_vector(3, 0)._own.clone()]
-        for pair_form in (1, 0):
-            _lib.call("lsk_set_option", b"sliced.pair_form", pair_form)
+        for pair_form in (1, 0, 2):   # 2: wave-staged with the windows straight into LDS
+            _lib.call("lsk_set_option", b"sliced.pair_form", min(pair_form, 1))
+            _lib.call("lsk_set_option", b"sliced.dma", 1 if pair_form == 2 else 0)
             if be.csr_sliced_spmv2(s, matrix.rows, xs, ys, 0, placement=matrix.sliced_placement.get(0, 0)) is not None:
-                for place2 in (0, 16, 64, 256, 1024):   # workgroup -> XCD placements
+                for place2 in (0, 64):   # workgroup -> XCD placements
                     ms = timed(ctx, lambda: be.csr_sliced_spmv2(s, matrix.rows, xs, ys, 0, placement=place2), 10)
                     out[f"pair_form{pair_form}_place{place2}_ms"] = round(ms, 3)
         _lib.call("lsk_set_option", b"sliced.pair_form", -1)
+        _lib.call("lsk_set_option", b"sliced.dma", 1)
         # both forms of the one-vector product, plain and with the fused dot shares, called directly
         place = matrix.sliced_placement.get(0, 0)
         shares = torch.empty(be.csr_sliced_dot_slots(s, matrix.rows), dtype=dtype, device="cuda")
-        for form, label in ((0, "block_form"), (1, "wave_form")):
+        for form, label in ((0, "block_form"), (1, "wave_form"), (1, "wave_dma_form")):
             _lib.call("lsk_set_option", b"sliced.form", form)
-            for place1 in (16, 64, 256):
+            _lib.call("lsk_set_option", b"sliced.dma", 1 if "dma" in label else 0)
+            for place1 in (64,):
                 out[f"{label}_place{place1}_ms"] = round(timed(ctx, lambda: be.csr_sliced_spmv(s, 0, matrix.rows, xs[0], ys[0], 0, place1), 10), 3)
             out[f"{label}_ms"] = round(timed(ctx, lambda: be.csr_sliced_spmv(s, 0, matrix.rows, xs[0], ys[0], 0, place), 20), 3)
             out[f"{label}_dot_ms"] = round(timed(ctx, lambda: be.csr_sliced_spmv_dot(s, matrix.rows, xs[0], ys[0], 0, xs[1],
                                                                                    shares, place), 20), 3)
-        _lib.call("lsk_set_option", b"sliced.form", int(os.environ.get("LSK_SLICED_FORM", "0")))
+        _lib.call("lsk_set_option", b"sliced.dma", 1)
+        _lib.call("lsk_set_option", b"sliced.form", int(os.environ.get("LSK_SLICED_FORM", "1")))
         a = planner.get_vector(3, 0).owned.clone()
         held, matrix.sliced_window = matrix.sliced_window, None
         out["c32_ms"] = round(timed(ctx, lambda: planner.matvec(3, 2), 20), 3)
