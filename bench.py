@@ -242,7 +242,8 @@ def main():
         dot = "true" if planner_fuses_dot(planner) else "false"
         opt = {key: library_option(key) for key in ("sliced.form", "sliced.dma", "sliced.runs")}
         if opt["sliced.form"] == 1:   # <T, CAP, DOT, K, RUN3, DMA>: wave-staged windows (the library's default)
-            kernel = (f"sliced_wave_kernel<double, {cap}, {dot}, 1, {'true' if opt['sliced.runs'] else 'false'}, "
+            run3 = bool(opt["sliced.runs"]) and all(p.runs_of_three for p in parts)
+            kernel = (f"sliced_wave_kernel<double, {cap}, {dot}, 1, {'true' if run3 else 'false'}, "
                       f"{'true' if opt['sliced.dma'] else 'false'}>")
         else:
             kernel = f"sliced_spmv_kernel<double, {cap}, {dot}, false>"

@@ -619,7 +619,7 @@ public:
             throw std::invalid_argument("matrix and vectors do not fit");
         for (int c = 0; c < range_.colors(); ++c) { // all pieces or none
             if (range_.volume(c) <= 0) continue;
-            int64_t info[8] = {};
+            int64_t info[9] = {};
             if (!sliced_[c].handle) return false;
             check(lsk_csr_sliced_info(sliced_[c].handle, info));
             if (!info[7]) return false;

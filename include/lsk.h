@@ -548,7 +548,8 @@ int lsk_sorted_key_offsets_u32(int64_t n, const uint32_t *keys, int64_t nkeys, u
  * row looks its own up), out[3] = patterns, out[4] = waves (quarter blocks) in which some row has
  * only an ordered part of its block's list (they read a 32-bit mask per row), out[5] = rows per
  * block, out[6] = bytes of LDS a launch uses, out[7] = 1 if lsk_csr_sliced_spmv2_* serves the structure
- * (every block on one staged list), else 0; out holds 8 values.
+ * (every block on one staged list), else 0, out[8] = 1 if every list that serves a block is runs of exactly
+ * three consecutive distances (27-point stencils); out holds 9 values.
  * Option "xcd_remap" places the workgroups as for lsk_csr_spmv_*. */
 typedef struct lsk_csr_sliced lsk_csr_sliced_t;
 int lsk_csr_sliced_create_f32(int64_t rows, int64_t nnz, const int64_t *rects, int64_t k_base, const int64_t *col,

@@ -438,10 +438,11 @@ class SlicedStructure:
 
     def __init__(self, lib, handle, dtype):
         self.lib, self.handle, self.dtype = lib, handle, dtype
-        out = (ctypes.c_int64 * 8)()
+        out = (ctypes.c_int64 * 9)()
         _lib.check(lib.lsk_csr_sliced_info(handle, out))
         (self.padded_entries, self.blocks, self.mixed_blocks, self.patterns, self.masked_waves, self.block_rows,
-         self.lds_bytes, pair) = (int(v) for v in out)
+         self.lds_bytes, pair, runs3) = (int(v) for v in out)
+        self.runs_of_three = bool(runs3)  # every list that serves a block is runs of three consecutive distances
         self.pair_served = bool(pair)   # lsk_csr_sliced_spmv2_* serves this structure
 
     def algorithmic_bytes(self, rows: int, elem_size: int) -> int:

@@ -138,7 +138,7 @@ __global__ void sliced_init_kernel(unsigned long long *keys, int *flags, long lo
     for (int i = threadIdx.x; i < kMaxPatterns * (kMaxLength + 1); i += blockDim.x) lists[i] = 0;
     if (threadIdx.x < kMaxPatterns) keys[threadIdx.x] = 0;
     if (threadIdx.x < kFlags) flags[threadIdx.x] = 0;
-    if (threadIdx.x < 3) counts[threadIdx.x] = 0;
+    if (threadIdx.x < 4) counts[threadIdx.x] = 0;
 }
 
 // Pass 1: hash of every row's (length, distances) list; first come, first served into the pattern
@@ -326,6 +326,8 @@ __global__ __launch_bounds__(kBlock) void sliced_finish_kernel(int64_t blocks, i
         atomicAdd(reinterpret_cast<unsigned long long *>(counts), 1ull);
         return;
     }
+    // counts[3]: which lists serve some block (bit = list id)
+    atomicOr(reinterpret_cast<unsigned long long *>(counts) + 3, 1ull << (meta[b].pattern & 63));
     const int waves = (f >> kBlkWaveShift) & 0xf;
     if (waves) {
         meta[b].pattern |= kBlockMasked | (waves << kWaveMaskedShift);
@@ -1168,6 +1170,7 @@ int create(const char *name, int64_t rows, int64_t nnz, const int64_t *rects, in
     m->blocks = blocks;
     unsigned long long *keys = nullptr;
     long long *rep = nullptr, *entries = nullptr, *inclusive = nullptr, *counts = nullptr;
+    std::vector<PatternInfo> infos; // the lists, host side
     int *flags = nullptr, *lists = nullptr, *g_maxlen = nullptr, *g_holder = nullptr, *g_uniform = nullptr, *blk_flags = nullptr;
     void *temp = nullptr;
     int status = LSK_OK;
@@ -1188,7 +1191,7 @@ int create(const char *name, int64_t rows, int64_t nnz, const int64_t *rects, in
     LSK_ALLOC(keys, kMaxPatterns);
     LSK_ALLOC(rep, kMaxPatterns);
     LSK_ALLOC(flags, kFlags);
-    LSK_ALLOC(counts, 3);
+    LSK_ALLOC(counts, 4);
     LSK_ALLOC(lists, kMaxPatterns * (kMaxLength + 1));
     LSK_ALLOC(entries, blocks);
     LSK_ALLOC(inclusive, blocks);
@@ -1223,7 +1226,7 @@ int create(const char *name, int64_t rows, int64_t nnz, const int64_t *rects, in
         LSK_TRY(hipStreamSynchronize(s));
         declined = host_flags[kFlagOutsideWindow] != 0;
         if (status == LSK_OK && !declined) {
-            std::vector<PatternInfo> infos(kMaxPatterns);
+            infos.assign(kMaxPatterns, PatternInfo{});
             for (int p = 0; p < kMaxPatterns; ++p) {
                 PatternInfo &info = infos[p];
                 info = PatternInfo{};
@@ -1237,12 +1240,9 @@ int create(const char *name, int64_t rows, int64_t nnz, const int64_t *rects, in
                         m->lds_bytes = std::max(m->lds_bytes, static_cast<size_t>(info.lds_elems) * sizeof(T));
                         plan_wave_staging(info, kBlockRows / kWavesPerBlock);
                         m->wave_lds_bytes = std::max(m->wave_lds_bytes, static_cast<size_t>(info.w_lds_elems) * sizeof(T));
-                        for (int q = 0; q < info.nruns; ++q)
-                            if (info.run_len[q] != 3) m->runs_of_three = false;
-                    } else if (info.len > 0) {
+
+                    } else if (info.len > 0)
                         m->all_staged = false;
-                        m->runs_of_three = false;
-                    }
                 }
             }
             LSK_TRY(hipMemcpyAsync(m->table, infos.data(), kMaxPatterns * sizeof(PatternInfo), hipMemcpyHostToDevice, s));
@@ -1273,13 +1273,22 @@ int create(const char *name, int64_t rows, int64_t nnz, const int64_t *rects, in
             LSK_TRY(hipcub::DeviceScan::InclusiveSum(temp, temp_bytes, entries, inclusive, static_cast<int>(blocks), s));
         sliced_bases_kernel<<<block_grid, kBlock, 0, s>>>(blocks, entries, inclusive, meta);
         LSK_TRY(hipGetLastError());
-        long long total = 0, counts_host[3] = {0, 0, 0};
+        long long total = 0, counts_host[4] = {0, 0, 0, 0};
         LSK_TRY(hipMemcpyAsync(&total, inclusive + (blocks - 1), sizeof(total), hipMemcpyDeviceToHost, s));
         LSK_TRY(hipMemcpyAsync(counts_host, counts, sizeof(counts_host), hipMemcpyDeviceToHost, s));
         LSK_TRY(hipStreamSynchronize(s));
         m->padded_entries = total;
         m->mixed_blocks = counts_host[0];
         m->masked_waves = counts_host[1];
+        // lists of runs of exactly three: judged on the lists that serve blocks (a row at the end of a grid
+        // line has a list of its own with shorter runs, but its block runs on the line's list with a mask)
+        m->runs_of_three = m->mixed_blocks == 0;
+        for (int p = 0; p < kMaxPatterns && p < static_cast<int>(infos.size()); ++p)
+            if ((static_cast<unsigned long long>(counts_host[3]) >> p) & 1ull) {
+                if (infos[p].nruns <= 0) m->runs_of_three = false;
+                for (int q = 0; q < infos[p].nruns; ++q)
+                    if (infos[p].run_len[q] != 3) m->runs_of_three = false;
+            }
         // not worth it when padding short rows to their block's longest would cost more than the column
         // array saves (the rows the last block lacks are left out: at most one block per piece)
         if (status == LSK_OK && static_cast<double>(counts_host[2]) * sizeof(T) > static_cast<double>(nnz) * (sizeof(T) + 3.0))
@@ -1651,6 +1660,7 @@ int lsk_csr_sliced_info(const lsk_csr_sliced_t *m, int64_t *out) {
     out[5] = int64_t(kBlock) * (16 / m->elem_bytes);
     out[6] = static_cast<int64_t>(m->lds_bytes);
     out[7] = pair_served(m) ? 1 : 0;
+    out[8] = m->runs_of_three ? 1 : 0;
     return LSK_OK;
 }
 

@@ -209,7 +209,7 @@ def test_sliced_pattern_products_fuzz(seed, suf):
         return
     assert code == _lib.LSK_OK, _lib.lib().lsk_last_error().decode()
     try:
-        info = (ctypes.c_int64 * 8)()
+        info = (ctypes.c_int64 * 9)()
         _lib.call("lsk_csr_sliced_info", handle, info)
         assert info[3] <= len(patterns) and info[2] <= info[1] and info[4] <= 4 * (info[1] - info[2])
         print(f"  blocks {info[1]}: {info[2]} mixed, {info[4]} masked waves; {info[3]} patterns, "

@@ -697,7 +697,7 @@ def sliced_case(suf, rects, k_base, col, val, x, x_lo, x_hi, row_first, tag, exp
         assert code == _lib.LSK_ERR_UNSUPPORTED and not handle.value, f"{tag}: create said {code}"
         return None
     assert code == _lib.LSK_OK, f"{tag}: create said {code}: {_lib.lib().lsk_last_error().decode()}"
-    info = (ctypes.c_int64 * 8)()
+    info = (ctypes.c_int64 * 9)()
     _lib.call("lsk_csr_sliced_info", handle, info)
     lens = np.maximum(rects[:, 1] - rects[:, 0] + 1, 0)
     br = BLOCK_ROWS[suf]
@@ -823,6 +823,10 @@ def test_csr_sliced_patterns_bit_exact(suf, sliced_forms):
             continue
         info = sliced_case(suf, rects, 0, col, val, x, 0, n - 1, 0, f"stencil{flag}{extent}")
         assert info[3] <= 27
+        # every list that serves a block of the 27-point (and of the 1-D 3-point) matrix is runs of three
+        # (a row at a line's end has a shorter list of its own, but its block runs on the line's list with
+        # a mask); the 5- and 7-point lists have single distances beside their one run
+        assert info[8] == (1 if flag in (1, 4) else 0), (flag, extent, info)
         # a piece in the middle: rows a..b of the matrix, entries from k_base, x window = its ghost interval
         a, b = n // 3, n - n // 4
         k_lo, k_hi = int(rects[a, 0]), int(rects[b - 1, 1])

@@ -33,6 +33,8 @@ def main():
     dtype = torch.float32 if (len(sys.argv) > 3 and sys.argv[3] == "f32") else torch.float64
     esz = 4 if dtype == torch.float32 else 8
     ctx = Context(torch.device("cuda", 0))
+    if "LSK_RUNS" in os.environ:
+        _lib.call("lsk_set_option", b"sliced.runs", int(os.environ["LSK_RUNS"]))
     t0 = time.perf_counter()
     matrix, planner, solver = bs.build_problem(ctx, flag, n, n, n, 1, 1, dtype, num_systems=1)
     ctx.synchronize()
