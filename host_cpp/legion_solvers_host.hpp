@@ -61,6 +61,7 @@ template <typename T> struct Abi;
         static constexpr auto csr_sliced_spmv2 = lsk_csr_sliced_spmv2_##SUF;                       \
         static constexpr auto csr_sliced_spmv2_dot = lsk_csr_sliced_spmv2_dot_##SUF;               \
         static constexpr auto csr_sliced_tune = lsk_csr_sliced_tune_##SUF;                         \
+        static constexpr auto csr_sliced_tune2 = lsk_csr_sliced_tune2_##SUF;                       \
         static constexpr auto csr_sliced_update_values = lsk_csr_sliced_update_values_##SUF;       \
         static constexpr auto stencil_fill_csr = lsk_stencil_fill_csr_##SUF;                       \
         static constexpr auto stencil_fill_coo = lsk_stencil_fill_coo_##SUF;                       \
@@ -627,7 +628,17 @@ public:
         for (int c = 0; c < range_.colors(); ++c) {
             const int64_t rows = range_.volume(c);
             if (rows <= 0) continue;
-            check(lsk_set_option("xcd_remap", sliced_[c].placement));
+            if (sliced_[c].pair_placement < 0) {
+                // two windows of x compete for each XCD's L2: the pair gets a placement of its own, timed once
+                // on the vectors at hand (the destinations are about to be overwritten anyway)
+                sliced_[c].pair_placement = sliced_[c].placement;
+                if (rows >= kTuneMinRows) {
+                    float ms = 0.0f;
+                    check(Abi<T>::csr_sliced_tune2(sliced_[c].handle, src_a.data(), src_b.data(), dst_a.piece(c),
+                                                   dst_b.piece(c), ctx_->stream(), &sliced_[c].pair_placement, &ms));
+                }
+            }
+            check(lsk_set_option("xcd_remap", sliced_[c].pair_placement));
             int status;
             int64_t count = 0;
             if (w_a)
@@ -713,13 +724,17 @@ private:
     struct Sliced {
         lsk_csr_sliced_t *handle = nullptr;
         int placement = 0;
+        mutable int pair_placement = -1; // of the two-vector product; -1: not chosen yet (matvec_pair does)
         Sliced() = default;
-        Sliced(Sliced &&o) noexcept : handle(o.handle), placement(o.placement) { o.handle = nullptr; }
+        Sliced(Sliced &&o) noexcept : handle(o.handle), placement(o.placement), pair_placement(o.pair_placement) {
+            o.handle = nullptr;
+        }
         Sliced &operator=(Sliced &&o) noexcept {
             if (this != &o) {
                 lsk_csr_sliced_destroy(handle);
                 handle = o.handle;
                 placement = o.placement;
+                pair_placement = o.pair_placement;
                 o.handle = nullptr;
             }
             return *this;

@@ -614,6 +614,15 @@ int lsk_csr_sliced_tune_f32(const lsk_csr_sliced_t *m, const float *x, float *y,
                             float *ms);
 int lsk_csr_sliced_tune_f64(const lsk_csr_sliced_t *m, const double *x, double *y, lsk_stream_t stream, int *xcd_remap,
                             float *ms);
+/* The same for the two-vector product lsk_csr_sliced_spmv2_* (ya <- A xa, yb <- A xb, both overwritten): with
+ * two windows of x competing for each XCD's L2 it prefers runs of neighbouring blocks on one XCD where the
+ * one-vector product does not care (27-point 512^3 fp64: 6.45 ms with placement 0, 5.55 ms with 64), so a
+ * caller that pairs products keeps a placement of its own for them.  LSK_ERR_UNSUPPORTED where
+ * lsk_csr_sliced_spmv2_* answers that.  No counterpart in the reference. */
+int lsk_csr_sliced_tune2_f32(const lsk_csr_sliced_t *m, const float *xa, const float *xb, float *ya, float *yb,
+                             lsk_stream_t stream, int *xcd_remap, float *ms);
+int lsk_csr_sliced_tune2_f64(const lsk_csr_sliced_t *m, const double *xa, const double *xb, double *ya, double *yb,
+                             lsk_stream_t stream, int *xcd_remap, float *ms);
 int lsk_csr_sliced_info(const lsk_csr_sliced_t *m, int64_t *out);
 int lsk_csr_sliced_destroy(lsk_csr_sliced_t *m);
 

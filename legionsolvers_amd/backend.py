@@ -9,7 +9,7 @@ from __future__ import annotations
 
 import ctypes
 import threading
-from typing import Sequence, Tuple
+from typing import Optional, Sequence, Tuple
 
 import torch
 
@@ -228,6 +228,18 @@ class HipBackend:
         remap, ms = ctypes.c_int(0), ctypes.c_float(0.0)
         _lib.call(f"lsk_csr_sliced_tune_{_lib.suffix(sliced.dtype)}", sliced.handle, _ptr(x), _ptr(y), self.stream(),
                   ctypes.byref(remap), ctypes.byref(ms))
+        return remap.value, ms.value
+
+    def csr_sliced_tune2(self, sliced: "SlicedStructure", xs, ys) -> Optional[Tuple[int, float]]:
+        """The same for the two-vector product (ys[k] <- A xs[k], overwritten); None where no two-vector
+        form serves the structure.  Synchronises."""
+        remap, ms = ctypes.c_int(0), ctypes.c_float(0.0)
+        code = getattr(self.lib, f"lsk_csr_sliced_tune2_{_lib.suffix(sliced.dtype)}")(
+            sliced.handle, _ptr(xs[0]), _ptr(xs[1]), _ptr(ys[0]), _ptr(ys[1]), self.stream(), ctypes.byref(remap),
+            ctypes.byref(ms))
+        if code == _lib.LSK_ERR_UNSUPPORTED:
+            return None
+        _lib.check(code)
         return remap.value, ms.value
 
     @staticmethod

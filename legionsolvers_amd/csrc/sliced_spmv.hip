@@ -697,23 +697,40 @@ __global__ __launch_bounds__(kBlock, (sliced_wave_waves_per_simd<K, CAP>())) voi
     // Requests vector k's windows: all of a list's windows at once (a 27-point list has 9), and the few
     // elements by which they are wider than the wave's rows with them -- one trip to memory, not one per
     // batch.  Those few elements come back in a register and are written by finish_stage.
+    // One window on its way: kWaveRows elements of x from distance `start` of the wave's first row to
+    // `off` in the wave's LDS area.
+    auto stage_window = [&](const T *x, T *area, int start, int off) {
+        const long long first = r0 + x_shift + start; // (wave-uniform)
+        T *dst = area + off;
+        if (first >= 0 && first + kWaveRows <= x_extent) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(x + first + lane * R),
+                                             (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+        } else { // a window that reaches past an end of the vector: element by element, clamped
+#pragma unroll
+            for (int i = 0; i < R; ++i) dst[lane + i * kWave] = fetch_from(x, first + lane + i * kWave);
+        }
+    };
+    // (lists of runs of three: the windows' distances and places are few enough for scalar registers,
+    // loaded together instead of one dependent scalar load per window)
+    constexpr int NQ = RUN3 ? CAP / 3 : 1;
+    int rstart[NQ], roff[NQ];
+    if constexpr (RUN3 && DMA) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            rstart[q] = info.run_start[q];
+            roff[q] = info.w_run_off[q];
+        }
+    }
     auto stage = [&](int k, T *area) {
         const T *x = k == 0 ? xa : xb;
         tail[k] = T(0);
         if (has_tail) tail[k] = fetch_from(x, r0 + x_shift + info.w_tail_dist[lane]);
-        if constexpr (DMA) {
-            for (int q = 0; q < nruns; ++q) {
-                const long long first = r0 + x_shift + info.run_start[q]; // (wave-uniform)
-                T *dst = area + info.w_run_off[q];
-                if (first >= 0 && first + kWaveRows <= x_extent) {
-                    __builtin_amdgcn_global_load_lds(
-                        (const __attribute__((address_space(1))) void *)(x + first + lane * R),
-                        (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
-                } else { // a window that reaches past an end of the vector: element by element, clamped
+        if constexpr (DMA && RUN3) {
 #pragma unroll
-                    for (int i = 0; i < R; ++i) dst[lane + i * kWave] = fetch_from(x, first + lane + i * kWave);
-                }
-            }
+            for (int q = 0; q < NQ; ++q)
+                if (q < nruns) stage_window(x, area, rstart[q], roff[q]);
+        } else if constexpr (DMA) {
+            for (int q = 0; q < nruns; ++q) stage_window(x, area, info.run_start[q], info.w_run_off[q]);
         } else {
             for (int q0 = 0; q0 < nruns; q0 += QB) {
                 T got[QB][R];
@@ -756,6 +773,11 @@ __global__ __launch_bounds__(kBlock, (sliced_wave_waves_per_simd<K, CAP>())) voi
         stage(1, xs + lds_wave_elems / 2);
         load_values();
     }
+    // (Tried for K = 2 and dropped: requesting the second vector's window q into its place as soon as the
+    // first vector's sums have read it, so that it travels while the remaining runs are summed.  The pair
+    // on the 27-point 512^3 fp64 matrix: 5.17 -> 5.51 ms with both right-hand sides the same vector, 6.45 ->
+    // 6.31 / 5.55 -> 5.92 ms with two vectors and either placement: the second trip is not what the pair
+    // waits for; the second vector's share of L2 is, see lsk_csr_sliced_tune2_*.)
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         const T *yin = k == 0 ? ya : yb;
@@ -1530,8 +1552,15 @@ int spmv2(const char *name, const lsk_csr_sliced *m, int64_t row_begin, int64_t 
 
 // Times the candidates of the workgroup -> XCD placement on this structure and reports the fastest.
 template <typename T>
-int tune(const char *name, const lsk_csr_sliced *m, const T *x, T *y, lsk_stream_t stream, int *remap_out, float *ms_out) {
+int tune(const char *name, const lsk_csr_sliced *m, const T *x, T *y, lsk_stream_t stream, int *remap_out, float *ms_out,
+         const T *xb = nullptr, T *yb = nullptr) {
+    // (xb, yb: the two-vector product is what is timed; it answers LSK_ERR_UNSUPPORTED where no two-vector
+    // form serves the structure)
     static const int candidates[] = {0, 16, 64, 256, 1024, 4096};
+    auto product = [&]() {
+        return xb ? spmv2<T>(name, m, 0, m->rows, x, xb, y, yb, 0, nullptr, nullptr, nullptr, nullptr, 0, nullptr, stream)
+                  : spmv<T>(name, m, 0, m->rows, x, y, 0, nullptr, nullptr, 0, nullptr, stream);
+    };
     constexpr int kWarm = 1, kTimed = 3;
     if (!m) return lsk::fail(LSK_ERR_ARG, "%s: null structure", name);
     int &placement = lsk::xcd_remap_option();
@@ -1544,12 +1573,10 @@ int tune(const char *name, const lsk_csr_sliced *m, const T *x, T *y, lsk_stream
     float best_ms = -1.0f;
     for (int c : candidates) {
         placement = c;
-        for (int i = 0; i < kWarm && status == LSK_OK; ++i)
-            status = spmv<T>(name, m, 0, m->rows, x, y, 0, nullptr, nullptr, 0, nullptr, stream);
+        for (int i = 0; i < kWarm && status == LSK_OK; ++i) status = product();
         if (status != LSK_OK) break;
         if (hipEventRecord(t0, s) != hipSuccess) { status = lsk::fail(LSK_ERR_HIP, "%s: event record", name); break; }
-        for (int i = 0; i < kTimed && status == LSK_OK; ++i)
-            status = spmv<T>(name, m, 0, m->rows, x, y, 0, nullptr, nullptr, 0, nullptr, stream);
+        for (int i = 0; i < kTimed && status == LSK_OK; ++i) status = product();
         if (status != LSK_OK) break;
         float ms = 0.0f;
         if (hipEventRecord(t1, s) != hipSuccess || hipEventSynchronize(t1) != hipSuccess ||
@@ -1585,6 +1612,17 @@ int lsk_csr_sliced_tune_f32(const lsk_csr_sliced_t *m, const float *x, float *y,
 int lsk_csr_sliced_tune_f64(const lsk_csr_sliced_t *m, const double *x, double *y, lsk_stream_t stream, int *xcd_remap,
                             float *ms) {
     return tune<double>("lsk_csr_sliced_tune_f64", m, x, y, stream, xcd_remap, ms);
+}
+
+int lsk_csr_sliced_tune2_f32(const lsk_csr_sliced_t *m, const float *xa, const float *xb, float *ya, float *yb,
+                             lsk_stream_t stream, int *xcd_remap, float *ms) {
+    if (!xa || !xb || !ya || !yb) return lsk::fail(LSK_ERR_ARG, "lsk_csr_sliced_tune2_f32: null vector");
+    return tune<float>("lsk_csr_sliced_tune2_f32", m, xa, ya, stream, xcd_remap, ms, xb, yb);
+}
+int lsk_csr_sliced_tune2_f64(const lsk_csr_sliced_t *m, const double *xa, const double *xb, double *ya, double *yb,
+                             lsk_stream_t stream, int *xcd_remap, float *ms) {
+    if (!xa || !xb || !ya || !yb) return lsk::fail(LSK_ERR_ARG, "lsk_csr_sliced_tune2_f64: null vector");
+    return tune<double>("lsk_csr_sliced_tune2_f64", m, xa, ya, stream, xcd_remap, ms, xb, yb);
 }
 
 int lsk_csr_sliced_create_f32(int64_t rows, int64_t nnz, const int64_t *rects, int64_t k_base, const int64_t *col,

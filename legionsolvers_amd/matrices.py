@@ -133,6 +133,7 @@ class _SlicedCopies:
         self.sliced = {}          # slice_structure(): piece colour -> sliced-pattern copy of the piece ...
         self.sliced_window = None # ... for products against this window
         self.sliced_placement = {}
+        self.pair_placement = {}     # ... of the two-vector product, chosen at its first launch (matvec_pair)
         self._sliced_refill = {}  # piece colour -> refill(copy): the piece's current values into that copy
         self._sliced_make = None
         self.setup_seconds = {}   # wall-clock seconds of the set-up stages run on this matrix
@@ -228,6 +229,7 @@ class _SlicedCopies:
                     if t < best:
                         self.sliced[c].close()
                         self.sliced[c], self.sliced_placement[c], best = other, pl, t
+                        self.pair_placement.pop(c, None)
                     else:
                         other.close()
             freed_total += freed
@@ -679,7 +681,17 @@ class CSRMatrix(AbstractMatrix, _SlicedCopies):
                 slots = be.csr_sliced_dot_slots(sliced, rows)
                 bufs = [d._partials("mv", i, slots) for d in dsts]
                 ws = [w._piece(i) for w in dot_with]
-            count = be.csr_sliced_spmv2(sliced, rows, xs, ys, 0, ws, bufs, self.sliced_placement.get(c, 0))
+            if c not in self.pair_placement:
+                # Two windows of x compete for each XCD's L2, so the pair has a placement of its own, timed
+                # once on the vectors at hand (ys is about to be overwritten anyway).
+                self.pair_placement[c] = self.sliced_placement.get(c, 0)
+                tune2 = getattr(be, "csr_sliced_tune2", None)
+                if tune2 is not None and rows >= self.TUNE_MIN_ROWS and os.environ.get("LSK_TUNE", "1") != "0":
+                    with self._stage("pair_placement_tuner"):
+                        tuned = tune2(sliced, xs, ys)
+                    if tuned is not None:
+                        self.pair_placement[c] = tuned[0]
+            count = be.csr_sliced_spmv2(sliced, rows, xs, ys, 0, ws, bufs, self.pair_placement[c])
             if count is None:
                 if launched:
                     raise RuntimeError("the two-vector product served one piece and declined another")

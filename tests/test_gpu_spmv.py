@@ -786,6 +786,21 @@ def sliced_pair_case(suf, handle, rows, br, xd, x_size, y0, wd, shares_a, tag, m
     assert torch.equal(yb, yd) and torch.equal(pa[:slots], shares_a) and torch.equal(pb[:slots], pb_single), f"{tag}: spmv2_dot"
     assert bool((pa[slots:] == 7.0).all()) and bool((pb[slots:] == 7.0).all()), f"{tag}: spmv2_dot wrote past its shares"
     assert getattr(lib, f"lsk_csr_sliced_spmv2_{suf}")(handle, 0, rows, P(xd), P(xb), P(ya), P(ya), 0, stream()) == _lib.LSK_ERR_ARG
+    # the pair's own placement tuner: a candidate and its time come back, the option it tries is restored,
+    # and the vectors hold the two products
+    held, remap, ms = ctypes.c_int(-1), ctypes.c_int(-1), ctypes.c_float(-1.0)
+    _lib.call("lsk_get_option", b"xcd_remap", ctypes.byref(held))
+    ya, yb = dev(y0), dev(y0)
+    _lib.call(f"lsk_csr_sliced_tune2_{suf}", handle, P(xd), P(xb), P(ya), P(yb), stream(), ctypes.byref(remap), ctypes.byref(ms))
+    now = ctypes.c_int(-2)
+    _lib.call("lsk_get_option", b"xcd_remap", ctypes.byref(now))
+    assert remap.value in (0, 16, 64, 256, 1024, 4096) and ms.value > 0.0 and now.value == held.value, f"{tag}: tune2"
+    for got, xv in ((ya, xd), (yb, xb)):
+        yd = dev(y0)
+        _lib.call(f"lsk_csr_sliced_spmv_{suf}", handle, 0, rows, P(xv), P(yd), 0, stream())
+        assert torch.equal(got, yd), f"{tag}: tune2 left something else than the products"
+    assert getattr(lib, f"lsk_csr_sliced_tune2_{suf}")(handle, P(xd), None, P(ya), P(yb), stream(), ctypes.byref(remap),
+                                                       ctypes.byref(ms)) == _lib.LSK_ERR_ARG
 
 
 @pytest.fixture(params=[(1, -1, 1, 1), (0, 1, 1, 0), (1, 0, 1, 0), (1, 1, 0, 0), (0, 0, 1, 1)],

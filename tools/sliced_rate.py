@@ -60,6 +60,9 @@ def main():
                 for place2 in (0, 64):   # workgroup -> XCD placements
                     ms = timed(ctx, lambda: be.csr_sliced_spmv2(s, matrix.rows, xs, ys, 0, placement=place2), 10)
                     out[f"pair_form{pair_form}_place{place2}_ms"] = round(ms, 3)
+                    if pair_form == 2:   # both right-hand sides the same vector: what the second one's cache footprint costs
+                        ms = timed(ctx, lambda: be.csr_sliced_spmv2(s, matrix.rows, [xs[0], xs[0]], ys, 0, placement=place2), 10)
+                        out[f"pair_form2_same_x_place{place2}_ms"] = round(ms, 3)
         _lib.call("lsk_set_option", b"sliced.pair_form", -1)
         _lib.call("lsk_set_option", b"sliced.dma", 1)
         # both forms of the one-vector product, plain and with the fused dot shares, called directly
