@@ -261,21 +261,22 @@ class HipBackend:
         return count.value
 
     def csr_sliced_spmv2(self, sliced: "SlicedStructure", rows: int, xs, ys, beta: int, dot_with=None, partials=None,
-                         placement: int = 0):
-        """Two products with one pass over the values: ys[k] <- A xs[k] + beta ys[k], k = 0, 1, each bit
-        for bit what csr_sliced_spmv gives for it alone.  With dot_with = (w0, w1) and partials = (p0, p1)
-        also the shares of ys[k] . w_k; returns their count (0 without).  None when the structure has
+                         placement: int = 0, row_begin: int = 0):
+        """Two products with one pass over the values: ys[k] <- A xs[k] + beta ys[k], k = 0, 1, over the rows
+        row_begin..rows-1 of the piece (ys, dot_with: the whole piece's vectors), each bit for bit what
+        csr_sliced_spmv gives for it alone.  With dot_with = (w0, w1) and partials = (p0, p1) also the
+        shares of ys[k] . w_k over those rows; returns their count (0 without).  None when the structure has
         blocks the two-vector kernel does not serve (the caller then launches the products one by one)."""
         self._place(placement)
         suffix = _lib.suffix(sliced.dtype)
         if dot_with is None:
             code = getattr(self.lib, f"lsk_csr_sliced_spmv2_{suffix}")(
-                sliced.handle, 0, rows, _ptr(xs[0]), _ptr(xs[1]), _ptr(ys[0]), _ptr(ys[1]), beta, self.stream())
+                sliced.handle, row_begin, rows, _ptr(xs[0]), _ptr(xs[1]), _ptr(ys[0]), _ptr(ys[1]), beta, self.stream())
             count = ctypes.c_int64(0)
         else:
             count = ctypes.c_int64(0)
             code = getattr(self.lib, f"lsk_csr_sliced_spmv2_dot_{suffix}")(
-                sliced.handle, 0, rows, _ptr(xs[0]), _ptr(xs[1]), _ptr(ys[0]), _ptr(ys[1]), beta, _ptr(dot_with[0]),
+                sliced.handle, row_begin, rows, _ptr(xs[0]), _ptr(xs[1]), _ptr(ys[0]), _ptr(ys[1]), beta, _ptr(dot_with[0]),
                 _ptr(dot_with[1]), _ptr(partials[0]), _ptr(partials[1]), min(partials[0].numel(), partials[1].numel()),
                 ctypes.byref(count), self.stream())
         if code == _lib.LSK_ERR_UNSUPPORTED:

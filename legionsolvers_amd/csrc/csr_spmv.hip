@@ -889,7 +889,10 @@ int tune_csr_spmv(const char *name, int64_t rows, int64_t nnz, const void *rects
     hipStream_t s = lsk::as_stream(stream);
     hipEvent_t t0 = nullptr, t1 = nullptr;
     LSK_HIP(hipEventCreate(&t0));
-    LSK_HIP(hipEventCreate(&t1));
+    if (const hipError_t e = hipEventCreate(&t1); e != hipSuccess) {
+        (void)hipEventDestroy(t0);
+        return lsk::hip_fail(e, "hipEventCreate", __FILE__, __LINE__);
+    }
     int best = saved, status = LSK_OK;
     float best_ms = -1.0f;
     for (int c : candidates) {

@@ -1568,7 +1568,10 @@ int tune(const char *name, const lsk_csr_sliced *m, const T *x, T *y, lsk_stream
     hipStream_t s = lsk::as_stream(stream);
     hipEvent_t t0 = nullptr, t1 = nullptr;
     LSK_HIP(hipEventCreate(&t0));
-    LSK_HIP(hipEventCreate(&t1));
+    if (const hipError_t e = hipEventCreate(&t1); e != hipSuccess) {
+        (void)hipEventDestroy(t0);
+        return lsk::hip_fail(e, "hipEventCreate", __FILE__, __LINE__);
+    }
     int best = saved, status = LSK_OK;
     float best_ms = -1.0f;
     for (int c : candidates) {

@@ -654,18 +654,21 @@ class CSRMatrix(AbstractMatrix, _SlicedCopies):
                 and all(c in self.sliced and self.sliced[c].pair_served
                         for c in kernel_partition.colors if range_partition.pieces[c].volume > 0))
 
-    def matvec_pair(self, dsts, xs, x_lo, x_hi, kernel_partition, dot_with=None, range_partition=None) -> bool:
+    def matvec_pair(self, dsts, xs, x_lo, x_hi, kernel_partition, dot_with=None, range_partition=None,
+                    split=None, phase=None) -> bool:
         """dsts[k] <- A xs[k] for k = 0, 1 with ONE pass over the values (two systems on one matrix: what
         the reference's BenchmarkStencil steps, test/BenchmarkStencil.cpp:181-199, where the planner
         launches one CSRMatvecTask per system).  Each result is bit for bit that of matvec(..., beta = 0);
-        dot_with = (w0, w1) leaves the shares of dot(dsts[k], w_k) as matvec's dot_with does.  False when
-        a piece's structure is not served: nothing was launched for ANY piece, the caller multiplies one
-        by one."""
+        dot_with = (w0, w1) leaves the shares of dot(dsts[k], w_k) as matvec's dot_with does; split, phase
+        as in matvec (the runs of rows of one phase; both phases together are the whole product and
+        leave all the shares).  False when a piece's structure is not served: nothing was launched for
+        ANY piece, the caller multiplies one by one."""
         range_partition = range_partition or dsts[0].index_partition
         be = self.ctx.backend
         if not self.pairs(x_lo, x_hi, kernel_partition, range_partition):
             return False
         fused = dot_with is not None
+        last_phase = split is None or phase == 1
         launched = False
         pieces = ([], [])
         for i, c in enumerate(kernel_partition.colors):
@@ -676,14 +679,10 @@ class CSRMatrix(AbstractMatrix, _SlicedCopies):
                 continue
             sliced = self.sliced[c]
             ys = [d._piece(i) for d in dsts]
-            bufs = ws = None
-            if fused:
-                slots = be.csr_sliced_dot_slots(sliced, rows)
-                bufs = [d._partials("mv", i, slots) for d in dsts]
-                ws = [w._piece(i) for w in dot_with]
+            ws = [w._piece(i) for w in dot_with] if fused else None
             if c not in self.pair_placement:
                 # Two windows of x compete for each XCD's L2, so the pair has a placement of its own, timed
-                # once on the vectors at hand (ys is about to be overwritten anyway).
+                # once on the vectors at hand (every row of ys is about to be overwritten anyway).
                 self.pair_placement[c] = self.sliced_placement.get(c, 0)
                 tune2 = getattr(be, "csr_sliced_tune2", None)
                 if tune2 is not None and rows >= self.TUNE_MIN_ROWS and os.environ.get("LSK_TUNE", "1") != "0":
@@ -691,7 +690,31 @@ class CSRMatrix(AbstractMatrix, _SlicedCopies):
                         tuned = tune2(sliced, xs, ys)
                     if tuned is not None:
                         self.pair_placement[c] = tuned[0]
-            count = be.csr_sliced_spmv2(sliced, rows, xs, ys, 0, ws, bufs, self.pair_placement[c])
+            place = self.pair_placement[c]
+            if split is not None and i in split:
+                runs = split[i]
+                slots = [be.csr_sliced_dot_slots(sliced, rb, ra) for _, ra, rb, _, _ in runs] if fused else []
+                # every run's shares side by side in one buffer per system, whichever phase launches it
+                bufs = [d._partials("mv", i, sum(slots)) for d in dsts] if fused else None
+                for n, (run_phase, ra, rb, _, _) in enumerate(runs):
+                    if run_phase != phase or rb <= ra:
+                        continue
+                    part = [b[sum(slots[:n]):] for b in bufs] if fused else None
+                    if be.csr_sliced_spmv2(sliced, rb, xs, ys, 0, ws, part, place, row_begin=ra) is None:
+                        raise RuntimeError("the two-vector product declined rows of a structure it serves")
+                launched = True
+                for k in (0, 1):
+                    pieces[k].append((bufs[k] if fused else None, sum(slots)))
+                continue
+            if split is not None and phase == 0:
+                for k in (0, 1):   # (a piece without a split entry goes with the late phase)
+                    pieces[k].append((None, 0))
+                continue
+            bufs = None
+            if fused:
+                slots = be.csr_sliced_dot_slots(sliced, rows)
+                bufs = [d._partials("mv", i, slots) for d in dsts]
+            count = be.csr_sliced_spmv2(sliced, rows, xs, ys, 0, ws, bufs, place)
             if count is None:
                 if launched:
                     raise RuntimeError("the two-vector product served one piece and declined another")
@@ -703,7 +726,7 @@ class CSRMatrix(AbstractMatrix, _SlicedCopies):
             touch = getattr(d, "_touch", None)
             if touch is not None:
                 touch()
-        if fused:
+        if fused and last_phase:
             for k in (0, 1):
                 dsts[k]._note_ready(dot_with[k], pieces[k])
         return True

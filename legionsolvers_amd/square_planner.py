@@ -55,6 +55,7 @@ class SquarePlanner:
         # bets of the fused product + dot (see _fused_dot_pays)
         self._fused_dot_issued = 0
         self._fused_dot_used = 0
+        self._paired_products = 0   # products of two systems that shared one pass over a matrix (matvec)
         self._fused_dot_pending = None
         # bets of the held-back solution update (see axpy)
         self._deferred_issued = [0, 0]  # [into the solution, into a workspace vector]
@@ -356,8 +357,8 @@ class SquarePlanner:
                 srcs = [self.get_vector(src_idx, f.domain_index) for f in (e, e2)]
                 with_dot = fuse and e.matrix.fuses_dot()
                 dot_with = [self.get_vector(src_idx, f.range_index) for f in (e, e2)] if with_dot else None
-                lo, hi = srcs[0].own_lo, srcs[0].own_hi
-                if e.matrix.matvec_pair(dsts, [v._own for v in srcs], lo, hi, e.kernel_partition, dot_with):
+                if self._matvec_pair(e, e2, dsts, srcs, dot_with):
+                    self._paired_products += 1
                     paired.add(mate)
                     touched.update((e.range_index, e2.range_index))
                     fused_any = fused_any or with_dot
@@ -407,22 +408,50 @@ class SquarePlanner:
         else:
             self._fused_dot_pending = None
 
+    def _matvec_pair(self, e, e2, dsts, srcs, dot_with) -> bool:
+        """The products of entries e and e2 (mates, see _pair_mate) in one pass over the matrix values.
+        Where ghost cells are due, both vectors' exchanges are posted, the rows that read none are
+        multiplied while they are in flight, and the rest afterwards -- as matvec does for one vector.
+        False: nothing was launched or posted."""
+        comm = self.ctx.comm
+        if not (e.plan.recvs or e.plan.sends):
+            return e.matrix.matvec_pair(dsts, [v._own for v in srcs], srcs[0].own_lo, srcs[0].own_hi,
+                                        e.kernel_partition, dot_with)
+        x_lo, x_hi = srcs[0].own_lo - e.plan.pad_lo, srcs[0].own_hi + e.plan.pad_hi
+        if not e.matrix.pairs(x_lo, x_hi, e.kernel_partition, dsts[0].index_partition):
+            return False
+        gathered = [self._gather_ghost(f, v) for f, v in ((e, srcs[0]), (e2, srcs[1]))]
+        xs = [g[0] for g in gathered]
+        args = (dsts, xs, x_lo, x_hi, e.kernel_partition, dot_with)
+        ok = True
+        if e.split is not None:
+            ok = e.matrix.matvec_pair(*args, split=e.split, phase=0)
+        for g in gathered:
+            comm.exchange_finish(g[3])
+        ok = ok and (e.matrix.matvec_pair(*args, split=e.split, phase=1) if e.split is not None
+                     else e.matrix.matvec_pair(*args))
+        if not ok:
+            raise RuntimeError("the two-vector product declined a matrix it said it serves")
+        return True
+
     def _pair_mate(self, idx: int, writers, touched, paired):
         """Index of a later matrix entry that can share one pass over the values with entry idx: the
-        same CSR matrix object on the same partitions, other spaces, each the only writer of its range
-        space, no ghost cells to fetch (one rank, or rows that read only their own); None if there is none."""
+        same CSR matrix object on the same partitions with the same halo plan, other spaces, each the
+        only writer of its range space; None if there is none."""
         entries = self.row_partitioned_matrices
         e = entries[idx]
         if (not isinstance(e.matrix, CSRMatrix) or writers[e.range_index] != 1 or e.range_index in touched
-                or e.plan.recvs or e.plan.sends or e.domain_index != e.range_index):
+                or e.domain_index != e.range_index):
             return None
         dst = self.get_vector(0, e.range_index)
-        if not e.matrix.pairs(dst.own_lo, dst.own_hi, e.kernel_partition, dst.index_partition):
+        if not e.matrix.pairs(dst.own_lo - e.plan.pad_lo, dst.own_hi + e.plan.pad_hi, e.kernel_partition,
+                              dst.index_partition):
             return None
         for j in range(idx + 1, len(entries)):
             f = entries[j]
             if (j in paired or f.matrix is not e.matrix or f.range_index == e.range_index
-                    or writers[f.range_index] != 1 or f.range_index in touched or f.plan.recvs or f.plan.sends
+                    or writers[f.range_index] != 1 or f.range_index in touched
+                    or f.plan.recvs != e.plan.recvs or f.plan.sends != e.plan.sends or f.split != e.split
                     or f.domain_index != f.range_index or f.kernel_partition.intervals != e.kernel_partition.intervals
                     or f.kernel_partition.colors != e.kernel_partition.colors):
                 continue

@@ -13,7 +13,8 @@ import oracle
 from oracle import solvers as S
 from thread_ranks import run_ranks
 
-from legionsolvers_amd import BiCGStabSolver, CGSolver, GMRESSolver
+from legionsolvers_amd import (BiCGStabSolver, CGSolver, GMRESSolver, IndexPartition, IndexSpace, PartitionedVector,
+                               SquarePlanner)
 from legionsolvers_amd import benchmark_stencil as bs
 
 pytestmark = pytest.mark.gpu
@@ -87,3 +88,53 @@ def test_other_solvers_thread_ranks(monkeypatch, solver_flag):
     _, osol = _oracle_history(n1, steps, solver_flag, pieces)
     for sol, (lo, hi) in out:
         assert np.abs(sol - osol[lo:hi + 1]).max() <= 1e-9 * np.abs(osol).max()
+
+
+@pytest.mark.parametrize("world,pieces,n1", [(4, 4, 64), (3, 6, 40)], ids=["4ranks-64cubed", "3ranks-6pieces-40cubed"])
+def test_two_systems_share_a_pass_across_ranks(monkeypatch, world, pieces, n1):
+    """Two systems on one matrix (the reference's BenchmarkStencil, test/BenchmarkStencil.cpp:181-199) on
+    several ranks: both vectors' halos are posted, the rows that need none are multiplied for both systems
+    in one pass over the values while they travel, the edge rows afterwards.  Every scalar and both
+    solutions equal, bit for bit, those of one product per system (LSK_PAIR=0), which the tests above hold
+    against the oracle."""
+    monkeypatch.setenv("LSK_TUNE", "0")
+    steps = 6
+
+    def body(ctx):
+        rows = n1 ** 3
+        _, offsets, coeffs = bs.sg.benchmark_stencil(4)
+        partition = IndexPartition.equal(IndexSpace(0, rows - 1), pieces)
+        matrix = bs.sg.create_linearized_csr_stencil_matrix(ctx, (n1, n1, n1), offsets, coeffs, partition, torch.float64)
+        planner = SquarePlanner(ctx, torch.float64)
+        for s in range(2):
+            sol = PartitionedVector(ctx, f"sol{s}", partition, torch.float64)
+            sol.zero_fill()
+            planner.add_sol_vector(sol)
+        for s in range(2):
+            rhs = PartitionedVector(ctx, f"rhs{s}", partition, torch.float64)
+            rhs.constant_fill(1.0) if s == 0 else rhs.random_fill(7)   # two different systems
+            planner.add_rhs_vector(rhs)
+        for s in range(2):
+            planner.add_row_partitioned_matrix(matrix, s, s)
+        solver = CGSolver(planner)
+        for _ in range(steps):
+            solver.step()
+        entry = planner.row_partitioned_matrices[0]
+        return {"history": [s.get_value() for s in solver.residual_norm_squared],
+                "sols": [planner.get_vector(0, s).to_host().numpy().copy() for s in range(2)],
+                "paired": planner._paired_products, "phases": sorted({run[0] for runs in (entry.split or {}).values() for run in runs}),
+                "fused_used": planner._fused_dot_used}
+
+    print(f"case thread ranks two systems world={world} pieces={pieces} {n1}^3 paired", flush=True)
+    paired = run_ranks(world, body)
+    monkeypatch.setenv("LSK_PAIR", "0")
+    print(f"case thread ranks two systems world={world} pieces={pieces} {n1}^3 one product per system", flush=True)
+    single = run_ranks(world, body)
+    for r, (a, b) in enumerate(zip(paired, single)):
+        assert a["paired"] >= steps and b["paired"] == 0, f"rank {r}: {a['paired']} / {b['paired']} paired products"
+        assert a["phases"] == [0, 1], f"rank {r}: halo/interior split not in force"
+        assert a["history"] == b["history"], f"rank {r}: scalars differ"
+        assert a["fused_used"] == b["fused_used"] and a["fused_used"] >= steps - 1
+        for s in range(2):
+            assert np.array_equal(a["sols"][s], b["sols"][s]), f"rank {r}: solution {s} differs"
+        assert all(np.isfinite(a["history"]))
