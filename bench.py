@@ -147,6 +147,12 @@ def cpu_baseline(matrix, n1: int):
     }
 
 
+def uniform_kernel_name(kernel: str) -> str:
+    """The instance that takes the values as scalars: the wave-staged kernel with its last template
+    argument (UNIFORM) true."""
+    return kernel.replace(", false>", ", true>") if kernel.startswith("sliced_wave_kernel") else kernel
+
+
 def library_option(key: str) -> int:
     import ctypes
     from legionsolvers_amd import _lib
@@ -244,7 +250,7 @@ def main():
         if opt["sliced.form"] == 1:   # <T, CAP, DOT, K, RUN3, DMA>: wave-staged windows (the library's default)
             run3 = bool(opt["sliced.runs"]) and all(p.runs_of_three for p in parts)
             kernel = (f"sliced_wave_kernel<double, {cap}, {dot}, 1, {'true' if run3 else 'false'}, "
-                      f"{'true' if opt['sliced.dma'] else 'false'}>")
+                      f"{'true' if opt['sliced.dma'] else 'false'}, false>")
         else:
             kernel = f"sliced_spmv_kernel<double, {cap}, {dot}, false>"
         layout = ("sliced-pattern copy made once at set-up: the values in blocks of 512 rows (16 bytes per lane and "
@@ -276,6 +282,25 @@ def main():
         traffic = measured.get("bytes_per_launch_sliced") if sliced else traffic32 if compressed else traffic64
         traffic_source = ("recorded, not measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
                           "tools/pmc_spmv.py, profiles/spmv_hbm_traffic.json")
+
+    # The same steps with the matrix values taken as scalars (option sliced.uniform): every matrix of the
+    # reference's benchmark is a constant-coefficient stencil, the sliced-pattern copy finds that out bit by
+    # bit at set-up, and the product then reads no value array at all.  Not the default: reported beside it.
+    uniform = None
+    if sliced and all(p.uniform_values for p in matrix.sliced.values()):
+        import ctypes
+        from legionsolvers_amd import _lib
+        _lib.call("lsk_set_option", b"sliced.uniform", 1)
+        try:
+            uni_steps = max(args.steps // 2, 2)
+            uni_iters = uni_steps / bs.timed_steps(ctx, solver, 2, uni_steps)
+            t_uni = spmv_kernel_time(ctx, matrix, planner, reps=20, form="sliced")
+        finally:
+            _lib.call("lsk_set_option", b"sliced.uniform", 0)
+        uni_bytes = sum(p.algorithmic_bytes(partition.pieces[c].volume, 8, without_values=True)
+                        for c, p in matrix.sliced.items())
+        uniform = {"iters_per_s": uni_iters, "ms_per_launch": t_uni * 1e3, "algorithmic_bytes_per_launch": uni_bytes,
+                   "achieved": uni_bytes / t_uni / 1e9, "kernel": uniform_kernel_name(kernel)}
 
     # the whole CG step on the reference's arrays as handed over (no set-up-time copy of any kind)
     held = matrix.sliced_window, matrix.col32_window
@@ -323,6 +348,7 @@ def main():
         "spmv_gbps": spmv_gbps_job,
         "two_system_iters_per_s": two_system,
         "two_system_iters_per_s_separate_products": two_system_separate,
+        "value_uniform_coefficients": uniform["iters_per_s"] if uniform else None,
         "value_untuned": iters_untuned,
         "value_reference_layout": iters_reference_layout,
         "setup_s": {k: round(v, 3) for k, v in setup_s.items()},
@@ -331,6 +357,11 @@ def main():
             "two_system_iters_per_s": "the reference's BenchmarkStencil as it runs: two systems on one matrix per step; "
                                       "both products share one pass over the matrix values (lsk_csr_sliced_spmv2_*), each "
                                       "bit for bit what its own product gives; ..._separate_products: one product per system",
+            "value_uniform_coefficients": "the same steps with option sliced.uniform = 1 (off by default): the matrix is a "
+                                          "constant-coefficient stencil, which the sliced-pattern copy verifies bit by bit at "
+                                          "set-up, and the product takes the 27 coefficients as scalars instead of reading "
+                                          "the value array; same multiplications and additions in the same order, same bits "
+                                          "(roofline_uniform_coefficients: that kernel, not bound by HBM any more)",
             "value_untuned": "the same steps before the set-up-time speed tuning (workgroup placement chosen by timing, "
                              "the copy re-made up to 6 times keeping the fastest, wait for the driver's scrubbing of freed "
                              "memory): LSK_TUNE=0",
@@ -348,6 +379,11 @@ def main():
             "ms_per_launch": t_spmv * 1e3,
             "algorithmic_bytes_per_launch": algo_bytes,
             "tile_placement": sorted(set((matrix.sliced_placement if sliced else matrix.placement).values())) or [0],
+        },
+        "roofline_uniform_coefficients": None if not uniform else {
+            "bound": "hbm", "achieved": uniform["achieved"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": uniform["achieved"] / HBM_PEAK_GBPS, "traffic": None, "kernel": uniform["kernel"],
+            "ms_per_launch": uniform["ms_per_launch"], "algorithmic_bytes_per_launch": uniform["algorithmic_bytes_per_launch"],
         },
         "roofline_32bit_structure": {
             "bound": "hbm", "achieved": algo_bytes32 / t_spmv32 / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",

@@ -10,7 +10,8 @@
 // sides of <A x, b> = <x, A^T b>; N > 1 transposes in runs of N entries; -binned 1 (with -coo 1) multiplies
 // through the binned copy of the COO matrix, in blocks of -bincols columns and tiles of -binrows rows
 // (0: the library's choice); -cgs 1 gives GMRES the classical Gram-Schmidt option; -pair 0 multiplies the two
-// systems one after the other instead of in one pass over the matrix.
+// systems one after the other instead of in one pass over the matrix; -uniform 1 sets the library's option
+// "sliced.uniform" (a constant-coefficient stencil's values as scalars: the products read no value array).
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -27,7 +28,7 @@ namespace {
 struct Args {
     long dim = 1, solver = 1, nx = 16, ny = 16, nz = 16, vp = 4, it = 20, pt = 1;
     long systems = 2, coo = 0, f32 = 0, restart = 10, history = 0, compress = 1, fuse = 1, redraws = 4, adjoint = 0, sliced = 1;
-    long binned = 0, bincols = 0, binrows = 0, cgs = 0, pair = 1;
+    long binned = 0, bincols = 0, binrows = 0, cgs = 0, pair = 1, uniform = 0;
 };
 
 Args parse(int argc, char **argv) {
@@ -39,7 +40,8 @@ Args parse(int argc, char **argv) {
         {"-history", &Args::history}, {"-compress", &Args::compress}, {"-fuse", &Args::fuse},
         {"-redraws", &Args::redraws}, {"-adjoint", &Args::adjoint},
         {"-sliced", &Args::sliced}, {"-binned", &Args::binned}, {"-bincols", &Args::bincols},
-        {"-binrows", &Args::binrows}, {"-cgs", &Args::cgs}, {"-pair", &Args::pair}};
+        {"-binrows", &Args::binrows}, {"-cgs", &Args::cgs}, {"-pair", &Args::pair},
+        {"-uniform", &Args::uniform}};
     for (int i = 1; i + 1 < argc; i += 2) {
         bool known = false;
         for (const auto &t : table)
@@ -133,6 +135,7 @@ template <typename T> int main_typed(const Args &a) {
     SquarePlanner<T> planner(ctx);
     planner.set_fusion(a.fuse != 0);
     planner.set_pairing(a.pair != 0);
+    check(lsk_set_option("sliced.uniform", a.uniform != 0));
     for (long s = 0; s < a.systems; ++s) {
         sols.push_back(std::make_unique<PartitionedVector<T>>(ctx, s ? "sol1" : "sol", partition));
         sols.back()->zero_fill();

@@ -624,6 +624,13 @@ int lsk_csr_sliced_tune2_f32(const lsk_csr_sliced_t *m, const float *xa, const f
 int lsk_csr_sliced_tune2_f64(const lsk_csr_sliced_t *m, const double *xa, const double *xb, double *ya, double *yb,
                              lsk_stream_t stream, int *xcd_remap, float *ms);
 int lsk_csr_sliced_info(const lsk_csr_sliced_t *m, int64_t *out);
+/* 1 when entry j of a block's list has ONE value in every row of every block on that list, checked bit by
+ * bit against the copy's values at create and again at every update_values (a constant-coefficient stencil,
+ * as every matrix of test/BenchmarkStencil.cpp:35-124 is); 0 otherwise.  With option "sliced.uniform" = 1
+ * (default 0) the products of such a structure take the values as scalars from a 64 x 32 table and do not
+ * read the value array: rows * 2 s bytes per product instead of padded entries * s + rows * 2 s, same
+ * multiplications and additions in the same order, same bits.  No counterpart in the reference. */
+int lsk_csr_sliced_uniform_values(const lsk_csr_sliced_t *m);
 int lsk_csr_sliced_destroy(lsk_csr_sliced_t *m);
 
 /* ------------------------------------------------ set-up helpers (device side) ------ */

@@ -96,6 +96,7 @@ PROTOTYPES = {
     "lsk_csr_sliced_spmv2_dot_f64": (_i, [_p, _i64, _i64, _p, _p, _p, _p, _i, _p, _p, _p, _p, _i64, _p, _p]),
     "lsk_csr_sliced_tune_f32": (_i, [_p, _p, _p, _p, _p, _p]),
     "lsk_csr_sliced_tune_f64": (_i, [_p, _p, _p, _p, _p, _p]),
+    "lsk_csr_sliced_uniform_values": (_i, [_p]),
     "lsk_csr_sliced_tune2_f32": (_i, [_p, _p, _p, _p, _p, _p, _p, _p]),
     "lsk_csr_sliced_tune2_f64": (_i, [_p, _p, _p, _p, _p, _p, _p, _p]),
     "lsk_csr_sliced_info": (_i, [_p, _p]),

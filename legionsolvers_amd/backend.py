@@ -458,10 +458,17 @@ class SlicedStructure:
         self.runs_of_three = bool(runs3)  # every list that serves a block is runs of three consecutive distances
         self.pair_served = bool(pair)   # lsk_csr_sliced_spmv2_* serves this structure
 
-    def algorithmic_bytes(self, rows: int, elem_size: int) -> int:
-        """Bytes one product of `rows` rows must move: the padded values, x and y once, 16 per block,
-        a 4-byte mask per row of a masked wave, a pattern id per row of a block without a common list."""
-        return (self.padded_entries * elem_size + rows * 2 * elem_size + self.blocks * 16
+    @property
+    def uniform_values(self) -> bool:
+        """Every position of every list has one value in all rows (asked anew: update_values can change it);
+        with option sliced.uniform = 1 the products of such a structure do not read the value array."""
+        return bool(self.lib.lsk_csr_sliced_uniform_values(self.handle))
+
+    def algorithmic_bytes(self, rows: int, elem_size: int, without_values: bool = False) -> int:
+        """Bytes one product of `rows` rows must move: the padded values (unless the product takes them
+        as scalars, see uniform_values), x and y once, 16 per block, a 4-byte mask per row of a masked
+        wave, a pattern id per row of a block without a common list."""
+        return ((0 if without_values else self.padded_entries * elem_size) + rows * 2 * elem_size + self.blocks * 16
                 + self.masked_waves * (self.block_rows // 4) * 4 + self.mixed_blocks * self.block_rows)
 
     def close(self) -> None:

@@ -73,6 +73,7 @@ struct Options {
     int sliced_form = 1;
     int sliced_dma = 1;       // the wave-staged form sends the windows of x from memory straight into LDS
     int sliced_runs = 1;      // ... and reads lists of runs of three run by run (0: entry by entry)
+    int sliced_uniform = 0;   // ... and takes the values as scalars where every list position has one value (no value loads)
     // Two right-hand sides: 1 wave-staged, one vector after the other through one LDS area; 0 both
     // vectors' windows in LDS at once (block-staged); -1: 1 where the wave-staged form serves.
     int sliced_pair_form = -1;

@@ -129,6 +129,8 @@ int lsk_set_option(const char *key, int value) {
         o.sliced_dma = value != 0;
     } else if (!std::strcmp(key, "sliced.runs")) {
         o.sliced_runs = value != 0;
+    } else if (!std::strcmp(key, "sliced.uniform")) {
+        o.sliced_uniform = value != 0;
     } else if (!std::strcmp(key, "sliced.pair_form")) {
         if (value < -1 || value > 1) return lsk::fail(LSK_ERR_ARG, "sliced.pair_form must be -1, 0 or 1");
         o.sliced_pair_form = value;
@@ -153,6 +155,7 @@ int lsk_get_option(const char *key, int *value) {
     else if (!std::strcmp(key, "sliced.form")) *value = o.sliced_form;
     else if (!std::strcmp(key, "sliced.dma")) *value = o.sliced_dma;
     else if (!std::strcmp(key, "sliced.runs")) *value = o.sliced_runs;
+    else if (!std::strcmp(key, "sliced.uniform")) *value = o.sliced_uniform;
     else if (!std::strcmp(key, "sliced.pair_form")) *value = o.sliced_pair_form;
     else return lsk::fail(LSK_ERR_ARG, "lsk_get_option: unknown key '%s'", key);
     return LSK_OK;

@@ -88,6 +88,12 @@ struct lsk_csr_sliced {
     unsigned char *row_pattern = nullptr; // per row
     unsigned *row_mask = nullptr;  // per row: which entries of its block's list the row has
     PatternInfo *table = nullptr;  // kMaxPatterns entries
+    // Uniform values: entry j of a block's list has ONE value in every row of every block on that list (a
+    // constant-coefficient stencil).  uniform[list * kMaxLength + j] is that value; the product can then
+    // run without reading the values at all (option sliced.uniform).
+    void *uniform = nullptr;
+    int *uniform_scratch = nullptr; // kMaxPatterns first-block slots + 1 mismatch flag
+    bool uniform_ok = false;
 };
 
 namespace {
@@ -370,6 +376,82 @@ __global__ __launch_bounds__(kBlock) void sliced_fill_kernel(int64_t rows, int64
     }
 }
 
+// Uniform values, step 1: the first block (lowest index) that runs on each list.
+__global__ __launch_bounds__(kBlock) void sliced_uniform_first_kernel(int64_t blocks, const BlockMeta *__restrict__ meta,
+                                                                      int *__restrict__ first) {
+    const int64_t b = int64_t(blockIdx.x) * kBlock + threadIdx.x;
+    if (b >= blocks) return;
+    const int pattern = meta[b].pattern;
+    if (pattern >= 0 && meta[b].maxlen > 0) atomicMin(&first[pattern & 0xff], static_cast<int>(min(b, int64_t(INT_MAX))));
+}
+
+// Step 2: one workgroup per list: the values of the first row of that block which has the whole list
+// (the row the list was taken from is one) become the list's candidate values.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void sliced_uniform_pick_kernel(int64_t rows, const BlockMeta *__restrict__ meta,
+                                                                     const unsigned *__restrict__ row_mask,
+                                                                     const T *__restrict__ val, const int *__restrict__ first,
+                                                                     T *__restrict__ uniform) {
+    constexpr int R = Lane<T>::R;
+    constexpr int kBlockRows = kBlock * R, kWaveRows = kWave * R;
+    __shared__ int chosen;
+    const int list = blockIdx.x;
+    const int b = first[list];
+    if (b == INT_MAX) return; // no block runs on this list
+    const BlockMeta m = meta[b];
+    const unsigned full = m.maxlen >= 32 ? 0xffffffffu : (1u << m.maxlen) - 1u;
+    if (threadIdx.x == 0) chosen = INT_MAX;
+    __syncthreads();
+    for (int h = 0; h < R; ++h) {
+        const int in = threadIdx.x * R + h;
+        const int64_t r = int64_t(b) * kBlockRows + in;
+        if (r >= rows) continue;
+        const bool masked = (m.pattern & kBlockMasked) && ((m.pattern >> (kWaveMaskedShift + in / kWaveRows)) & 1);
+        if (!masked || (row_mask[r] & full) == full) atomicMin(&chosen, in);
+    }
+    __syncthreads();
+    const int in = chosen;
+    if (in == INT_MAX) return; // (cannot happen: the list is that of one of the block's rows)
+    const T *src = val + m.base + int64_t(in / kWaveRows) * m.maxlen * kWaveRows + in % kWaveRows;
+    for (int j = threadIdx.x; j < kMaxLength; j += kBlock)
+        uniform[list * kMaxLength + j] = j < m.maxlen ? src[int64_t(j) * kWaveRows] : T(0);
+}
+
+// Step 3: every value of every row against its list's candidate, bit by bit.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void sliced_uniform_check_kernel(int64_t rows, const BlockMeta *__restrict__ meta,
+                                                                      const unsigned *__restrict__ row_mask,
+                                                                      const T *__restrict__ val, const T *__restrict__ uniform,
+                                                                      int *__restrict__ mismatch) {
+    constexpr int R = Lane<T>::R;
+    using V = typename Lane<T>::V;
+    using Bits = std::conditional_t<sizeof(T) == 8, unsigned long long, unsigned>;
+    constexpr int kBlockRows = kBlock * R, kWaveRows = kWave * R;
+    const int64_t b = blockIdx.x;
+    const BlockMeta m = meta[b];
+    if (m.pattern < 0) {
+        if (threadIdx.x == 0) *mismatch = 1; // a block without a common list: not this form's business
+        return;
+    }
+    const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
+    const int64_t r = b * kBlockRows + int64_t(threadIdx.x) * R;
+    const bool masked = (m.pattern & kBlockMasked) && ((m.pattern >> (kWaveMaskedShift + wave)) & 1);
+    unsigned mask[R];
+    for (int h = 0; h < R; ++h) mask[h] = r + h >= rows ? 0u : masked ? row_mask[r + h] : 0xffffffffu;
+    const T *vp = val + m.base + int64_t(wave) * m.maxlen * kWaveRows + lane * R;
+    const T *mine = uniform + (m.pattern & 0xff) * kMaxLength;
+    bool differs = false;
+    for (int j = 0; j < m.maxlen; ++j) {
+        const V v = __builtin_nontemporal_load(reinterpret_cast<const V *>(vp + int64_t(j) * kWaveRows));
+        const Bits want = __builtin_bit_cast(Bits, mine[j]);
+        for (int h = 0; h < R; ++h) {
+            const T got = v[h];
+            differs = differs || (((mask[h] >> j) & 1u) && __builtin_bit_cast(Bits, got) != want);
+        }
+    }
+    if (__any(differs) && lane == 0) *mismatch = 1;
+}
+
 // The product.  One workgroup per block of 256 R rows; lane t owns rows R t .. R t + R - 1 of the
 // block.  CAP: the longest row the instance serves (all of a lane's value loads are in flight at
 // once).  DOT: workgroup g (of the logical order, whatever its placement) also leaves partials[g] =
@@ -633,13 +715,18 @@ template <int K, int CAP> constexpr int sliced_wave_waves_per_simd() {
 // DMA: a window that lies wholly inside the vector goes from memory straight into LDS (one
 // global_load_lds_dwordx4 per window and wave: no registers, nothing to wait for before the next
 // request), the others through registers as before.
-template <typename T, int CAP, bool DOT, int K, bool RUN3, bool DMA>
-__global__ __launch_bounds__(kBlock, (sliced_wave_waves_per_simd<K, CAP>())) void sliced_wave_kernel(
+// UNIFORM: entry j of the block's list has one value for every row (a constant-coefficient stencil): the
+// values come from `uniform` as scalars and the value array is not read at all.
+template <typename T, int CAP, bool DOT, int K, bool RUN3, bool DMA, bool UNIFORM>
+#ifndef LSK_UNIFORM_WAVES
+#define LSK_UNIFORM_WAVES 4
+#endif
+__global__ __launch_bounds__(kBlock, (UNIFORM ? LSK_UNIFORM_WAVES : sliced_wave_waves_per_simd<K, CAP>())) void sliced_wave_kernel(
     int64_t block_begin, int64_t row_begin, int64_t row_end, const BlockMeta *__restrict__ meta,
     const T *__restrict__ val, const unsigned *__restrict__ row_mask, const PatternInfo *__restrict__ table,
     const T *__restrict__ xa, const T *__restrict__ xb, long long x_shift, long long x_extent, T *__restrict__ ya,
     T *__restrict__ yb, int beta, int remap, const T *__restrict__ wa, const T *__restrict__ wb, T *__restrict__ pa,
-    T *__restrict__ pb, int lds_wave_elems, int yw_aligned) {
+    T *__restrict__ pb, int lds_wave_elems, int yw_aligned, const T *__restrict__ uniform) {
     constexpr int R = Lane<T>::R;
     using V = typename Lane<T>::V;
     constexpr int kBlockRows = kBlock * R, kWaveRows = kWave * R;
@@ -675,9 +762,23 @@ __global__ __launch_bounds__(kBlock, (sliced_wave_waves_per_simd<K, CAP>())) voi
     const long long xlast = x_extent - 1;
     const unsigned lenmask = maxlen >= 32 ? 0xffffffffu : (1u << maxlen) - 1u;
     const bool plain = !masked && __all(all_live);
-    V v[CAP];
+    V v[UNIFORM ? 1 : CAP];
+    T uv[UNIFORM ? CAP : 1]; // UNIFORM: the list's values (scalars)
+    auto value = [&](int j, int h) -> T {
+        if constexpr (UNIFORM) return uv[j];
+        else return v[j][h];
+    };
     unsigned packed[(CAP + 1) / 2];
     T result[K][R];
+    // DIRECT (UNIFORM, lists of runs of three): x straight from memory into registers, no LDS at all.  With
+    // no values to wait for, what a wave spends is the chain meta -> windows -> sums; without the LDS areas
+    // (9.5 KiB per wave for the 27-point list) twice as many waves walk that chain at a time.
+#ifndef LSK_UNIFORM_DIRECT
+#define LSK_UNIFORM_DIRECT 1
+#endif
+    constexpr bool DIRECT = LSK_UNIFORM_DIRECT && UNIFORM && RUN3;
+    // (27-point 512^3 fp64: 1.27 ms through LDS, 0.92 ms direct; one ALIGNED 16-byte load per lane and run
+    // with the two outer elements taken from the neighbouring lanes' registers: 1.57 ms.)
     // AHEAD: both vectors' windows requested before anything is summed, each into its own LDS area; else
     // the vectors share one area, one after the other.  Measured with the windows going straight into
     // LDS: ahead 7.5 ms, one after the other 6.3 ms for the pair on the 27-point 512^3 fp64 matrix (the
@@ -761,6 +862,12 @@ __global__ __launch_bounds__(kBlock, (sliced_wave_waves_per_simd<K, CAP>())) voi
         // below would make each of them wait for the one before
 #pragma unroll
         for (int i = 0; i < (CAP + 1) / 2; ++i) packed[i] = info.w_lds_off_packed[i];
+        if constexpr (UNIFORM) {
+            const T *mine = uniform + (pattern & 0xff) * kMaxLength; // (wave-uniform address: scalar loads)
+#pragma unroll
+            for (int j = 0; j < CAP; ++j) uv[j] = mine[j]; // (zero past the list's end)
+            return;
+        }
         __builtin_amdgcn_sched_barrier(0); // (the value loads stay behind the staging, whose registers they take)
 #pragma unroll
         for (int j = 0; j < CAP; ++j) {
@@ -783,19 +890,40 @@ __global__ __launch_bounds__(kBlock, (sliced_wave_waves_per_simd<K, CAP>())) voi
         const T *yin = k == 0 ? ya : yb;
         T *area = AHEAD ? xs + k * (lds_wave_elems / 2) : xs;
         if constexpr (!AHEAD) {
-            stage(k, area);
+            if constexpr (!DIRECT) stage(k, area);
             if (k == 0) load_values();
         }
         // A window that went straight into LDS has landed when the load counter says so.  The wave's own
         // LDS writes are in place before its reads: LDS serves a wave's accesses in order, and the fence
         // keeps the compiler from moving the reads up.
-        if constexpr (DMA) {
-            if (!AHEAD || k == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        constexpr int NV = (R + 2 + R - 1) / R; // 16-byte pieces that cover the R + 2 elements of a run of three
+        V xg[DIRECT ? CAP / 3 : 1][NV];
+        if constexpr (DIRECT) {
+            const T *x = k == 0 ? xa : xb;
+#pragma unroll
+            for (int q = 0; q < CAP / 3; ++q) {
+                if (3 * q >= maxlen) continue; // (wave-uniform)
+                const long long first = r0 + x_shift + rstart[q];
+                if (first >= 0 && first + kWaveRows + R <= x_extent) {
+                    const T *src = x + first + lane * R;
+#pragma unroll
+                    for (int i = 0; i < NV; ++i) __builtin_memcpy(&xg[q][i], src + i * R, sizeof(V)); // (8-byte aligned)
+                } else { // a window that reaches past an end of the vector: element by element, clamped
+#pragma unroll
+                    for (int i = 0; i < NV; ++i)
+#pragma unroll
+                        for (int c = 0; c < R; ++c) xg[q][i][c] = fetch_from(x, first + lane * R + i * R + c);
+                }
+            }
+        } else {
+            if constexpr (DMA) {
+                if (!AHEAD || k == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            if (has_tail) area[info.w_tail_off[lane]] = tail[k];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
-        if (has_tail) area[info.w_tail_off[lane]] = tail[k];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         const T *lane_xs = area + lane * R;
         T acc[R];
 #pragma unroll
@@ -808,13 +936,13 @@ __global__ __launch_bounds__(kBlock, (sliced_wave_waves_per_simd<K, CAP>())) voi
                 for (int h = 0; h < R; ++h) xv[h] = src[h];
                 if constexpr (decltype(plain_tag)::value) {
 #pragma unroll
-                    for (int h = 0; h < R; ++h) acc[h] = acc[h] + v[j][h] * xv[h];
+                    for (int h = 0; h < R; ++h) acc[h] = acc[h] + value(j, h) * xv[h];
                 } else {
 #pragma unroll
                     for (int h = 0; h < R; ++h) asm volatile("" : "+v"(xv[h]));
 #pragma unroll
                     for (int h = 0; h < R; ++h) {
-                        const T sum = acc[h] + v[j][h] * xv[h];
+                        const T sum = acc[h] + value(j, h) * xv[h];
                         acc[h] = ((mask[h] & lenmask) >> j) & 1u ? sum : acc[h];
                     }
                 }
@@ -824,21 +952,26 @@ __global__ __launch_bounds__(kBlock, (sliced_wave_waves_per_simd<K, CAP>())) voi
             if (3 * q < maxlen) { // (wave-uniform; the list is whole runs)
                 // packed[] holds the place of every entry: that of the run's first is the window's start
                 const T *src = lane_xs + ((packed[(3 * q) / 2] >> (16 * ((3 * q) % 2))) & 0xffffu);
-                constexpr int NV = (R + 2 + R - 1) / R; // 16-byte reads that cover R + 2 elements
                 V xw[NV];
 #pragma unroll
-                for (int i = 0; i < NV; ++i) xw[i] = *reinterpret_cast<const V *>(src + i * R);
+                for (int i = 0; i < NV; ++i) {
+                    if constexpr (DIRECT) xw[i] = xg[q][i];
+                    else xw[i] = *reinterpret_cast<const V *>(src + i * R);
+                }
                 if constexpr (!decltype(plain_tag)::value) {
 #pragma unroll
                     for (int i = 0; i < NV; ++i) asm volatile("" : "+v"(xw[i]));
                 }
+                T xe[R + 2]; // the R + 2 elements of x the lane's R rows read in this run
+#pragma unroll
+                for (int i = 0; i < R + 2; ++i) xe[i] = xw[i / R][i % R];
 #pragma unroll
                 for (int e = 0; e < 3; ++e) {
                     const int j = 3 * q + e;
 #pragma unroll
                     for (int h = 0; h < R; ++h) {
-                        const T xv = xw[(e + h) / R][(e + h) % R];
-                        const T sum = acc[h] + v[j][h] * xv;
+                        const T xv = xe[e + h];
+                        const T sum = acc[h] + value(j, h) * xv;
                         if constexpr (decltype(plain_tag)::value) acc[h] = sum;
                         else acc[h] = ((mask[h] & lenmask) >> j) & 1u ? sum : acc[h];
                     }
@@ -1164,6 +1297,9 @@ void plan_wave_staging(PatternInfo &p, int wave_rows) {
 }
 
 template <typename T>
+int uniform_refresh(lsk_csr_sliced *m, hipStream_t s);
+
+template <typename T>
 int create(const char *name, int64_t rows, int64_t nnz, const int64_t *rects, int64_t k_base, const int64_t *col,
            const T *val, int64_t row_first, int64_t x_lo, int64_t x_hi, lsk_stream_t stream, lsk_csr_sliced **out) {
     constexpr int R = Lane<T>::R;
@@ -1324,6 +1460,7 @@ int create(const char *name, int64_t rows, int64_t nnz, const int64_t *rects, in
                 LSK_TRY(hipGetLastError());
                 LSK_TRY(hipStreamSynchronize(s));
             }
+            if (status == LSK_OK) status = uniform_refresh<T>(m, s);
         }
     }
 #undef LSK_TRY
@@ -1338,6 +1475,39 @@ int create(const char *name, int64_t rows, int64_t nnz, const int64_t *rects, in
                             host_flags[kFlagMismatch], host_flags[kFlagOutsideWindow]);
     }
     *out = m;
+    return LSK_OK;
+}
+
+inline bool wave_form_serves(const lsk_csr_sliced *m);
+
+// Finds out whether the copy's values are uniform per list position (see lsk_csr_sliced::uniform) and
+// leaves the lists' values in m->uniform.  Synchronises the stream.
+template <typename T>
+int uniform_refresh(lsk_csr_sliced *m, hipStream_t s) {
+    m->uniform_ok = false;
+    if (!wave_form_serves(m) || m->blocks <= 0 || m->blocks > INT_MAX) return LSK_OK;
+    if (!m->uniform) LSK_HIP(hipMalloc(&m->uniform, sizeof(T) * kMaxPatterns * kMaxLength));
+    if (!m->uniform_scratch) LSK_HIP(hipMalloc(reinterpret_cast<void **>(&m->uniform_scratch), sizeof(int) * (kMaxPatterns + 1)));
+    int init[kMaxPatterns + 1];
+    for (int i = 0; i < kMaxPatterns; ++i) init[i] = INT_MAX;
+    init[kMaxPatterns] = 0;
+    LSK_HIP(hipMemcpyAsync(m->uniform_scratch, init, sizeof(init), hipMemcpyHostToDevice, s));
+    LSK_HIP(hipStreamSynchronize(s)); // (init is on this stack)
+    const BlockMeta *meta = static_cast<const BlockMeta *>(m->meta);
+    const T *val = static_cast<const T *>(m->val);
+    T *uniform = static_cast<T *>(m->uniform);
+    sliced_uniform_first_kernel<<<static_cast<unsigned>(lsk::ceil_div(m->blocks, kBlock)), kBlock, 0, s>>>(m->blocks, meta,
+                                                                                                         m->uniform_scratch);
+    LSK_LAUNCH_CHECK();
+    sliced_uniform_pick_kernel<T><<<kMaxPatterns, kBlock, 0, s>>>(m->rows, meta, m->row_mask, val, m->uniform_scratch, uniform);
+    LSK_LAUNCH_CHECK();
+    sliced_uniform_check_kernel<T><<<static_cast<unsigned>(m->blocks), kBlock, 0, s>>>(m->rows, meta, m->row_mask, val, uniform,
+                                                                                      m->uniform_scratch + kMaxPatterns);
+    LSK_LAUNCH_CHECK();
+    int mismatch = 1;
+    LSK_HIP(hipMemcpyAsync(&mismatch, m->uniform_scratch + kMaxPatterns, sizeof(int), hipMemcpyDeviceToHost, s));
+    LSK_HIP(hipStreamSynchronize(s));
+    m->uniform_ok = mismatch == 0;
     return LSK_OK;
 }
 
@@ -1359,7 +1529,8 @@ int update_values(const char *name, lsk_csr_sliced *m, int64_t rows, int64_t nnz
         rows, padded_rows, reinterpret_cast<const long long *>(rects), k_base, val, static_cast<const BlockMeta *>(m->meta),
         m->row_mask, static_cast<T *>(m->val));
     LSK_LAUNCH_CHECK();
-    return LSK_OK;
+    // (whether the new values are uniform per list position has to be found out again: waits for the stream)
+    return uniform_refresh<T>(m, lsk::as_stream(stream));
 }
 
 // Whether the wave-staged kernel serves the structure: every block on one staged list, and the four
@@ -1380,21 +1551,22 @@ int launch_wave(const lsk_csr_sliced *m, int64_t block_begin, unsigned blocks, i
     const bool dma = lsk::options().sliced_dma != 0;
     const int areas = (LSK_WAVE_AHEAD && dma && K == 2) ? 2 : 1; // LDS areas per wave (see AHEAD in the kernel)
     const int wave_elems = static_cast<int>(m->wave_lds_bytes / sizeof(T)) * areas;
-    const size_t lds = m->wave_lds_bytes * kWavesPerBlock * areas;
-#define LSK_WAVE_LAUNCH2(CAP, DOT, RUN3, DMA)                                                                      \
+    size_t lds = m->wave_lds_bytes * kWavesPerBlock * areas;
+#define LSK_WAVE_LAUNCH2(CAP, DOT, RUN3, DMA, UNIFORM)                                                             \
     do {                                                                                                           \
-        auto kernel = sliced_wave_kernel<T, CAP, DOT, K, RUN3, DMA>;                                               \
+        auto kernel = sliced_wave_kernel<T, CAP, DOT, K, RUN3, DMA, UNIFORM>;                                      \
         if (lds > (size_t(64) << 10))                                                                              \
             LSK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),                                    \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));       \
         kernel<<<blocks, kBlock, lds, s>>>(block_begin, row_begin, row_end, meta, val, m->row_mask, m->table, xa, xb, \
                                            x_shift, x_extent, ya, yb, beta, remap, wa, wb, pa, pb, wave_elems,      \
-                                           yw_aligned);                                                            \
+                                           yw_aligned, static_cast<const T *>(m->uniform));                        \
     } while (0)
 #define LSK_WAVE_LAUNCH(CAP, DOT, RUN3)                                                                            \
     do {                                                                                                           \
-        if (dma) LSK_WAVE_LAUNCH2(CAP, DOT, RUN3, true);                                                           \
-        else LSK_WAVE_LAUNCH2(CAP, DOT, RUN3, false);                                                              \
+        if (dma && uniform) LSK_WAVE_LAUNCH2(CAP, DOT, RUN3, true, true);                                          \
+        else if (dma) LSK_WAVE_LAUNCH2(CAP, DOT, RUN3, true, false);                                               \
+        else LSK_WAVE_LAUNCH2(CAP, DOT, RUN3, false, false);                                                       \
     } while (0)
 #define LSK_WAVE_CAP(CAP, RUN3)                                                                                    \
     do {                                                                                                           \
@@ -1402,6 +1574,9 @@ int launch_wave(const lsk_csr_sliced *m, int64_t block_begin, unsigned blocks, i
         else LSK_WAVE_LAUNCH(CAP, false, RUN3);                                                                    \
     } while (0)
     const bool run3 = m->runs_of_three && lsk::options().sliced_runs != 0;
+    // the values as scalars, where every list position has one value and the caller asked for it
+    const bool uniform = m->uniform_ok && m->uniform && lsk::options().sliced_uniform != 0;
+    if (LSK_UNIFORM_DIRECT && uniform && dma && run3 && m->max_len > 20 && m->max_len <= 27) lds = 0; // (DIRECT in the kernel)
     if (m->max_len <= 8) LSK_WAVE_CAP(8, false);
     else if (m->max_len <= 16) LSK_WAVE_CAP(16, false);
     else if (m->max_len <= 20) LSK_WAVE_CAP(20, false);
@@ -1705,6 +1880,8 @@ int lsk_csr_sliced_info(const lsk_csr_sliced_t *m, int64_t *out) {
     return LSK_OK;
 }
 
+int lsk_csr_sliced_uniform_values(const lsk_csr_sliced_t *m) { return m && m->uniform_ok ? 1 : 0; }
+
 int lsk_csr_sliced_destroy(lsk_csr_sliced_t *m) {
     if (!m) return LSK_OK;
     (void)hipFree(m->val);
@@ -1712,6 +1889,8 @@ int lsk_csr_sliced_destroy(lsk_csr_sliced_t *m) {
     (void)hipFree(m->row_pattern);
     (void)hipFree(m->row_mask);
     (void)hipFree(m->table);
+    (void)hipFree(m->uniform);
+    (void)hipFree(m->uniform_scratch);
     delete m;
     return LSK_OK;
 }

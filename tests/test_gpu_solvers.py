@@ -343,6 +343,39 @@ def test_two_systems_on_one_matrix_share_a_pass(gpu_ctx, monkeypatch, solver_nam
     assert not torch.equal(a1, b1)
 
 
+@pytest.mark.parametrize("solver_name", ["cg", "bicgstab", "gmres"])
+@pytest.mark.parametrize("flag,extent,pieces", [(4, (3, 4, 512), 2), (4, (7, 12, 70), 1), (3, (9, 11, 13), 1)],
+                         ids=["27-point-2-pieces", "27-point", "7-point"])
+def test_uniform_coefficients_give_the_same_bits(gpu_ctx, solver_name, flag, extent, pieces):
+    """Option sliced.uniform = 1 on a constant-coefficient stencil, two systems: the products take the
+    coefficients as scalars and read no value array, and every scalar of the history and both solutions
+    are bit for bit those of the default."""
+    import ctypes
+    from legionsolvers_amd import _lib
+    rects, row, col, val, n = hc.stencil_problem(flag, extent, np.float64)
+    rhs = np.random.default_rng(5).standard_normal(n)
+    outcomes = []
+    try:
+        for uniform in (1, 0):
+            _lib.call("lsk_set_option", b"sliced.uniform", uniform)
+            pl = hc.mirror_planner(gpu_ctx, "csr", rects, row, col, val, n, pieces, np.float64, rhs, spaces=2)
+            pl.get_vector(1, 1).owned.mul_(-0.5)
+            matrix = pl.row_partitioned_matrices[0].matrix
+            assert matrix.sliced and all(s.uniform_values for s in matrix.sliced.values())
+            solver = {"cg": CGSolver, "bicgstab": BiCGStabSolver}[solver_name](pl) if solver_name != "gmres" \
+                else GMRESSolver(pl, 4)
+            for _ in range(5):
+                solver.step()
+            history = {"cg": lambda: solver.residual_norm_squared, "bicgstab": lambda: solver.rho,
+                       "gmres": lambda: [h for col_ in solver.inner_products for h in col_]}[solver_name]()
+            outcomes.append(([s.get_value() for s in history], pl.get_vector(0, 0).to_host().clone(),
+                             pl.get_vector(0, 1).to_host().clone()))
+    finally:
+        _lib.call("lsk_set_option", b"sliced.uniform", 0)
+    (h1, a1, b1), (h0, a0, b0) = outcomes
+    assert h1 == h0 and torch.equal(a1, a0) and torch.equal(b1, b0)
+
+
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("shuffled", [False, True])
 def test_binned_coo_follows_the_oracle(gpu_ctx, monkeypatch, dtype, shuffled):

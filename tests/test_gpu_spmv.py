@@ -680,7 +680,7 @@ def sliced_padding_too_costly(suf, rects, nnz):
     return padded * esz > nnz * (esz + 3)
 
 
-def sliced_case(suf, rects, k_base, col, val, x, x_lo, x_hi, row_first, tag, expect=True):
+def sliced_case(suf, rects, k_base, col, val, x, x_lo, x_hi, row_first, tag, expect=True, uniform=None):
     """lsk_csr_sliced_create_* + lsk_csr_sliced_spmv_* on a piece: bit-exact against the oracle's
     ascending-k loop (separate multiply and add), for beta = 0 and 1 and for a range of rows."""
     npdt, tdt, _ = DT[suf]
@@ -703,6 +703,10 @@ def sliced_case(suf, rects, k_base, col, val, x, x_lo, x_hi, row_first, tag, exp
     br = BLOCK_ROWS[suf]
     padded = sum(br * int(lens[s:s + br].max()) for s in range(0, rows, br))
     assert info[0] == padded and info[1] == -(-rows // br) and info[5] == br, f"{tag}: info {list(info)}"
+    if uniform is not None:
+        # (only structures whose blocks all run on one staged list are judged: info[7] says so)
+        assert _lib.lib().lsk_csr_sliced_uniform_values(handle) == (uniform if info[7] else 0), f"{tag}: uniform values"
+        print(f"     uniform values: {_lib.lib().lsk_csr_sliced_uniform_values(handle)} (blocks without one list: {info[2]})", flush=True)
     try:
         rng = np.random.default_rng(rows)
         y0 = rng.standard_normal(rows).astype(npdt)
@@ -836,7 +840,7 @@ def test_csr_sliced_patterns_bit_exact(suf, sliced_forms):
         if n < 64:  # one block, padded from 343 entries to a block of 27-entry rows: not worth it
             sliced_case(suf, rects, 0, col, val, x, 0, n - 1, 0, f"stencil{flag}{extent}", expect=False)
             continue
-        info = sliced_case(suf, rects, 0, col, val, x, 0, n - 1, 0, f"stencil{flag}{extent}")
+        info = sliced_case(suf, rects, 0, col, val, x, 0, n - 1, 0, f"stencil{flag}{extent}", uniform=0)
         assert info[3] <= 27
         # every list that serves a block of the 27-point (and of the 1-D 3-point) matrix is runs of three
         # (a row at a line's end has a shorter list of its own, but its block runs on the line's list with
@@ -852,6 +856,59 @@ def test_csr_sliced_patterns_bit_exact(suf, sliced_forms):
         if x_hi > x_lo + 1:
             sliced_case(suf, rects[a:b], k_lo, pc, pv, x[x_lo + 1:x_hi + 1], x_lo + 1, x_hi, a,
                         f"stencil{flag}{extent} short window", expect=False)
+
+
+@pytest.mark.parametrize("suf", ["f64", "f32"])
+def test_csr_sliced_uniform_values(suf):
+    """Constant-coefficient stencils (every matrix of the reference's benchmark): each list position has
+    one value, the structure says so, and with option sliced.uniform = 1 every form of the product -- one
+    vector, ranges of rows, accumulating, with dot shares, two vectors -- runs without the value array and
+    still gives the oracle's bits.  Values rewritten in place are judged anew."""
+    npdt, tdt, _ = DT[suf]
+    lib = _lib.lib()
+    rng = np.random.default_rng(23)
+    _lib.call("lsk_set_option", b"sliced.uniform", 1)
+    try:
+        for flag, extent in ((1, (1000,)), (2, (37, 41)), (3, (9, 11, 13)), (4, (7, 12, 70)), (4, (3, 4, 512))):
+            offs, cfs = oracle.benchmark_stencil_offsets(flag)
+            rects, _, col, val = oracle.linearized_stencil(extent, offs, cfs, dtype=npdt, coo=True)
+            n = int(np.prod(extent))
+            x = rng.standard_normal(n).astype(npdt)
+            sliced_case(suf, rects, 0, col, val, x, 0, n - 1, 0, f"stencil{flag}{extent} its own coefficients", uniform=1)
+            a, b = n // 3, n - n // 4
+            k_lo, k_hi = int(rects[a, 0]), int(rects[b - 1, 1])
+            pc, pv = col[k_lo:k_hi + 1], val[k_lo:k_hi + 1]
+            x_lo, x_hi = int(pc.min()), int(pc.max())
+            sliced_case(suf, rects[a:b], k_lo, pc, pv, x[x_lo:x_hi + 1], x_lo, x_hi, a,
+                        f"stencil{flag}{extent} piece, its own coefficients", uniform=1)
+        # values rewritten in place: one entry off -> not uniform (the product reads the array again);
+        # put back -> uniform again; each time the oracle's bits
+        offs, cfs = oracle.benchmark_stencil_offsets(4)
+        rects, _, col, val = oracle.linearized_stencil((7, 12, 70), offs, cfs, dtype=npdt, coo=True)
+        rows = rects.shape[0]
+        x = rng.standard_normal(rows).astype(npdt)
+        rd, cd, vd, xd = dev(rects), dev(col), dev(val), dev(x)
+        handle = ctypes.c_void_p(0)
+        _lib.call(f"lsk_csr_sliced_create_{suf}", rows, val.size, P(rd), 0, P(cd), P(vd), 0, 0, rows - 1, stream(),
+                  ctypes.byref(handle))
+        try:
+            assert lib.lsk_csr_sliced_uniform_values(handle) == 1
+            for k, expect in ((val.size // 2, 0), (None, 1), (0, 0), (val.size - 1, 0), (None, 1)):
+                now = val.copy()
+                if k is not None:
+                    now[k] = np.nextafter(now[k], npdt(10))   # one bit off
+                vd.copy_(torch.from_numpy(now))
+                _lib.call(f"lsk_csr_sliced_update_values_{suf}", handle, rows, val.size, P(rd), 0, P(vd), stream())
+                assert lib.lsk_csr_sliced_uniform_values(handle) == expect, f"entry {k} changed"
+                want = np.zeros(rows, dtype=npdt)
+                oracle.csr_matvec(rects, 0, col, now, x, 0, rows - 1, want, beta=0)
+                yd = torch.empty(rows, dtype=tdt, device="cuda")
+                _lib.call(f"lsk_csr_sliced_spmv_{suf}", handle, 0, rows, P(xd), P(yd), 0, stream())
+                assert np.array_equal(yd.cpu().numpy().view(np.uint8), want.view(np.uint8)), f"entry {k} changed: product"
+        finally:
+            _lib.call("lsk_csr_sliced_destroy", handle)
+    finally:
+        _lib.call("lsk_set_option", b"sliced.uniform", 0)
 
 
 def test_csr_sliced_patterns_decline():

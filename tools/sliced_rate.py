@@ -78,6 +78,19 @@ def main():
                                                                                    shares, place), 20), 3)
         _lib.call("lsk_set_option", b"sliced.dma", 1)
         _lib.call("lsk_set_option", b"sliced.form", int(os.environ.get("LSK_SLICED_FORM", "1")))
+        # the values as scalars (constant-coefficient stencils): no value loads at all
+        out["uniform_values"] = s.uniform_values
+        if s.uniform_values:
+            _lib.call("lsk_set_option", b"sliced.uniform", 1)
+            for place1 in (0, 16, 64, 256):
+                out[f"uniform_place{place1}_ms"] = round(timed(ctx, lambda: be.csr_sliced_spmv(s, 0, matrix.rows, xs[0], ys[0], 0, place1), 20), 3)
+            out["uniform_dot_ms"] = round(timed(ctx, lambda: be.csr_sliced_spmv_dot(s, matrix.rows, xs[0], ys[0], 0, xs[1],
+                                                                                     shares, place), 20), 3)
+            for place2 in (0, 64):
+                out[f"uniform_pair_place{place2}_ms"] = round(timed(ctx, lambda: be.csr_sliced_spmv2(s, matrix.rows, xs, ys, 0, placement=place2), 10), 3)
+            out["uniform_bytes"] = s.algorithmic_bytes(matrix.rows, esz, without_values=True)
+            out["uniform_cg_ms_per_step"] = round(timed(ctx, solver.step, 30), 3)
+            _lib.call("lsk_set_option", b"sliced.uniform", 0)
         a = planner.get_vector(3, 0).owned.clone()
         held, matrix.sliced_window = matrix.sliced_window, None
         out["c32_ms"] = round(timed(ctx, lambda: planner.matvec(3, 2), 20), 3)
