@@ -629,7 +629,9 @@ int lsk_csr_sliced_info(const lsk_csr_sliced_t *m, int64_t *out);
  * as every matrix of test/BenchmarkStencil.cpp:35-124 is); 0 otherwise.  With option "sliced.uniform" = 1
  * (default 0) the products of such a structure take the values as scalars from a 64 x 32 table and do not
  * read the value array: rows * 2 s bytes per product instead of padded entries * s + rows * 2 s, same
- * multiplications and additions in the same order, same bits.  No counterpart in the reference. */
+ * multiplications and additions in the same order, same bits.  After update_values the check runs behind
+ * the refill on that stream and nobody waits for it: products launched before its verdict is in read the
+ * value array; this call does wait for it.  No counterpart in the reference. */
 int lsk_csr_sliced_uniform_values(const lsk_csr_sliced_t *m);
 int lsk_csr_sliced_destroy(lsk_csr_sliced_t *m);
 

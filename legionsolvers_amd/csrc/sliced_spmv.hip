@@ -93,7 +93,13 @@ struct lsk_csr_sliced {
     // run without reading the values at all (option sliced.uniform).
     void *uniform = nullptr;
     int *uniform_scratch = nullptr; // kMaxPatterns first-block slots + 1 mismatch flag
-    bool uniform_ok = false;
+    // The verdict after update_values arrives without anyone waiting for it: the check is enqueued behind
+    // the refill, its flag copied to pinned memory, and the products read the value array until the event
+    // behind that copy has passed.
+    int *uniform_host = nullptr;    // pinned: the mismatch flag as the last check left it
+    hipEvent_t uniform_event = nullptr;
+    mutable bool uniform_pending = false;
+    mutable bool uniform_ok = false;
 };
 
 namespace {
@@ -374,6 +380,10 @@ __global__ __launch_bounds__(kBlock) void sliced_fill_kernel(int64_t rows, int64
         const bool has = (mask >> j) & 1u;
         dst[int64_t(j) * kWaveRows] = has ? val[lo + __popc(mask & ((1u << j) - 1u))] : T(0);
     }
+}
+
+__global__ void sliced_uniform_init_kernel(int *scratch) {
+    scratch[threadIdx.x] = threadIdx.x < kMaxPatterns ? INT_MAX : 0;
 }
 
 // Uniform values, step 1: the first block (lowest index) that runs on each list.
@@ -1297,7 +1307,7 @@ void plan_wave_staging(PatternInfo &p, int wave_rows) {
 }
 
 template <typename T>
-int uniform_refresh(lsk_csr_sliced *m, hipStream_t s);
+int uniform_refresh(lsk_csr_sliced *m, hipStream_t s, bool wait);
 
 template <typename T>
 int create(const char *name, int64_t rows, int64_t nnz, const int64_t *rects, int64_t k_base, const int64_t *col,
@@ -1460,7 +1470,7 @@ int create(const char *name, int64_t rows, int64_t nnz, const int64_t *rects, in
                 LSK_TRY(hipGetLastError());
                 LSK_TRY(hipStreamSynchronize(s));
             }
-            if (status == LSK_OK) status = uniform_refresh<T>(m, s);
+            if (status == LSK_OK) status = uniform_refresh<T>(m, s, /*wait=*/true);
         }
     }
 #undef LSK_TRY
@@ -1481,21 +1491,25 @@ int create(const char *name, int64_t rows, int64_t nnz, const int64_t *rects, in
 inline bool wave_form_serves(const lsk_csr_sliced *m);
 
 // Finds out whether the copy's values are uniform per list position (see lsk_csr_sliced::uniform) and
-// leaves the lists' values in m->uniform.  Synchronises the stream.
+// leaves the lists' values in m->uniform.  wait: the verdict is in m->uniform_ok on return (set-up time);
+// else everything is enqueued on the stream and the verdict is picked up later (uniform_verdict).
 template <typename T>
-int uniform_refresh(lsk_csr_sliced *m, hipStream_t s) {
+int uniform_refresh(lsk_csr_sliced *m, hipStream_t s, bool wait) {
     m->uniform_ok = false;
+    m->uniform_pending = false;
     if (!wave_form_serves(m) || m->blocks <= 0 || m->blocks > INT_MAX) return LSK_OK;
-    if (!m->uniform) LSK_HIP(hipMalloc(&m->uniform, sizeof(T) * kMaxPatterns * kMaxLength));
-    if (!m->uniform_scratch) LSK_HIP(hipMalloc(reinterpret_cast<void **>(&m->uniform_scratch), sizeof(int) * (kMaxPatterns + 1)));
-    int init[kMaxPatterns + 1];
-    for (int i = 0; i < kMaxPatterns; ++i) init[i] = INT_MAX;
-    init[kMaxPatterns] = 0;
-    LSK_HIP(hipMemcpyAsync(m->uniform_scratch, init, sizeof(init), hipMemcpyHostToDevice, s));
-    LSK_HIP(hipStreamSynchronize(s)); // (init is on this stack)
+    if (wait && !m->uniform) { // (the resources are made at set-up time only: update_values allocates nothing)
+        LSK_HIP(hipMalloc(&m->uniform, sizeof(T) * kMaxPatterns * kMaxLength));
+        LSK_HIP(hipMalloc(reinterpret_cast<void **>(&m->uniform_scratch), sizeof(int) * (kMaxPatterns + 1)));
+        LSK_HIP(hipHostMalloc(reinterpret_cast<void **>(&m->uniform_host), sizeof(int)));
+        LSK_HIP(hipEventCreateWithFlags(&m->uniform_event, hipEventDisableTiming));
+    }
+    if (!m->uniform || !m->uniform_scratch || !m->uniform_host || !m->uniform_event) return LSK_OK;
     const BlockMeta *meta = static_cast<const BlockMeta *>(m->meta);
     const T *val = static_cast<const T *>(m->val);
     T *uniform = static_cast<T *>(m->uniform);
+    sliced_uniform_init_kernel<<<1, kMaxPatterns + 1, 0, s>>>(m->uniform_scratch);
+    LSK_LAUNCH_CHECK();
     sliced_uniform_first_kernel<<<static_cast<unsigned>(lsk::ceil_div(m->blocks, kBlock)), kBlock, 0, s>>>(m->blocks, meta,
                                                                                                          m->uniform_scratch);
     LSK_LAUNCH_CHECK();
@@ -1504,11 +1518,32 @@ int uniform_refresh(lsk_csr_sliced *m, hipStream_t s) {
     sliced_uniform_check_kernel<T><<<static_cast<unsigned>(m->blocks), kBlock, 0, s>>>(m->rows, meta, m->row_mask, val, uniform,
                                                                                       m->uniform_scratch + kMaxPatterns);
     LSK_LAUNCH_CHECK();
-    int mismatch = 1;
-    LSK_HIP(hipMemcpyAsync(&mismatch, m->uniform_scratch + kMaxPatterns, sizeof(int), hipMemcpyDeviceToHost, s));
-    LSK_HIP(hipStreamSynchronize(s));
-    m->uniform_ok = mismatch == 0;
+    LSK_HIP(hipMemcpyAsync(m->uniform_host, m->uniform_scratch + kMaxPatterns, sizeof(int), hipMemcpyDeviceToHost, s));
+    LSK_HIP(hipEventRecord(m->uniform_event, s));
+    m->uniform_pending = true;
+    if (wait) {
+        LSK_HIP(hipEventSynchronize(m->uniform_event));
+        m->uniform_ok = *m->uniform_host == 0;
+        m->uniform_pending = false;
+    }
     return LSK_OK;
+}
+
+// Whether the structure's values are known to be uniform per list position.  While a check is still on
+// its way (after update_values) the answer is no -- the product that reads the values is always right --
+// unless the caller is willing to wait for it.
+inline bool uniform_verdict(const lsk_csr_sliced *m, bool wait) {
+    if (m->uniform_pending) {
+        const hipError_t e = wait ? hipEventSynchronize(m->uniform_event) : hipEventQuery(m->uniform_event);
+        if (e == hipSuccess) {
+            m->uniform_ok = *m->uniform_host == 0;
+            m->uniform_pending = false;
+        } else if (e != hipErrorNotReady) {
+            (void)hipGetLastError();
+            m->uniform_pending = false; // (an error: stay with the value array)
+        }
+    }
+    return !m->uniform_pending && m->uniform_ok;
 }
 
 // The values again, from the caller's array into the blocks (the last set-up pass alone): for a caller
@@ -1529,8 +1564,9 @@ int update_values(const char *name, lsk_csr_sliced *m, int64_t rows, int64_t nnz
         rows, padded_rows, reinterpret_cast<const long long *>(rects), k_base, val, static_cast<const BlockMeta *>(m->meta),
         m->row_mask, static_cast<T *>(m->val));
     LSK_LAUNCH_CHECK();
-    // (whether the new values are uniform per list position has to be found out again: waits for the stream)
-    return uniform_refresh<T>(m, lsk::as_stream(stream));
+    // (whether the new values are uniform per list position is found out again, behind the refill on the
+    // same stream; nobody waits for it: until the verdict is in, the products read the value array)
+    return uniform_refresh<T>(m, lsk::as_stream(stream), /*wait=*/false);
 }
 
 // Whether the wave-staged kernel serves the structure: every block on one staged list, and the four
@@ -1575,7 +1611,7 @@ int launch_wave(const lsk_csr_sliced *m, int64_t block_begin, unsigned blocks, i
     } while (0)
     const bool run3 = m->runs_of_three && lsk::options().sliced_runs != 0;
     // the values as scalars, where every list position has one value and the caller asked for it
-    const bool uniform = m->uniform_ok && m->uniform && lsk::options().sliced_uniform != 0;
+    const bool uniform = lsk::options().sliced_uniform != 0 && m->uniform && uniform_verdict(m, /*wait=*/false);
     if (LSK_UNIFORM_DIRECT && uniform && dma && run3 && m->max_len > 20 && m->max_len <= 27) lds = 0; // (DIRECT in the kernel)
     if (m->max_len <= 8) LSK_WAVE_CAP(8, false);
     else if (m->max_len <= 16) LSK_WAVE_CAP(16, false);
@@ -1880,7 +1916,7 @@ int lsk_csr_sliced_info(const lsk_csr_sliced_t *m, int64_t *out) {
     return LSK_OK;
 }
 
-int lsk_csr_sliced_uniform_values(const lsk_csr_sliced_t *m) { return m && m->uniform_ok ? 1 : 0; }
+int lsk_csr_sliced_uniform_values(const lsk_csr_sliced_t *m) { return m && m->uniform && uniform_verdict(m, /*wait=*/true) ? 1 : 0; }
 
 int lsk_csr_sliced_destroy(lsk_csr_sliced_t *m) {
     if (!m) return LSK_OK;
@@ -1891,6 +1927,8 @@ int lsk_csr_sliced_destroy(lsk_csr_sliced_t *m) {
     (void)hipFree(m->table);
     (void)hipFree(m->uniform);
     (void)hipFree(m->uniform_scratch);
+    if (m->uniform_host) (void)hipHostFree(m->uniform_host);
+    if (m->uniform_event) (void)hipEventDestroy(m->uniform_event);
     delete m;
     return LSK_OK;
 }
