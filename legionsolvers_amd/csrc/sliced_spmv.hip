@@ -321,6 +321,39 @@ __global__ __launch_bounds__(kBlock) void sliced_masks_kernel(int64_t rows, int 
     atomicOr(&blk_flags[b], 1 << (kBlkWaveShift + wave));
 }
 
+// Pass 5b: a block whose rows fit no ordered part of its longest row's list (the last line of one grid
+// plane and the first of the next: two lists of equal length, neither part of the other) looks for
+// another list of the table that all of them are ordered parts of -- the interior row's, for a stencil --
+// and, if there is one, runs on the shortest such list like any other masked block.  supersets[p]: the
+// lists that list p is an ordered part of (bit c), from the host.  The masks pass runs again afterwards.
+__global__ __launch_bounds__(kBlock) void sliced_rescue_kernel(int64_t rows, int block_rows,
+                                                               const unsigned char *__restrict__ row_pattern,
+                                                               const PatternInfo *__restrict__ table,
+                                                               const unsigned long long *__restrict__ supersets,
+                                                               BlockMeta *__restrict__ meta, int *__restrict__ blk_flags) {
+    const int64_t b = blockIdx.x;
+    if (!(blk_flags[b] & kBlkMixed)) return;
+    __shared__ unsigned long long present;
+    if (threadIdx.x == 0) present = 0ull;
+    __syncthreads();
+    for (int i = threadIdx.x; i < block_rows; i += kBlock) {
+        const int64_t r = b * block_rows + i;
+        if (r < rows) atomicOr(&present, 1ull << row_pattern[r]);
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    unsigned long long candidates = ~0ull;
+    for (int p = 0; p < kMaxPatterns; ++p)
+        if ((present >> p) & 1ull) candidates &= supersets[p];
+    int best = -1;
+    for (int c = 0; c < kMaxPatterns; ++c)
+        if (((candidates >> c) & 1ull) && (best < 0 || table[c].len < table[best].len)) best = c;
+    if (best < 0) return; // stays a block without a common list
+    meta[b].pattern = best;
+    meta[b].maxlen = table[best].len;
+    blk_flags[b] = kBlkNeedsMasks;
+}
+
 // Pass 6: the blocks' final records and sizes.
 __global__ __launch_bounds__(kBlock) void sliced_finish_kernel(int64_t blocks, int64_t rows, int block_rows,
                                                                const int *__restrict__ blk_flags,
@@ -386,13 +419,25 @@ __global__ void sliced_uniform_init_kernel(int *scratch) {
     scratch[threadIdx.x] = threadIdx.x < kMaxPatterns ? INT_MAX : 0;
 }
 
-// Uniform values, step 1: the first block (lowest index) that runs on each list.
-__global__ __launch_bounds__(kBlock) void sliced_uniform_first_kernel(int64_t blocks, const BlockMeta *__restrict__ meta,
+// Uniform values, step 1: per list, the first block (lowest index) that runs on it and has a row with
+// the whole list (a block that only borrowed the list -- sliced_rescue_kernel -- has none).  One
+// workgroup per block.
+__global__ __launch_bounds__(kBlock) void sliced_uniform_first_kernel(int64_t rows, int rows_per_lane,
+                                                                      const BlockMeta *__restrict__ meta,
+                                                                      const unsigned *__restrict__ row_mask,
                                                                       int *__restrict__ first) {
-    const int64_t b = int64_t(blockIdx.x) * kBlock + threadIdx.x;
-    if (b >= blocks) return;
-    const int pattern = meta[b].pattern;
-    if (pattern >= 0 && meta[b].maxlen > 0) atomicMin(&first[pattern & 0xff], static_cast<int>(min(b, int64_t(INT_MAX))));
+    const int64_t b = blockIdx.x;
+    const BlockMeta m = meta[b];
+    if (m.pattern < 0 || m.maxlen <= 0) return;
+    const unsigned full = m.maxlen >= 32 ? 0xffffffffu : (1u << m.maxlen) - 1u;
+    const int wave = threadIdx.x / kWave;
+    const bool masked = (m.pattern & kBlockMasked) && ((m.pattern >> (kWaveMaskedShift + wave)) & 1);
+    bool has = false;
+    for (int h = 0; h < rows_per_lane; ++h) {
+        const int64_t r = (b * kBlock + threadIdx.x) * rows_per_lane + h;
+        has = has || (r < rows && (!masked || (row_mask[r] & full) == full));
+    }
+    if (__syncthreads_or(has) && threadIdx.x == 0) atomicMin(&first[m.pattern & 0xff], static_cast<int>(min(b, int64_t(INT_MAX))));
 }
 
 // Step 2: one workgroup per list: the values of the first row of that block which has the whole list
@@ -400,7 +445,7 @@ __global__ __launch_bounds__(kBlock) void sliced_uniform_first_kernel(int64_t bl
 template <typename T>
 __global__ __launch_bounds__(kBlock) void sliced_uniform_pick_kernel(int64_t rows, const BlockMeta *__restrict__ meta,
                                                                      const unsigned *__restrict__ row_mask,
-                                                                     const T *__restrict__ val, const int *__restrict__ first,
+                                                                     const T *__restrict__ val, int *__restrict__ first,
                                                                      T *__restrict__ uniform) {
     constexpr int R = Lane<T>::R;
     constexpr int kBlockRows = kBlock * R, kWaveRows = kWave * R;
@@ -421,7 +466,10 @@ __global__ __launch_bounds__(kBlock) void sliced_uniform_pick_kernel(int64_t row
     }
     __syncthreads();
     const int in = chosen;
-    if (in == INT_MAX) return; // (cannot happen: the list is that of one of the block's rows)
+    if (in == INT_MAX) { // (the unmasked wave's rows lie past the end of the piece: no candidate, no verdict)
+        if (threadIdx.x == 0) first[list] = INT_MAX;
+        return;
+    }
     const T *src = val + m.base + int64_t(in / kWaveRows) * m.maxlen * kWaveRows + in % kWaveRows;
     for (int j = threadIdx.x; j < kMaxLength; j += kBlock)
         uniform[list * kMaxLength + j] = j < m.maxlen ? src[int64_t(j) * kWaveRows] : T(0);
@@ -432,15 +480,17 @@ template <typename T>
 __global__ __launch_bounds__(kBlock) void sliced_uniform_check_kernel(int64_t rows, const BlockMeta *__restrict__ meta,
                                                                       const unsigned *__restrict__ row_mask,
                                                                       const T *__restrict__ val, const T *__restrict__ uniform,
-                                                                      int *__restrict__ mismatch) {
+                                                                      const int *__restrict__ first, int *__restrict__ mismatch) {
     constexpr int R = Lane<T>::R;
     using V = typename Lane<T>::V;
     using Bits = std::conditional_t<sizeof(T) == 8, unsigned long long, unsigned>;
     constexpr int kBlockRows = kBlock * R, kWaveRows = kWave * R;
     const int64_t b = blockIdx.x;
     const BlockMeta m = meta[b];
-    if (m.pattern < 0) {
-        if (threadIdx.x == 0) *mismatch = 1; // a block without a common list: not this form's business
+    if (m.pattern < 0 || (m.maxlen > 0 && first[m.pattern & 0xff] == INT_MAX)) {
+        // a block without a common list, or on a list that no row of the piece has as a whole (no
+        // candidate values): not this form's business
+        if (threadIdx.x == 0) *mismatch = 1;
         return;
     }
     const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
@@ -1340,6 +1390,7 @@ int create(const char *name, int64_t rows, int64_t nnz, const int64_t *rects, in
     long long *rep = nullptr, *entries = nullptr, *inclusive = nullptr, *counts = nullptr;
     std::vector<PatternInfo> infos; // the lists, host side
     int *flags = nullptr, *lists = nullptr, *g_maxlen = nullptr, *g_holder = nullptr, *g_uniform = nullptr, *blk_flags = nullptr;
+    unsigned long long *supersets = nullptr;
     void *temp = nullptr;
     int status = LSK_OK;
     int host_flags[kFlags] = {0};
@@ -1347,7 +1398,7 @@ int create(const char *name, int64_t rows, int64_t nnz, const int64_t *rects, in
         for (void *p : {static_cast<void *>(keys), static_cast<void *>(rep), static_cast<void *>(entries),
                         static_cast<void *>(inclusive), static_cast<void *>(counts), static_cast<void *>(flags),
                         static_cast<void *>(lists), static_cast<void *>(g_maxlen), static_cast<void *>(g_holder),
-                        static_cast<void *>(g_uniform), static_cast<void *>(blk_flags), temp})
+                        static_cast<void *>(g_uniform), static_cast<void *>(blk_flags), static_cast<void *>(supersets), temp})
             (void)hipFree(p);
     };
 #define LSK_TRY(expr)                                                                               \
@@ -1360,6 +1411,7 @@ int create(const char *name, int64_t rows, int64_t nnz, const int64_t *rects, in
     LSK_ALLOC(rep, kMaxPatterns);
     LSK_ALLOC(flags, kFlags);
     LSK_ALLOC(counts, 4);
+    LSK_ALLOC(supersets, kMaxPatterns);
     LSK_ALLOC(lists, kMaxPatterns * (kMaxLength + 1));
     LSK_ALLOC(entries, blocks);
     LSK_ALLOC(inclusive, blocks);
@@ -1414,7 +1466,25 @@ int create(const char *name, int64_t rows, int64_t nnz, const int64_t *rects, in
                 }
             }
             LSK_TRY(hipMemcpyAsync(m->table, infos.data(), kMaxPatterns * sizeof(PatternInfo), hipMemcpyHostToDevice, s));
-            LSK_TRY(hipStreamSynchronize(s)); // (infos leaves scope)
+            // which staged lists every list is an ordered part of (itself included): what a block whose
+            // rows do not fit its longest row's list may run on instead (sliced_rescue_kernel)
+            unsigned long long host_supersets[kMaxPatterns];
+            for (int p = 0; p < kMaxPatterns; ++p) {
+                host_supersets[p] = 0ull;
+                if (infos[p].len < 0) continue;
+                for (int c = 0; c < kMaxPatterns; ++c) {
+                    if (infos[c].len < infos[p].len || infos[c].nruns <= 0) continue;
+                    int pos = 0;
+                    bool fits = true;
+                    for (int j = 0; fits && j < infos[p].len; ++j) {
+                        while (pos < infos[c].len && infos[c].dist[pos] != infos[p].dist[j]) ++pos;
+                        fits = pos++ < infos[c].len;
+                    }
+                    if (fits) host_supersets[p] |= 1ull << c;
+                }
+            }
+            LSK_TRY(hipMemcpyAsync(supersets, host_supersets, sizeof(host_supersets), hipMemcpyHostToDevice, s));
+            LSK_TRY(hipStreamSynchronize(s)); // (infos and host_supersets leave scope)
         }
     }
     if (status == LSK_OK && !declined) {
@@ -1429,6 +1499,11 @@ int create(const char *name, int64_t rows, int64_t nnz, const int64_t *rects, in
         BlockMeta *meta = static_cast<BlockMeta *>(m->meta);
         sliced_combine_kernel<<<block_grid, kBlock, 0, s>>>(blocks, groups, kBlockRows / kWave, g_maxlen, g_holder, g_uniform,
                                                             meta, blk_flags);
+        LSK_TRY(hipGetLastError());
+        sliced_masks_kernel<<<row_grid, kBlock, 0, s>>>(rows, kBlockRows, m->row_pattern, m->table, meta, blk_flags, m->row_mask);
+        LSK_TRY(hipGetLastError());
+        sliced_rescue_kernel<<<static_cast<unsigned>(blocks), kBlock, 0, s>>>(rows, kBlockRows, m->row_pattern, m->table, supersets,
+                                                                             meta, blk_flags);
         LSK_TRY(hipGetLastError());
         sliced_masks_kernel<<<row_grid, kBlock, 0, s>>>(rows, kBlockRows, m->row_pattern, m->table, meta, blk_flags, m->row_mask);
         LSK_TRY(hipGetLastError());
@@ -1510,12 +1585,13 @@ int uniform_refresh(lsk_csr_sliced *m, hipStream_t s, bool wait) {
     T *uniform = static_cast<T *>(m->uniform);
     sliced_uniform_init_kernel<<<1, kMaxPatterns + 1, 0, s>>>(m->uniform_scratch);
     LSK_LAUNCH_CHECK();
-    sliced_uniform_first_kernel<<<static_cast<unsigned>(lsk::ceil_div(m->blocks, kBlock)), kBlock, 0, s>>>(m->blocks, meta,
-                                                                                                         m->uniform_scratch);
+    sliced_uniform_first_kernel<<<static_cast<unsigned>(m->blocks), kBlock, 0, s>>>(m->rows, Lane<T>::R, meta, m->row_mask,
+                                                                                   m->uniform_scratch);
     LSK_LAUNCH_CHECK();
     sliced_uniform_pick_kernel<T><<<kMaxPatterns, kBlock, 0, s>>>(m->rows, meta, m->row_mask, val, m->uniform_scratch, uniform);
     LSK_LAUNCH_CHECK();
     sliced_uniform_check_kernel<T><<<static_cast<unsigned>(m->blocks), kBlock, 0, s>>>(m->rows, meta, m->row_mask, val, uniform,
+                                                                                      m->uniform_scratch,
                                                                                       m->uniform_scratch + kMaxPatterns);
     LSK_LAUNCH_CHECK();
     LSK_HIP(hipMemcpyAsync(m->uniform_host, m->uniform_scratch + kMaxPatterns, sizeof(int), hipMemcpyDeviceToHost, s));
