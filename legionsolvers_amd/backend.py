@@ -8,6 +8,7 @@ and the built library: there is no CPU fallback in the product path.
 from __future__ import annotations
 
 import ctypes
+import os
 import threading
 from typing import Optional, Sequence, Tuple
 
@@ -35,6 +36,10 @@ class HipBackend:
         self.device = torch.device("cuda", index)
         torch.cuda.set_device(index)
         _lib.check(self.lib.lsk_init(index))
+        # LSK_UNIFORM=1: the library's option "sliced.uniform" (a constant-coefficient stencil's values as
+        # scalars; off by default) for programs that cannot set it themselves
+        if os.environ.get("LSK_UNIFORM") in ("0", "1"):
+            _lib.call("lsk_set_option", b"sliced.uniform", int(os.environ["LSK_UNIFORM"]))
         # Partial sums of dot/nrm2: private to this backend so that other users of the
         # library's per-device scratch cannot race with it.
         self._ws_bytes = int(self.lib.lsk_dot_workspace_bytes(0))
