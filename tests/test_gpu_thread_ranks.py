@@ -123,7 +123,8 @@ def test_two_systems_share_a_pass_across_ranks(monkeypatch, world, pieces, n1):
         return {"history": [s.get_value() for s in solver.residual_norm_squared],
                 "sols": [planner.get_vector(0, s).to_host().numpy().copy() for s in range(2)],
                 "paired": planner._paired_products, "phases": sorted({run[0] for runs in (entry.split or {}).values() for run in runs}),
-                "fused_used": planner._fused_dot_used}
+                "fused_used": planner._fused_dot_used,
+                "uniform": bool(matrix.sliced) and all(s.uniform_values for s in matrix.sliced.values())}
 
     print(f"case thread ranks two systems world={world} pieces={pieces} {n1}^3 paired", flush=True)
     paired = run_ranks(world, body)
@@ -138,3 +139,17 @@ def test_two_systems_share_a_pass_across_ranks(monkeypatch, world, pieces, n1):
         for s in range(2):
             assert np.array_equal(a["sols"][s], b["sols"][s]), f"rank {r}: solution {s} differs"
         assert all(np.isfinite(a["history"]))
+    # ... and with the stencil's coefficients taken as scalars (option sliced.uniform): the same bits again
+    from legionsolvers_amd import _lib
+    monkeypatch.delenv("LSK_PAIR")
+    _lib.call("lsk_set_option", b"sliced.uniform", 1)
+    try:
+        print(f"case thread ranks two systems world={world} pieces={pieces} {n1}^3 paired, scalar coefficients", flush=True)
+        scalar = run_ranks(world, body)
+    finally:
+        _lib.call("lsk_set_option", b"sliced.uniform", 0)
+    for r, (a, c) in enumerate(zip(paired, scalar)):
+        assert c["uniform"], f"rank {r}: the pieces' values should be uniform per list position"
+        assert a["history"] == c["history"], f"rank {r}: scalars differ with scalar coefficients"
+        for s in range(2):
+            assert np.array_equal(a["sols"][s], c["sols"][s]), f"rank {r}: solution {s} differs with scalar coefficients"
