@@ -153,15 +153,18 @@ def test_spmv_random_structures(gpu_ctx, suf, kind):
             _lib.call("lsk_set_option", b"coo.variant", 1)
 
 
+@pytest.mark.parametrize("values", ["random", "by-distance"])
 @pytest.mark.parametrize("seed", range(8))
 @pytest.mark.parametrize("suf", ["f64", "f32"])
-def test_sliced_pattern_products_fuzz(seed, suf):
+def test_sliced_pattern_products_fuzz(seed, suf, values):
     """Random matrices made of a few row patterns (lists of column distances with repeats, in any
     order, some of them ordered parts of others, some unrelated, some empty), laid out in runs of
     random length so that blocks come out uniform, masked and mixed: the sliced-pattern product equals
     the oracle's ascending-k loop bit for bit, whole and by ranges of rows.  Odd seeds draw lists made
     of a few runs of consecutive distances (served through the LDS staging area), even seeds arbitrary
-    ones (mostly too many runs for it: x straight from memory)."""
+    ones (mostly too many runs for it: x straight from memory).  values = "by-distance": an entry's value
+    depends on its distance alone, so that every position of every list has one value, and option
+    sliced.uniform is on: where the structure qualifies the product takes the values as scalars."""
     npdt, tdt, _ = DT[suf]
     rng = np.random.default_rng(1000 + seed)
     rows = int(rng.integers(65, 6000))
@@ -195,13 +198,19 @@ def test_sliced_pattern_products_fuzz(seed, suf):
     if nnz == 0:
         pytest.skip("drew an empty matrix")
     val = rng.standard_normal(nnz).astype(npdt)
+    if values == "by-distance":
+        of_distance = rng.standard_normal(81).astype(npdt)
+        val = of_distance[col - (row_first + np.repeat(np.arange(rows), lens)) + 40]
     x_lo, x_hi = int(col.min()), int(col.max())
     x = rng.standard_normal(x_hi - x_lo + 1).astype(npdt)
     print(f"case sliced fuzz seed={seed} {suf} rows={rows} nnz={nnz} patterns={len(patterns)} run={run}", flush=True)
     rd, cd, vd, xd = dev(rects), dev(col), dev(val), dev(x)
     handle = ctypes.c_void_p(0)
+    _lib.call("lsk_set_option", b"sliced.uniform", 1 if values == "by-distance" else 0)
     code = getattr(_lib.lib(), f"lsk_csr_sliced_create_{suf}")(rows, nnz, P(rd), k_base, P(cd), P(vd), row_first, x_lo,
                                                              x_hi, stream(), ctypes.byref(handle))
+    if code != _lib.LSK_OK:
+        _lib.call("lsk_set_option", b"sliced.uniform", 0)
     if code == _lib.LSK_ERR_UNSUPPORTED:   # too much padding for this draw: a legitimate answer
         br = 512 if suf == "f64" else 1024
         padded = sum(int(lens[s:s + br].size) * int(lens[s:s + br].max()) for s in range(0, rows, br))
@@ -213,7 +222,7 @@ def test_sliced_pattern_products_fuzz(seed, suf):
         _lib.call("lsk_csr_sliced_info", handle, info)
         assert info[3] <= len(patterns) and info[2] <= info[1] and info[4] <= 4 * (info[1] - info[2])
         print(f"  blocks {info[1]}: {info[2]} mixed, {info[4]} masked waves; {info[3]} patterns, "
-              f"{info[6]} bytes of LDS", flush=True)
+              f"{info[6]} bytes of LDS; uniform values {_lib.lib().lsk_csr_sliced_uniform_values(handle)}", flush=True)
         y0 = rng.standard_normal(rows).astype(npdt)
         for beta, (ra, rb) in ((0, (0, rows)), (1, (0, rows)), (1, (rows // 4, rows - rows // 3)), (0, (63, 130)),
                                (0, (509, 1030)), (1, (1023, 1025))):
@@ -229,4 +238,5 @@ def test_sliced_pattern_products_fuzz(seed, suf):
             assert np.array_equal(got.view(np.uint8), want.view(np.uint8)), \
                 f"seed {seed}: beta={beta} rows {ra}..{rb}: {int((got != want).sum())} rows differ (info {list(info)})"
     finally:
+        _lib.call("lsk_set_option", b"sliced.uniform", 0)
         _lib.call("lsk_csr_sliced_destroy", handle)
