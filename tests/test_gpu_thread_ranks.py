@@ -139,6 +139,16 @@ def test_two_systems_share_a_pass_across_ranks(monkeypatch, world, pieces, n1):
         for s in range(2):
             assert np.array_equal(a["sols"][s], b["sols"][s]), f"rank {r}: solution {s} differs"
         assert all(np.isfinite(a["history"]))
+    # ... with the products waiting for their halos (no interior / edge split): the pair in one launch per piece
+    monkeypatch.delenv("LSK_PAIR")
+    monkeypatch.setenv("LSK_OVERLAP", "0")
+    print(f"case thread ranks two systems world={world} pieces={pieces} {n1}^3 paired, no overlap", flush=True)
+    waited = run_ranks(world, body)
+    monkeypatch.delenv("LSK_OVERLAP")
+    for r, (a, c) in enumerate(zip(paired, waited)):
+        assert c["paired"] >= steps and c["phases"] == [], f"rank {r}: {c['paired']} paired products, phases {c['phases']}"
+        assert a["history"] == c["history"] and all(np.array_equal(a["sols"][s], c["sols"][s]) for s in range(2)), f"rank {r}"
+    monkeypatch.setenv("LSK_PAIR", "0")
     # ... and with the stencil's coefficients taken as scalars (option sliced.uniform): the same bits again
     from legionsolvers_amd import _lib
     monkeypatch.delenv("LSK_PAIR")
