@@ -288,7 +288,6 @@ def main():
     # bit at set-up, and the product then reads no value array at all.  Not the default: reported beside it.
     uniform = None
     if sliced and all(p.uniform_values for p in matrix.sliced.values()):
-        import ctypes
         from legionsolvers_amd import _lib
         _lib.call("lsk_set_option", b"sliced.uniform", 1)
         try:
