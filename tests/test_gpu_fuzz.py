@@ -154,7 +154,7 @@ def test_spmv_random_structures(gpu_ctx, suf, kind):
 
 
 @pytest.mark.parametrize("values", ["random", "by-distance"])
-@pytest.mark.parametrize("seed", range(8))
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("LSK_FUZZ_SEEDS", "8"))))
 @pytest.mark.parametrize("suf", ["f64", "f32"])
 def test_sliced_pattern_products_fuzz(seed, suf, values):
     """Random matrices made of a few row patterns (lists of column distances with repeats, in any
@@ -179,7 +179,7 @@ def test_sliced_pattern_products_fuzz(seed, suf, values):
     for _ in range(n_patterns - 1):
         kind = rng.integers(0, 8)
         if kind < 4:       # ... ordered parts of it, a few entries short (masked slices)
-            keep = np.sort(rng.choice(base.size, size=base.size - int(rng.integers(1, 4)), replace=False))
+            keep = np.sort(rng.choice(base.size, size=max(base.size - int(rng.integers(1, 4)), 0), replace=False))
             patterns.append(base[keep])
         elif kind < 7:     # ... unrelated lists of about the same length (mixed slices)
             patterns.append(rng.integers(-40, 41, size=max(base.size - int(rng.integers(0, 3)), 1)))
@@ -237,6 +237,26 @@ def test_sliced_pattern_products_fuzz(seed, suf, values):
             got = yd.cpu().numpy()
             assert np.array_equal(got.view(np.uint8), want.view(np.uint8)), \
                 f"seed {seed}: beta={beta} rows {ra}..{rb}: {int((got != want).sum())} rows differ (info {list(info)})"
+        # the other kernel forms on the whole piece: block-staged, wave-staged through registers, and (where
+        # every block runs on one staged list) two right-hand sides in one pass
+        want = np.zeros(rows, dtype=npdt)
+        oracle.csr_matvec(rects, k_base, col, val, x, x_lo, x_hi, want, beta=0)
+        for form, dma in ((0, 1), (1, 0), (1, 1)):
+            _lib.call("lsk_set_option", b"sliced.form", form)
+            _lib.call("lsk_set_option", b"sliced.dma", dma)
+            yd = dev(y0)
+            _lib.call(f"lsk_csr_sliced_spmv_{suf}", handle, 0, rows, P(xd), P(yd), 0, stream())
+            assert np.array_equal(yd.cpu().numpy().view(np.uint8), want.view(np.uint8)), f"seed {seed}: form {form} dma {dma}"
+            if info[7]:
+                xb = rng.standard_normal(x.size).astype(npdt)
+                want_b = np.zeros(rows, dtype=npdt)
+                oracle.csr_matvec(rects, k_base, col, val, xb, x_lo, x_hi, want_b, beta=0)
+                ya, yb, xbd = dev(y0), dev(y0), dev(xb)
+                _lib.call(f"lsk_csr_sliced_spmv2_{suf}", handle, 0, rows, P(xd), P(xbd), P(ya), P(yb), 0, stream())
+                assert np.array_equal(ya.cpu().numpy().view(np.uint8), want.view(np.uint8)) and \
+                    np.array_equal(yb.cpu().numpy().view(np.uint8), want_b.view(np.uint8)), f"seed {seed}: pair, form {form} dma {dma}"
     finally:
+        _lib.call("lsk_set_option", b"sliced.form", 1)
+        _lib.call("lsk_set_option", b"sliced.dma", 1)
         _lib.call("lsk_set_option", b"sliced.uniform", 0)
         _lib.call("lsk_csr_sliced_destroy", handle)
