@@ -150,4 +150,14 @@ def test_two_systems_in_one_pass_print_the_same(solver):
         assert [l for l in paired if not l.startswith("paired_products")] == \
                [l for l in separate if not l.startswith("paired_products")]
         if vp == 1:
-            assert count(paired) > 0   # (a piece with a block of mixed rows makes the library decline the pair)
+            assert count(paired) > 0   # (a piece with a block that fits no common list makes the library decline the pair)
+
+
+@pytest.mark.parametrize("solver", [1, 2, 3])
+def test_scalar_coefficients_print_the_same(solver):
+    """-uniform 1 (the library's option sliced.uniform: a constant-coefficient stencil's values as scalars,
+    no value array read): the same history and solution sums to the last digit as the default."""
+    for dim, grid, vp in ((4, (3, 4, 512), 2), (3, (9, 11, 13), 1), (2, (37, 41, 1), 1)):
+        flags = ("-dim", dim, "-nx", grid[0], "-ny", grid[1], "-nz", grid[2], "-vp", vp, "-solver", solver, "-it", 7,
+                 "-restart", 4, "-history", 1)
+        assert run(*flags, "-uniform", 1)[2] == run(*flags)[2]
