@@ -82,7 +82,10 @@ def init_distributed():
     torch.cuda.set_device(local_rank)
     if world > 1 and not dist.is_initialized():
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            try:    # (device_id binds the communicator to this rank's GPU at once instead of at the first collective)
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            except TypeError:   # a torch.distributed without that argument
+                dist.init_process_group("nccl")
         else:
             dist.init_process_group(backend)
     return world, local_rank
