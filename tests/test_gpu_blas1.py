@@ -558,3 +558,19 @@ def test_multi_dot_and_multi_axpy(suf, offset):
     assert fn(16, 65, ptrs, P(v), P(out), None, 0, stream()) == _lib.LSK_ERR_ARG         # too many vectors
     fa = getattr(lib, f"lsk_multi_axpy_{suf}")
     assert fa(16, 1, ptrs, P(out), 0, P(v), None, 0, None, stream()) == _lib.LSK_ERR_ARG  # a source is the destination
+
+
+def test_torch_rccl_transport_single_rank():
+    """The torch.distributed transport the planner uses between ranks (backend nccl = RCCL), on the one
+    rank a one-GPU machine has: an all-reduce and a grouped send / receive with itself, ordered against
+    kernels on the current stream (tools/nccl_single_rank_probe.py, in a process of its own so that this
+    one keeps no process group)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29573")
+    done = subprocess.run([sys.executable, os.path.join(root, "tools", "nccl_single_rank_probe.py")], env=env,
+                          capture_output=True, text=True, timeout=240)
+    print(done.stdout[-600:], flush=True)
+    assert done.returncode == 0 and "results as expected: True" in done.stdout, done.stderr[-800:]
