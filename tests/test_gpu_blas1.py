@@ -568,8 +568,12 @@ def test_torch_rccl_transport_single_rank():
     import os
     import subprocess
     import sys
+    import socket
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29573")
+    with socket.socket() as probe:   # a port nobody holds right now
+        probe.bind(("127.0.0.1", 0))
+        port = probe.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     done = subprocess.run([sys.executable, os.path.join(root, "tools", "nccl_single_rank_probe.py")], env=env,
                           capture_output=True, text=True, timeout=240)
     print(done.stdout[-600:], flush=True)
