@@ -631,7 +631,7 @@ public:
             if (sliced_[c].pair_placement < 0) {
                 // two windows of x compete for each XCD's L2: the pair gets a placement of its own, timed once
                 // on the vectors at hand (the destinations are about to be overwritten anyway)
-                sliced_[c].pair_placement = sliced_[c].placement;
+                sliced_[c].pair_placement = sliced_[c].placement ? sliced_[c].placement : 64; // (only round robin is slow)
                 if (rows >= kTuneMinRows) {
                     float ms = 0.0f;
                     check(Abi<T>::csr_sliced_tune2(sliced_[c].handle, src_a.data(), src_b.data(), dst_a.piece(c),

@@ -683,7 +683,8 @@ class CSRMatrix(AbstractMatrix, _SlicedCopies):
             if c not in self.pair_placement:
                 # Two windows of x compete for each XCD's L2, so the pair has a placement of its own, timed
                 # once on the vectors at hand (every row of ys is about to be overwritten anyway).
-                self.pair_placement[c] = self.sliced_placement.get(c, 0)
+                # (untimed: runs of 64 blocks per XCD -- only the round-robin placement is slow for the pair)
+                self.pair_placement[c] = self.sliced_placement.get(c, 0) or 64
                 tune2 = getattr(be, "csr_sliced_tune2", None)
                 if tune2 is not None and rows >= self.TUNE_MIN_ROWS and os.environ.get("LSK_TUNE", "1") != "0":
                     with self._stage("pair_placement_tuner"):
