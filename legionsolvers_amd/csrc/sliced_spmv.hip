@@ -49,7 +49,7 @@ struct PatternInfo {
     int len;        // entries; -1: unused slot
     int nruns;      // runs of consecutive distances; 0: not staged (too many runs or too much LDS)
     int lds_elems;  // elements of LDS the staged windows take, for blocks of 256 R rows
-    int pad;
+    int w_diag_off; // where x at distance 0 (the row's own element) sits in a wave's windows; -1: the list has no such entry
     int dist[kMaxLength];     // distance of entry j
     int lds_off[kMaxLength];  // where the x value of entry j for the block's first row sits in LDS
     unsigned lds_off_packed[kMaxLength / 2]; // the same, two 16-bit offsets per word (entry 2k low, 2k + 1 high)
@@ -786,7 +786,10 @@ __global__ __launch_bounds__(kBlock, (UNIFORM ? LSK_UNIFORM_WAVES : sliced_wave_
     const T *__restrict__ val, const unsigned *__restrict__ row_mask, const PatternInfo *__restrict__ table,
     const T *__restrict__ xa, const T *__restrict__ xb, long long x_shift, long long x_extent, T *__restrict__ ya,
     T *__restrict__ yb, int beta, int remap, const T *__restrict__ wa, const T *__restrict__ wb, T *__restrict__ pa,
-    T *__restrict__ pb, int lds_wave_elems, int yw_aligned, const T *__restrict__ uniform) {
+    T *__restrict__ pb, int lds_wave_elems, int yw_aligned, const T *__restrict__ uniform, int w_is_x) {
+    // w_is_x (DOT): bit k: w of vector k is the very memory x's rows are (the product's own input vector, as
+    // in CG's p . A p), so the shares take it from the window at distance 0, which is in LDS already,
+    // instead of reading it a second time.
     constexpr int R = Lane<T>::R;
     using V = typename Lane<T>::V;
     constexpr int kBlockRows = kBlock * R, kWaveRows = kWave * R;
@@ -1054,16 +1057,18 @@ __global__ __launch_bounds__(kBlock, (UNIFORM ? LSK_UNIFORM_WAVES : sliced_wave_
 #pragma unroll
             for (int j = 0; j < CAP; ++j) entry(j, std::false_type{});
         }
-        if (k + 1 < K) { // the reads are done before the next vector's windows overwrite the area
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-        }
 #pragma unroll
         for (int h = 0; h < R; ++h) result[k][h] = acc[h];
         if constexpr (DOT) {
             const T *w = k == 0 ? wa : wb;
             T share = T(0);
-            if (all_live && yw_aligned) {
+            const int own = info.w_diag_off; // (wave-uniform)
+            if (!DIRECT && ((w_is_x >> k) & 1) && own >= 0) { // w is x: the rows' own elements are in the windows
+                const T *mine = lane_xs + own;
+#pragma unroll
+                for (int h = 0; h < R; ++h)
+                    if (live[h]) share = share + acc[h] * mine[h];
+            } else if (all_live && yw_aligned) {
                 const V wv = *reinterpret_cast<const V *>(w + r);
 #pragma unroll
                 for (int h = 0; h < R; ++h) share = share + acc[h] * wv[h];
@@ -1074,6 +1079,10 @@ __global__ __launch_bounds__(kBlock, (UNIFORM ? LSK_UNIFORM_WAVES : sliced_wave_
             }
             share = lsk::wave_sum(share);
             if (lane == 0) wave_share[k][wave] = share;
+        }
+        if (k + 1 < K) { // the reads are done before the next vector's windows overwrite the area
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         }
     }
     // the block's only barrier: its stores leave together, 4 KiB per vector
@@ -1346,6 +1355,9 @@ void plan_wave_staging(PatternInfo &p, int wave_rows) {
         lds_off[j] = j < p.len ? p.w_run_off[run_of[j]] + (p.dist[j] - p.run_start[run_of[j]]) : 0;
     for (int k = 0; k < kMaxLength / 2; ++k)
         p.w_lds_off_packed[k] = static_cast<unsigned>(lds_off[2 * k]) | (static_cast<unsigned>(lds_off[2 * k + 1]) << 16);
+    p.w_diag_off = -1;
+    for (int j = 0; j < p.len; ++j)
+        if (p.dist[j] == 0) p.w_diag_off = lds_off[j];
     p.w_ntail = 0;
     for (int q = 0; q < p.nruns; ++q)
         for (int e = 0; e + 1 < p.run_len[q]; ++e) {
@@ -1450,6 +1462,7 @@ int create(const char *name, int64_t rows, int64_t nnz, const int64_t *rects, in
             for (int p = 0; p < kMaxPatterns; ++p) {
                 PatternInfo &info = infos[p];
                 info = PatternInfo{};
+                info.w_diag_off = -1;
                 const int *mine = host_lists.data() + p * (kMaxLength + 1);
                 info.len = mine[0];
                 for (int j = 0; j < kMaxLength; ++j) info.dist[j] = j < info.len ? mine[1 + j] : 0;
@@ -1664,6 +1677,8 @@ int launch_wave(const lsk_csr_sliced *m, int64_t block_begin, unsigned blocks, i
     const int areas = (LSK_WAVE_AHEAD && dma && K == 2) ? 2 : 1; // LDS areas per wave (see AHEAD in the kernel)
     const int wave_elems = static_cast<int>(m->wave_lds_bytes / sizeof(T)) * areas;
     size_t lds = m->wave_lds_bytes * kWavesPerBlock * areas;
+    // w the very rows of x (CG's p . A p): the shares take it from the staged windows (see the kernel)
+    const int w_is_x = !dot ? 0 : (wa == xa + x_shift ? 1 : 0) | (K == 2 && wb == xb + x_shift ? 2 : 0);
 #define LSK_WAVE_LAUNCH2(CAP, DOT, RUN3, DMA, UNIFORM)                                                             \
     do {                                                                                                           \
         auto kernel = sliced_wave_kernel<T, CAP, DOT, K, RUN3, DMA, UNIFORM>;                                      \
@@ -1672,7 +1687,7 @@ int launch_wave(const lsk_csr_sliced *m, int64_t block_begin, unsigned blocks, i
                                         hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));       \
         kernel<<<blocks, kBlock, lds, s>>>(block_begin, row_begin, row_end, meta, val, m->row_mask, m->table, xa, xb, \
                                            x_shift, x_extent, ya, yb, beta, remap, wa, wb, pa, pb, wave_elems,      \
-                                           yw_aligned, static_cast<const T *>(m->uniform));                        \
+                                           yw_aligned, static_cast<const T *>(m->uniform), w_is_x);                \
     } while (0)
 #define LSK_WAVE_LAUNCH(CAP, DOT, RUN3)                                                                            \
     do {                                                                                                           \

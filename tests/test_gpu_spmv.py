@@ -766,6 +766,34 @@ def sliced_case(suf, rects, k_base, col, val, x, x_lo, x_hi, row_first, tag, exp
         code = getattr(_lib.lib(), f"lsk_csr_sliced_spmv_dot_{suf}")(handle, 0, rows, P(xd), P(yd), 0, P(wd), P(partials),
                                                                    slots - 1, ctypes.byref(count), stream())
         assert code == _lib.LSK_ERR_ARG and count.value == 0, f"{tag}: short partials buffer accepted"
+        # w the very rows of x (CG's p . A p: the kernel then takes w from its staged windows of x): the same
+        # shares, bit for bit, as with a copy of those rows somewhere else in memory
+        shift = row_first - x_lo
+        if shift >= 0 and shift + rows <= x.size:
+            w_view = xd[shift:shift + rows]
+            w_copy = w_view.clone()
+            got = []
+            for wv in (w_view, w_copy):
+                yd = dev(y0)
+                part = torch.full((slots,), 7.0, dtype=tdt, device="cuda")
+                _lib.call(f"lsk_csr_sliced_spmv_dot_{suf}", handle, 0, rows, P(xd), P(yd), 0, P(wv), P(part), slots,
+                          ctypes.byref(count), stream())
+                assert np.array_equal(yd.cpu().numpy().view(np.uint8), want.view(np.uint8)), f"{tag}: fused, w = x"
+                got.append(part)
+            assert torch.equal(got[0], got[1]), f"{tag}: shares differ when w is the rows of x"
+            if info[7]:
+                xb2 = dev(rng.standard_normal(x.size).astype(npdt))
+                outs = []
+                for wa2, wb2 in ((w_view, xb2[shift:shift + rows]), (w_copy, xb2[shift:shift + rows].clone())):
+                    ya, yb = dev(y0), dev(y0)
+                    pa = torch.full((slots,), 7.0, dtype=tdt, device="cuda")
+                    pb = torch.full((slots,), 7.0, dtype=tdt, device="cuda")
+                    _lib.call(f"lsk_csr_sliced_spmv2_dot_{suf}", handle, 0, rows, P(xd), P(xb2), P(ya), P(yb), 0, P(wa2),
+                              P(wb2), P(pa), P(pb), slots, ctypes.byref(count), stream())
+                    outs.append((pa, pb))
+                assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), \
+                    f"{tag}: the pair's shares differ when w is the rows of x"
+                assert torch.equal(outs[0][0], got[0]), f"{tag}: the pair's first shares are not the single product's"
         sliced_pair_case(suf, handle, rows, br, xd, x.size, y0, wd, partials[:slots].clone(), tag,
                          must_serve=bool(info[7]))
         assert info[7] == 1 or not tag.startswith("stencil"), f"{tag}: the two-vector product should serve a stencil"

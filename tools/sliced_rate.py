@@ -76,6 +76,9 @@ def main():
             out[f"{label}_ms"] = round(timed(ctx, lambda: be.csr_sliced_spmv(s, 0, matrix.rows, xs[0], ys[0], 0, place), 20), 3)
             out[f"{label}_dot_ms"] = round(timed(ctx, lambda: be.csr_sliced_spmv_dot(s, matrix.rows, xs[0], ys[0], 0, xs[1],
                                                                                    shares, place), 20), 3)
+            # ... with w the product's own input vector (CG's p . A p): taken from the staged windows, not read again
+            out[f"{label}_dot_w_is_x_ms"] = round(timed(ctx, lambda: be.csr_sliced_spmv_dot(s, matrix.rows, xs[0], ys[0], 0, xs[0],
+                                                                                          shares, place), 20), 3)
         _lib.call("lsk_set_option", b"sliced.dma", 1)
         _lib.call("lsk_set_option", b"sliced.form", int(os.environ.get("LSK_SLICED_FORM", "1")))
         # the values as scalars (constant-coefficient stencils): no value loads at all
