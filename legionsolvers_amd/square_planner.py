@@ -509,5 +509,12 @@ class SquarePlanner:
     def _fused_dot_pays(self) -> bool:
         """The fused product + dot is a bet on the caller's next dot product (CG wins it every
         step, GMRES once in 31 products, BiCGStab never): after a few products, keep betting
-        only while at least half of the bets were won."""
-        return self._fused_dot_issued < 4 or 2 * self._fused_dot_used >= self._fused_dot_issued
+        only while at least half of the bets were won.  A product that goes without a bet makes the
+        record fade a little, so that a caller who changes its ways (a run of plain products, then CG)
+        is offered bets again: one in three products or so while they keep being lost (on the
+        sliced-pattern copy a lost bet costs nothing: the shares' second operand is the product's own input)."""
+        if self._fused_dot_issued < 4 or 2 * self._fused_dot_used >= self._fused_dot_issued:
+            return True
+        self._fused_dot_issued *= 0.9
+        self._fused_dot_used *= 0.9
+        return False

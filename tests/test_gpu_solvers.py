@@ -675,3 +675,19 @@ def test_classical_gram_schmidt_gmres_follows_its_oracle(gpu_ctx, dtype, pieces)
     want = opl.get_vector(0, 0).astype(np.float64)
     got = mpl.get_vector(0, 0).to_host().numpy().astype(np.float64)
     assert np.abs(got - want).max() <= tol * np.abs(want).max()
+
+
+def test_fused_dot_bets_come_back_after_plain_products(gpu_ctx):
+    """The planner fuses the shares of a dot product into a product as a bet on the caller's next dot; a run
+    of products that nobody follows with a dot stops the bets, and a solver that comes afterwards gets them
+    back within a few steps (CG's p . A p wins every one)."""
+    rects, row, col, val, n = hc.stencil_problem(4, (7, 12, 70), np.float64)
+    pl = hc.mirror_planner(gpu_ctx, "csr", rects, row, col, val, n, 1, np.float64, np.ones(n))
+    solver = CGSolver(pl)
+    for _ in range(24):
+        pl.matvec(CGSolver.Q, CGSolver.P)
+    assert pl._fused_dot_used == 0 and pl._fused_dot_issued >= 3   # bets were lost, and are placed sparingly now
+    used = pl._fused_dot_used
+    for _ in range(40):
+        solver.step()
+    assert pl._fused_dot_used - used >= 15, (used, pl._fused_dot_used, pl._fused_dot_issued)
