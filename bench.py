@@ -241,13 +241,19 @@ def main():
     # CG's first step overwrites Q with the same product.
     planner.matvec(CGSolver.Q, CGSolver.P)
     ctx.comm.all_reduce_sum(torch.zeros(1, dtype=torch.float64, device=ctx.device))  # likewise the dots' all-reduce
-    if world == 1:   # (with more ranks the ranks' waits would differ)
-        # (the matrix's own product, not the planner's: the planner keeps count of the dot shares its products
-        # leave and nobody uses, and would stop fusing them in)
-        entry0 = planner.row_partitioned_matrices[0]
-        p_vec, q_vec = planner.get_vector(CGSolver.P, 0), planner.get_vector(CGSolver.Q, 0)
-        setup_s["wait_for_a_quiet_device"] = wait_for_a_quiet_device(
-            ctx, lambda: matrix.matvec(q_vec, p_vec._own, p_vec.own_lo, p_vec.own_hi, entry0.kernel_partition, 0))
+    # (one rank: the matrix's own product, not the planner's -- the planner keeps count of the dot shares its
+    # products leave and nobody uses, and would stop fusing them in; more ranks: a copy of this rank's part of a
+    # vector, which needs no other rank -- a GPU that just ran a smaller case of the scaling series is in the same
+    # shadow -- and the ranks meet again at the barrier in front of the timed steps)
+    entry0 = planner.row_partitioned_matrices[0]
+    p_vec, q_vec = planner.get_vector(CGSolver.P, 0), planner.get_vector(CGSolver.Q, 0)
+    if world == 1:
+        probe = lambda: matrix.matvec(q_vec, p_vec._own, p_vec.own_lo, p_vec.own_hi, entry0.kernel_partition, 0)  # noqa: E731
+    else:
+        def probe():   # (sixteen copies a sample: long enough for a few per cent to show above the timer's jitter)
+            for _ in range(16):
+                ctx.backend.copy(q_vec._own, p_vec._own)
+    setup_s["wait_for_a_quiet_device"] = wait_for_a_quiet_device(ctx, probe, tolerance=0.015 if world == 1 else 0.03)
     untuned_steps = max(args.steps // 2, 2)
     iters_untuned = untuned_steps / bs.timed_steps(ctx, solver, args.warmup, untuned_steps)
     if tune_env != "0":
