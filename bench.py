@@ -20,7 +20,9 @@ Besides the contract's fields the line carries:
                 32-bit copy of the structure and the reference's 64-bit column field
   cpu_baseline  the CPU oracle's CG step (OpenMP over row blocks) on the same matrix, copied to the host,
                 rank 0 at N = 1 only
-  value_untuned, value_reference_layout, setup_s, host_ms_per_step   see "notes" in the line
+  transport, rccl_ranks   what carries the halo exchange and the dots' all-reduce between ranks, and how
+                many ranks the RCCL communicator behind it reports (null on one rank)
+  value_reference_layout, setup_s, host_ms_per_step, value_with_redraws (--redraws)   see "notes" in the line
 """
 from __future__ import annotations
 
@@ -30,12 +32,51 @@ import os
 import sys
 import time
 
-import torch
-import torch.distributed as dist
-
 REPO = os.path.dirname(os.path.abspath(__file__))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
+
+
+def launch_ranks_if_needed(argv) -> None:
+    """`python bench.py --gpus N` with N > 1 and no launcher around it (WORLD_SIZE unset): start the N
+    ranks as a CHILD job, `python -m torch.distributed.run --nproc-per-node N ... bench.py <same flags>`,
+    pass its output through and exit with its code.  Runs before this process has imported torch or
+    touched a GPU; the child is a fresh process, never a re-exec of this one.  When the child fails
+    with the library's own RCCL transport, it is started once more with LSK_TRANSPORT=torch."""
+    import socket
+    import subprocess
+    gpus = 1
+    for i, a in enumerate(argv):
+        if a == "--gpus" and i + 1 < len(argv):
+            gpus = int(argv[i + 1])
+        elif a.startswith("--gpus="):
+            gpus = int(a.split("=", 1)[1])
+    if gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return
+    rc = 1
+    attempts = [dict(os.environ)]
+    if os.environ.get("LSK_TRANSPORT") in (None, "", "lsk") and os.environ.get("LSK_DIST_BACKEND", "nccl") == "nccl":
+        attempts.append(dict(os.environ, LSK_TRANSPORT="torch"))
+    for n, env in enumerate(attempts):
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *argv]
+        print(f"[bench] WORLD_SIZE is unset: starting {gpus} ranks: {' '.join(cmd)}"
+              + (" (second attempt, LSK_TRANSPORT=torch)" if n else ""), file=sys.stderr, flush=True)
+        rc = subprocess.call(cmd, env=env, cwd=REPO)
+        if rc == 0:
+            break
+    sys.exit(rc)
+
+
+if __name__ == "__main__":
+    launch_ranks_if_needed(sys.argv[1:])
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
 
 from legionsolvers_amd import CGSolver, Context, IndexPartition, IndexSpace, PartitionedVector  # noqa: E402
 from legionsolvers_amd import benchmark_stencil as bs  # noqa: E402
@@ -200,11 +241,15 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--n", "--grid", dest="n", type=int, default=512, help="grid points per dimension")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--redraws", action="store_true",
+                    help="after the timed steps, also re-make the matrix copy a few times keeping the fastest "
+                         "(LSK_TUNE=2) and report the rate with it beside the headline: value_with_redraws")
     args = ap.parse_args()
 
     world, local_rank = bs.init_distributed()
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE is {world}: launch one rank per GPU")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE is {world}: one rank per GPU "
+                         "(a plain `python bench.py --gpus N` starts them itself)")
     ctx = Context(torch.device("cuda", local_rank))
     n1 = args.n
     rows = n1 ** 3
@@ -214,11 +259,8 @@ def main():
         ctx.synchronize()
         setup_s[name] = setup_s.get(name, 0.0) + time.perf_counter() - t0
 
-    # single-system CG: the metric.  Set-up first WITHOUT the speed tuning (placement tuner, redraws
-    # of the copies, steadiness wait), so that the untuned rate can be timed; then the tuning, then
-    # the rate the line reports.
-    tune_env = os.environ.get("LSK_TUNE")
-    os.environ["LSK_TUNE"] = "0"
+    # single-system CG: the metric, with the planner's defaults (which include timing a handful of
+    # workgroup placements once per matrix, and nothing that re-makes a copy or waits).
     t0 = time.perf_counter()
     _, offsets, coeffs = bs.sg.benchmark_stencil(4)
     partition = IndexPartition.equal(IndexSpace(0, rows - 1), world)
@@ -227,14 +269,10 @@ def main():
     t0 = time.perf_counter()
     _, planner, solver = bs.build_problem(ctx, 4, n1, n1, n1, world, 1, torch.float64, num_systems=1, matrix=matrix)
     stage("vectors_partitions_halo_plan", t0)
-    for key in ("compress_32bit", "sliced_copy"):
+    for key in ("compress_32bit", "sliced_copy", "placement_tuner"):
         if key in matrix.setup_seconds:
             setup_s[key] = matrix.setup_seconds[key]
             setup_s["vectors_partitions_halo_plan"] -= matrix.setup_seconds[key]
-    if tune_env is None:
-        del os.environ["LSK_TUNE"]
-    else:
-        os.environ["LSK_TUNE"] = tune_env
     nnz_total = (3 * n1 - 2) ** 3
     # One untimed matvec Q <- A P before anything is timed: it opens the point-to-point
     # connections of the halo exchange, so that a run with --warmup 0 does not time their set-up.
@@ -254,20 +292,6 @@ def main():
             for _ in range(16):
                 ctx.backend.copy(q_vec._own, p_vec._own)
     setup_s["wait_for_a_quiet_device"] = wait_for_a_quiet_device(ctx, probe, tolerance=0.015 if world == 1 else 0.03)
-    untuned_steps = max(args.steps // 2, 2)
-    iters_untuned = untuned_steps / bs.timed_steps(ctx, solver, args.warmup, untuned_steps)
-    if tune_env != "0":
-        before = dict(matrix.setup_seconds)
-        if matrix.sliced:
-            matrix.tune_sliced_copies()
-        else:
-            entry = planner.row_partitioned_matrices[0]
-            x_lo, x_hi = matrix.col32_window if matrix.col32_window else (planner.get_vector(2, 0).own_lo,
-                                                                         planner.get_vector(2, 0).own_hi)
-            matrix.tune(x_lo, x_hi, entry.kernel_partition, partition)
-        for key, v in matrix.setup_seconds.items():
-            if v != before.get(key):
-                setup_s[key] = v - before.get(key, 0.0)
     seconds = bs.timed_steps(ctx, solver, args.warmup, args.steps)
     iters_per_s = args.steps / seconds
     rr = solver.residual_norm_squared[-1].get_value()
@@ -320,6 +344,15 @@ def main():
         traffic = measured.get("bytes_per_launch_sliced") if sliced else traffic32 if compressed else traffic64
         traffic_source = ("recorded, not measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
                           "tools/pmc_spmv.py, profiles/spmv_hbm_traffic.json")
+
+    with_redraws = None
+    if args.redraws and sliced:
+        before = dict(matrix.setup_seconds)
+        matrix.tune_sliced_copies(redraws=int(os.environ.get("LSK_TUNE_REDRAWS", matrix.SLICED_REDRAWS)))
+        for key, v in matrix.setup_seconds.items():
+            if v != before.get(key):
+                setup_s[key + "_with_redraws"] = v - before.get(key, 0.0)
+        with_redraws = args.steps / bs.timed_steps(ctx, solver, args.warmup, args.steps)
 
     # The same steps with the matrix values taken as scalars (option sliced.uniform): every matrix of the
     # reference's benchmark is a constant-coefficient stencil, the sliced-pattern copy finds that out bit by
@@ -386,7 +419,10 @@ def main():
         "two_system_iters_per_s": two_system,
         "two_system_iters_per_s_separate_products": two_system_separate,
         "value_uniform_coefficients": uniform["iters_per_s"] if uniform else None,
-        "value_untuned": iters_untuned,
+        "value_with_redraws": with_redraws,
+        "transport": ctx.comm.transport if world > 1 else None,
+        "rccl_ranks": ctx.comm.rccl_ranks,
+        "transport_note": ctx.comm.transport_note,
         "value_reference_layout": iters_reference_layout,
         "setup_s": {k: round(v, 3) for k, v in setup_s.items()},
         "host_ms_per_step": host_ms,
@@ -399,9 +435,12 @@ def main():
                                           "set-up, and the product takes the 27 coefficients as scalars instead of reading "
                                           "the value array; same multiplications and additions in the same order, same bits "
                                           "(roofline_uniform_coefficients: that kernel, not bound by HBM any more)",
-            "value_untuned": "the same steps before the set-up-time speed tuning (workgroup placement chosen by timing, "
-                             "the copy re-made up to 6 times keeping the fastest, wait for the driver's scrubbing of freed "
-                             "memory): LSK_TUNE=0",
+            "value_with_redraws": "only with --redraws: the same steps after the opt-in set-up-time tuning LSK_TUNE=2 (the "
+                                  "copy re-made up to 6 times keeping the fastest, then a wait for the driver's scrubbing "
+                                  "of freed memory); the headline `value` runs without it",
+            "transport": "lsk = the library's RCCL layer (lsk_allreduce_sum_*, lsk_halo_exchange_* of include/lsk.h, halo on "
+                         "a second stream of the same priority); torch = torch.distributed; rccl_ranks as lsk_comm_rank "
+                         "reports it",
             "value_reference_layout": "the same steps with every product on the int64 columns and 16-byte rects as handed "
                                       "over (csr_spmv_wave_kernel<double, long, ...>), no set-up-time copy",
             "setup_s": "wall-clock seconds before the first timed step, stage by stage, this rank (wait_for_a_quiet_device: "
@@ -446,7 +485,9 @@ def main():
     if ctx.rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:
+        ctx.synchronize()
         dist.barrier()
+        ctx.comm.close()
         dist.destroy_process_group()
 
 

@@ -4,8 +4,8 @@
 // three output lines.  Extensions for tests: -systems 1 solves a single system, -coo 1 builds the
 // COO form of the matrix, -f32 1 uses float entries, -restart N sets GMRES's restart length
 // (the reference hard-codes 10), -history 1 prints the solver's scalar history one value per line,
-// -compress 0 / -sliced 0 / -fuse 0 / -redraws 0 turn the 32-bit structure, the sliced-pattern copy,
-// the held-back updates and the set-up-time array redraws off, -adjoint N (after the solve) multiplies the solution by the
+// -compress 0 / -sliced 0 / -fuse 0 turn the 32-bit structure, the sliced-pattern copy and
+// the held-back updates off, -redraws N re-makes the set-up-time copies N times keeping the fastest (off by default), -adjoint N (after the solve) multiplies the solution by the
 // transpose and prints it against the product itself (the stencil matrices are symmetric) and both
 // sides of <A x, b> = <x, A^T b>; N > 1 transposes in runs of N entries; -binned 1 (with -coo 1) multiplies
 // through the binned copy of the COO matrix, in blocks of -bincols columns and tiles of -binrows rows
@@ -27,7 +27,7 @@ namespace {
 
 struct Args {
     long dim = 1, solver = 1, nx = 16, ny = 16, nz = 16, vp = 4, it = 20, pt = 1;
-    long systems = 2, coo = 0, f32 = 0, restart = 10, history = 0, compress = 1, fuse = 1, redraws = 4, adjoint = 0, sliced = 1;
+    long systems = 2, coo = 0, f32 = 0, restart = 10, history = 0, compress = 1, fuse = 1, redraws = 0, adjoint = 0, sliced = 1;
     long binned = 0, bincols = 0, binrows = 0, cgs = 0, pair = 1, uniform = 0;
 };
 

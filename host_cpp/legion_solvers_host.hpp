@@ -508,7 +508,7 @@ private:
 template <typename T> class CSRMatrix : public AbstractMatrix<T> {
 public:
     CSRMatrix(const Context &ctx, const EqualPartition &range, int64_t domain_size, DeviceArray<int64_t> rects,
-              DeviceArray<int64_t> col, DeviceArray<T> val, bool compress = true, int redraws = 4, bool slice = true)
+              DeviceArray<int64_t> col, DeviceArray<T> val, bool compress = true, int redraws = 0, bool slice = true)
         : ctx_(&ctx), range_(range), domain_(domain_size), rects_(std::move(rects)), col_(std::move(col)),
           val_(std::move(val)) {
         for (int c = 0; c < range_.colors(); ++c) {

@@ -714,12 +714,16 @@ typedef struct lsk_comm *lsk_comm_t;
 int lsk_comm_unique_id(void *id_out /* LSK_UNIQUE_ID_BYTES */);
 int lsk_comm_init_rank(lsk_comm_t *comm, int nranks, int rank, const void *id);
 int lsk_comm_destroy(lsk_comm_t comm);
+/* Gives the communicator up without waiting for what is enqueued on it (ncclCommAbort): for a rank
+ * that found a peer missing and wants its own streams to drain.  The handle is dead afterwards. */
+int lsk_comm_abort(lsk_comm_t comm);
 int lsk_comm_rank(lsk_comm_t comm, int *rank, int *nranks);
 /* In-place sum over ranks of `count` scalars at buf (device). */
 int lsk_allreduce_sum_f32(lsk_comm_t comm, float *buf, int count, lsk_stream_t stream);
 int lsk_allreduce_sum_f64(lsk_comm_t comm, double *buf, int count, lsk_stream_t stream);
 /* Point-to-point halo exchange, grouped into one RCCL group: for i < nsend send
- * send_count[i] elements at send_ptr[i] to send_peer[i]; same for receives. */
+ * send_count[i] elements at send_ptr[i] to send_peer[i]; same for receives.  A peer may be the
+ * calling rank itself (the i-th such send lands in the i-th such receive). */
 int lsk_halo_exchange_f32(lsk_comm_t comm, int nsend, const int *send_peer,
                           const float *const *send_ptr, const int64_t *send_count, int nrecv,
                           const int *recv_peer, float *const *recv_ptr,

@@ -121,6 +121,7 @@ PROTOTYPES = {
     "lsk_comm_unique_id": (_i, [_p]),
     "lsk_comm_init_rank": (_i, [ctypes.POINTER(_p), _i, _i, _p]),
     "lsk_comm_destroy": (_i, [_p]),
+    "lsk_comm_abort": (_i, [_p]),
     "lsk_comm_rank": (_i, [_p, ctypes.POINTER(_i), ctypes.POINTER(_i)]),
 }
 PROTOTYPES.update(_typed(_FT, lambda s, t: {

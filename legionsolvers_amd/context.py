@@ -32,6 +32,9 @@ class Context:
             backend = HipBackend(device)
         self.backend = backend
         self.device = backend.device
+        bind = getattr(self.comm, "bind_device", None)
+        if bind is not None:   # the RCCL communicator of the "lsk" transport needs the rank's GPU
+            bind(self.device)
 
     @property
     def rank(self) -> int:

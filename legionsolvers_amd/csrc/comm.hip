@@ -57,15 +57,30 @@ int halo_exchange(lsk_comm_t c, int nsend, const int *send_peer, const T *const 
     if ((nsend && (!send_peer || !send_ptr || !send_count)) ||
         (nrecv && (!recv_peer || !recv_ptr || !recv_count)))
         return lsk::fail(LSK_ERR_ARG, "lsk_halo_exchange: null list");
+    // (a transfer to the calling rank itself is allowed: RCCL pairs a send and a receive of one rank
+    // inside a group, in the order they were posted, and moves the data with a copy on the device)
     for (int i = 0; i < nsend; ++i)
-        if (send_peer[i] < 0 || send_peer[i] >= c->nranks || send_peer[i] == c->rank ||
-            send_count[i] < 0 || (send_count[i] > 0 && !send_ptr[i]))
+        if (send_peer[i] < 0 || send_peer[i] >= c->nranks || send_count[i] < 0 ||
+            (send_count[i] > 0 && !send_ptr[i]))
             return lsk::fail(LSK_ERR_ARG, "lsk_halo_exchange: bad send entry %d", i);
     for (int i = 0; i < nrecv; ++i)
-        if (recv_peer[i] < 0 || recv_peer[i] >= c->nranks || recv_peer[i] == c->rank ||
-            recv_count[i] < 0 || (recv_count[i] > 0 && !recv_ptr[i]))
+        if (recv_peer[i] < 0 || recv_peer[i] >= c->nranks || recv_count[i] < 0 ||
+            (recv_count[i] > 0 && !recv_ptr[i]))
             return lsk::fail(LSK_ERR_ARG, "lsk_halo_exchange: bad recv entry %d", i);
     hipStream_t s = lsk::as_stream(stream);
+    if (c->nranks == 1 && lsk::options().comm_skip_single_rank) {
+        // one rank: every transfer is to itself; the i-th send lands in the i-th receive
+        if (nsend != nrecv) return lsk::fail(LSK_ERR_ARG, "lsk_halo_exchange: %d sends to itself, %d receives", nsend, nrecv);
+        for (int i = 0; i < nsend; ++i) {
+            if (send_count[i] != recv_count[i])
+                return lsk::fail(LSK_ERR_ARG, "lsk_halo_exchange: transfer %d to itself sends %lld and receives %lld elements",
+                                 i, (long long)send_count[i], (long long)recv_count[i]);
+            if (send_count[i] > 0 && send_ptr[i] != recv_ptr[i])
+                LSK_HIP(hipMemcpyAsync(recv_ptr[i], send_ptr[i], size_t(send_count[i]) * sizeof(T),
+                                       hipMemcpyDeviceToDevice, s));
+        }
+        return LSK_OK;
+    }
     LSK_NCCL(ncclGroupStart());
     // From here on the group is open: a failing call is remembered, the group is closed whatever
     // happened (a group left open would swallow every later RCCL call of this thread), and the
@@ -134,6 +149,14 @@ int lsk_comm_destroy(lsk_comm_t comm) {
     ncclResult_t st = ncclCommDestroy(comm->comm);
     delete comm;
     if (st != ncclSuccess) return nccl_fail(st, "ncclCommDestroy", __FILE__, __LINE__);
+    return LSK_OK;
+}
+
+int lsk_comm_abort(lsk_comm_t comm) {
+    if (!comm) return LSK_OK;
+    ncclResult_t st = ncclCommAbort(comm->comm);
+    delete comm;
+    if (st != ncclSuccess) return nccl_fail(st, "ncclCommAbort", __FILE__, __LINE__);
     return LSK_OK;
 }
 

@@ -165,7 +165,7 @@ class _SlicedCopies:
     def _make_sliced_copies(self, make, x_lo: int, x_hi: int, kernel_partition, range_partition) -> bool:
         """make(i, c): the copy of local piece i (colour c), None when the library declines.  The
         copies are made for all pieces or none; unless LSK_TUNE=0, their placement is then chosen by
-        timing and they are re-made a few times (tune_sliced_copies)."""
+        timing (tune_sliced_copies; with LSK_TUNE=2 they are also re-made a few times)."""
         made = {}
         with self._stage("sliced_copy"):
             for i, c in enumerate(kernel_partition.colors):
@@ -186,12 +186,14 @@ class _SlicedCopies:
     def tune_sliced_copies(self, redraws: int = None) -> None:
         """Set-up-time speed tuning of the sliced-pattern copies of large pieces (TUNE_MIN_ROWS rows
         or more), none of which changes a result: (1) the workgroup -> XCD placement is chosen by
-        timing a few candidates; (2) the copy is made up to `redraws` more times (LSK_TUNE_REDRAWS,
-        default SLICED_REDRAWS) while the previous one is still held, and the fastest is kept: where
-        the driver puts an array in HBM moves the product's time by several per cent, the draw cannot
-        be steered but it can be repeated (needs room for a second copy); (3) a wait until the
-        driver's scrubbing of what the redraws freed no longer slows the product.  The planner runs it
-        when it registers a matrix (unless LSK_TUNE=0); seconds per stage in self.setup_seconds."""
+        timing a few candidates (0.1 s at the headline size); (2) OPT-IN, with LSK_TUNE=2 or a
+        `redraws` argument: the copy is made up to `redraws` more times (LSK_TUNE_REDRAWS, default
+        SLICED_REDRAWS) while the previous one is still held, and the fastest is kept: where the driver
+        puts an array in HBM moves the product's time by several per cent, the draw cannot be steered
+        but it can be repeated (needs room for a second copy, seconds of set-up; worth about 2 % at the
+        headline size, for a solve of thousands of steps); (3) after redraws, a wait until the driver's
+        scrubbing of what they freed no longer slows the product.  The planner runs it when it registers
+        a matrix (unless LSK_TUNE=0); seconds per stage in self.setup_seconds."""
         if not self.sliced or not self.val.is_cuda or getattr(self, "_sliced_make", None) is None:
             return
         make, kernel_partition, range_partition = self._sliced_make
@@ -200,7 +202,7 @@ class _SlicedCopies:
         x = y = last = None
         freed_total = 0
         if redraws is None:
-            redraws = int(os.environ.get("LSK_TUNE_REDRAWS", self.SLICED_REDRAWS))
+            redraws = int(os.environ.get("LSK_TUNE_REDRAWS", self.SLICED_REDRAWS)) if _redraws_asked_for() else 0
         for i, c in enumerate(kernel_partition.colors):
             rows = range_partition.pieces[c].volume
             if c not in self.sliced or rows < self.TUNE_MIN_ROWS:
@@ -276,6 +278,11 @@ class _SlicedCopies:
         t1.synchronize()
         return t0.elapsed_time(t1) / reps
 
+
+
+def _redraws_asked_for() -> bool:
+    """Re-making set-up-time copies to draw a better place in HBM is opt-in: LSK_TUNE=2."""
+    return os.environ.get("LSK_TUNE", "1") == "2"
 
 
 class CSRMatrix(AbstractMatrix, _SlicedCopies):
@@ -483,7 +490,7 @@ class CSRMatrix(AbstractMatrix, _SlicedCopies):
         matrix; x and y do not matter).  The draw cannot be steered, but it can be repeated: copy
         the arrays into fresh allocations while the old ones are still held, time both, keep the
         faster set, a few times.  Needs room for a second copy; skipped otherwise."""
-        redraws = int(os.environ.get("LSK_TUNE_REDRAWS", str(self.REDRAWS)))
+        redraws = int(os.environ.get("LSK_TUNE_REDRAWS", str(self.REDRAWS))) if _redraws_asked_for() else 0
         if redraws <= 0 or not self.val.is_cuda or getattr(self.ctx.backend, "csr_spmv_tune", None) is None:
             return
         compressed = self.col32 is not None and self.col32_window == (x_lo, x_hi)  # then rects / col are off the path

@@ -284,10 +284,12 @@ def test_rccl_layer_single_rank():
             _lib.check(lib.lsk_set_option(b"comm.skip_single_rank", 1))
     _lib.check(lib.lsk_halo_exchange_f64(comm, 0, None, None, None, 0, None, None, None, stream()))
     buf = dev(np.array([1.5, 2.5]))
-    bad_peer = (ctypes.c_int * 1)(0)
+    bad_peer = (ctypes.c_int * 1)(1)       # a rank the communicator does not have
     ptrs = (ctypes.c_void_p * 1)(buf.data_ptr())
     cnt = (ctypes.c_int64 * 1)(1)
     assert lib.lsk_halo_exchange_f64(comm, 1, bad_peer, ptrs, cnt, 0, None, None, None, stream()) == -2
+    own_peer = (ctypes.c_int * 1)(0)       # a send to the rank itself that no receive takes
+    assert lib.lsk_halo_exchange_f64(comm, 1, own_peer, ptrs, cnt, 0, None, None, None, stream()) == -2
     # after a refused exchange the communicator still works (no RCCL group was left open)
     _lib.check(lib.lsk_set_option(b"comm.skip_single_rank", 0))
     try:

@@ -576,6 +576,7 @@ def test_values_changed_brings_every_copy_up_to_date(gpu_ctx, monkeypatch, kind,
     from legionsolvers_amd import COOMatrix, CSRMatrix
     monkeypatch.setattr(CSRMatrix, "TUNE_MIN_ROWS", 1)   # force the tuner and the redraws on a small problem
     monkeypatch.setattr(COOMatrix, "TUNE_MIN_ROWS", 1)
+    monkeypatch.setenv("LSK_TUNE", "2")   # (the redraws are opt-in)
     monkeypatch.setenv("LSK_TUNE_REDRAWS", "2")
     rng = np.random.default_rng(60)
     if sliced in ("blocked", "binned"):

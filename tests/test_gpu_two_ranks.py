@@ -63,3 +63,20 @@ def test_bench_contract_two_ranks_one_gpu():
     assert line["scaling"] == "strong" and line["unit"] == "iters/s" and line["value"] > 0
     assert line["config"]["pieces"] == 2 and "cpu_baseline" not in line
     assert set(line["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
+    assert line["transport"] == "torch" and line["rccl_ranks"] is None    # gloo rehearsal: RCCL cannot share a card
+
+
+def test_bench_starts_its_own_ranks_two_ranks_one_gpu():
+    """The same through a plain `python bench.py --gpus 2` (no launcher, WORLD_SIZE unset): bench.py starts
+    the two ranks itself as a child job and passes rank 0's line through."""
+    env = _env({})
+    for key in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(key, None)
+    cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--grid", "40"]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=400, cwd=REPO)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["config"]["pieces"] == 2 and line["value"] > 0
+    assert line["transport"] == "torch" and line["rccl_ranks"] is None    # gloo rehearsal: RCCL cannot share a card

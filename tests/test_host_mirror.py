@@ -269,6 +269,102 @@ def _worker(rank, world, port, out_dir):
         dist.destroy_process_group()
 
 
+def _bootstrap_worker(rank, world, port, out_dir):
+    """The unique-id bootstrap of the library's RCCL transport over the torch.distributed store: rank 0
+    makes the id (ncclGetUniqueId through the C ABI, which needs no GPU), the other reads it."""
+    import ctypes
+    from torch.distributed.distributed_c10d import _get_default_store
+    from legionsolvers_amd import _lib
+    from legionsolvers_amd.comm import UNIQUE_ID_BYTES, bootstrap_unique_id
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        made = []
+
+        def make_id():
+            buf = ctypes.create_string_buffer(UNIQUE_ID_BYTES)
+            _lib.call("lsk_comm_unique_id", buf)
+            made.append(buf.raw)
+            return buf.raw
+
+        ids = [bootstrap_unique_id(rank, make_id, _get_default_store(), f"test/{k}") for k in range(2)]
+        assert len(made) == (2 if rank == 0 else 0)          # only rank 0 asks RCCL for ids
+        everyone = [None] * world
+        dist.all_gather_object(everyone, ids)
+        assert all(e == everyone[0] for e in everyone), "every rank holds rank 0's ids"
+        assert ids[0] != ids[1] and all(len(i) == UNIQUE_ID_BYTES for i in ids)
+        # a CPU context keeps torch.distributed as its transport (no GPU to bind an RCCL communicator to)
+        ctx = Context(backend=OracleBackend())
+        assert ctx.comm.transport == "torch" and ctx.comm.rccl_ranks is None
+        if rank == 0:
+            open(os.path.join(out_dir, "ok"), "w").write("ok")
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_unique_id_bootstrap_two_gloo_ranks(tmp_path):
+    mp.spawn(_bootstrap_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    assert os.path.exists(os.path.join(tmp_path, "ok"))
+
+
+def test_unique_id_bootstrap_rules():
+    from legionsolvers_amd.comm import Communicator, UNIQUE_ID_BYTES, bootstrap_unique_id
+
+    class Store(dict):
+        def set(self, k, v):
+            self[k] = v
+
+        def get(self, k):
+            return self[k]
+
+    store = Store()
+    uid = bytes(range(UNIQUE_ID_BYTES))
+    assert bootstrap_unique_id(0, lambda: uid, store, "k") == uid
+    assert bootstrap_unique_id(3, lambda: pytest.fail("only rank 0 makes the id"), store, "k") == uid
+    with pytest.raises(ValueError):
+        bootstrap_unique_id(0, lambda: b"short", store, "k2")
+    store.set("bad", b"x")
+    with pytest.raises(RuntimeError):
+        bootstrap_unique_id(1, None, store, "bad")
+    with pytest.raises(ValueError):
+        Communicator(transport="mpi")
+
+
+def test_bench_starts_its_own_ranks_only_when_nobody_else_did(monkeypatch):
+    """`python bench.py --gpus N` without a launcher starts the ranks as a child job; under a launcher
+    (WORLD_SIZE set) or for one GPU it runs in place."""
+    import importlib.util
+    import subprocess
+    spec = importlib.util.spec_from_file_location("bench_for_test", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.delenv("LSK_TRANSPORT", raising=False)
+    monkeypatch.delenv("LSK_DIST_BACKEND", raising=False)
+    calls = []
+    monkeypatch.setattr(subprocess, "call", lambda cmd, **kw: calls.append((cmd, kw["env"].get("LSK_TRANSPORT"))) or 7)
+    bench.launch_ranks_if_needed(["--steps", "3"])                     # one GPU: in place
+    bench.launch_ranks_if_needed(["--gpus", "1"])
+    monkeypatch.setenv("WORLD_SIZE", "4")
+    bench.launch_ranks_if_needed(["--gpus", "4"])                     # under a launcher: in place
+    assert not calls
+    monkeypatch.delenv("WORLD_SIZE")
+    with pytest.raises(SystemExit) as exc:
+        bench.launch_ranks_if_needed(["--gpus", "4", "--steps", "3"])
+    assert exc.value.code == 7                                        # the child's code
+    assert [t for _, t in calls] == [None, "torch"]                   # second attempt on torch.distributed's transport
+    cmd = calls[0][0]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "4", "--steps", "3"]
+    calls.clear()
+    monkeypatch.setattr(subprocess, "call", lambda cmd, **kw: calls.append(cmd) or 0)
+    with pytest.raises(SystemExit) as exc:
+        bench.launch_ranks_if_needed(["--gpus=2"])
+    assert exc.value.code == 0 and len(calls) == 1
+
+
 def test_two_rank_gloo_matches_oracle(tmp_path, krylov_golden):
     mp.spawn(_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
     res = torch.load(os.path.join(tmp_path, "results.pt"), weights_only=False)
