@@ -1216,6 +1216,9 @@ public:
     GMRESSolver(SquarePlanner<T> &planner, int restart_length, bool classical = false)
         : pl(planner), restart(restart_length), classical_(classical), negative_one(planner.get_context(), T(-1)),
           dummy_coefficient(planner.get_context(), T(1)) {
+        // (one multi_dot call takes at most 64 vectors, and all inner products of a sweep share one buffer)
+        if (classical && restart_length > 64)
+            throw std::invalid_argument("GMRESSolver: the classical Gram-Schmidt option takes a restart length of at most 64");
         pl.allocate_workspace(restart + 1);
     }
     static int krylov_basis(int i) { return i + 2; }

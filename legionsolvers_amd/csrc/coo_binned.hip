@@ -136,8 +136,9 @@ __global__ __launch_bounds__(kSetupBlock) void bin_padded_kernel(int64_t nbins, 
 __global__ __launch_bounds__(kSetupBlock) void block_starts_kernel(int64_t nblocks, int64_t ntiles,
                                                                    const long long *__restrict__ where,
                                                                    long long *__restrict__ start) {
-    const int64_t c = int64_t(blockIdx.x) * kSetupBlock + threadIdx.x;
-    if (c <= nblocks) start[c] = where[c * ntiles];
+    const int64_t stride = int64_t(gridDim.x) * kSetupBlock; // (grid_for caps the grid)
+    for (int64_t c = int64_t(blockIdx.x) * kSetupBlock + threadIdx.x; c <= nblocks; c += stride)
+        start[c] = where[c * ntiles];
 }
 
 template <typename T>
@@ -395,6 +396,15 @@ void release(lsk_coo_binned *m) {
 template <typename T>
 size_t lds_bytes(int elems) { return (static_cast<size_t>(elems) + kPad) * sizeof(T); }
 
+// Both product kernels may ask for the whole LDS of a CU (see lsk::allow_large_lds).
+template <typename T>
+int allow_lds(hipStream_t s) {
+    static std::atomic<uint64_t> multiply_done{0}, reduce_done{0};
+    const int rc = lsk::allow_large_lds(reinterpret_cast<const void *>(binned_multiply_kernel<T>), multiply_done, s);
+    if (rc != LSK_OK) return rc;
+    return lsk::allow_large_lds(reinterpret_cast<const void *>(binned_reduce_kernel<T>), reduce_done, s);
+}
+
 template <typename T>
 int create(const char *name, int64_t nnz, const uint32_t *row32, const uint32_t *col32, const T *val,
            int64_t y_first, int64_t y_last, int64_t x_extent, int block_cols, int tile_rows, lsk_stream_t stream,
@@ -563,12 +573,7 @@ int create(const char *name, int64_t nnz, const uint32_t *row32, const uint32_t 
                                                                             m->segptr, m->segs);
             LSK_TRY(hipGetLastError());
         }
-        LSK_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(binned_multiply_kernel<T>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    static_cast<int>(lds_bytes<T>(block_cols))));
-        LSK_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(binned_reduce_kernel<T>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    static_cast<int>(lds_bytes<double>(tile_rows))));
+        if (status == LSK_OK) status = allow_lds<T>(s);
         LSK_TRY(hipStreamSynchronize(s)); // set-up time: the scratch is freed before returning
     }
 #undef LSK_TRY
@@ -599,6 +604,7 @@ int spmv(const char *name, const lsk_coo_binned *m, const T *x, T *y, int beta, 
     if (!x || !y) return lsk::fail(LSK_ERR_ARG, "%s: null vector", name);
     if (beta != 0 && beta != 1) return lsk::fail(LSK_ERR_ARG, "%s: beta must be 0 or 1", name);
     hipStream_t s = lsk::as_stream(stream);
+    if (const int rc = allow_lds<T>(s); rc != LSK_OK) return rc; // (a handle made on another device)
     if (m->units > 0) {
         binned_multiply_kernel<T><<<static_cast<unsigned>(m->units), kBinBlock, lds_bytes<T>(m->block_cols), s>>>(
             m->unit, static_cast<const T *>(m->val), m->lc, x, m->x_extent, m->block_cols, static_cast<T *>(m->prod),

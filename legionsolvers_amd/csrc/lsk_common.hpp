@@ -3,6 +3,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -40,6 +41,29 @@ inline hipStream_t as_stream(lsk_stream_t s) { return reinterpret_cast<hipStream
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+constexpr int kMaxLdsBytes = 160 << 10; // LDS of one gfx950 CU, and the most one workgroup can ask for
+
+// A launch with more than 64 KiB of dynamic LDS needs the kernel's cap raised first.  The cap belongs
+// to the kernel (per device), not to a launch or to a handle: it is raised to the whole CU's LDS, once
+// per kernel instance and device (`done`: one bit per device, a static of the call site), so that no
+// later launch with another size lowers it under a live one, and a product launched again makes no
+// runtime call besides the launch itself.  The one call that does raise it must not be recorded into
+// a graph: while `s` is capturing it is refused with a message that says so.
+inline int allow_large_lds(const void *kernel, std::atomic<uint64_t> &done, hipStream_t s) {
+    int dev = 0;
+    LSK_HIP(hipGetDevice(&dev));
+    const uint64_t bit = uint64_t(1) << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return LSK_OK;
+    hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &capturing) != hipSuccess) (void)hipGetLastError();
+    if (capturing != hipStreamCaptureStatusNone)
+        return fail(LSK_ERR_UNSUPPORTED, "the first launch of this kernel on device %d raises its LDS limit, which cannot be "
+                                         "captured: launch the product once before capturing it", dev);
+    LSK_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsBytes));
+    done.fetch_or(bit, std::memory_order_release);
+    return LSK_OK;
+}
 
 // Per-device library state: the partial-sum scratch of the reductions.
 struct DeviceState {

@@ -1621,7 +1621,13 @@ int uniform_refresh(lsk_csr_sliced *m, hipStream_t s, bool wait) {
 // Whether the structure's values are known to be uniform per list position.  While a check is still on
 // its way (after update_values) the answer is no -- the product that reads the values is always right --
 // unless the caller is willing to wait for it.
-inline bool uniform_verdict(const lsk_csr_sliced *m, bool wait) {
+inline bool uniform_verdict(const lsk_csr_sliced *m, bool wait, hipStream_t launching_on = nullptr) {
+    if (m->uniform_pending && !wait && launching_on) {
+        // a product being recorded into a graph makes no runtime query: it reads the values
+        hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(launching_on, &capturing) != hipSuccess) (void)hipGetLastError();
+        if (capturing != hipStreamCaptureStatusNone) return false;
+    }
     if (m->uniform_pending) {
         const hipError_t e = wait ? hipEventSynchronize(m->uniform_event) : hipEventQuery(m->uniform_event);
         if (e == hipSuccess) {
@@ -1682,9 +1688,11 @@ int launch_wave(const lsk_csr_sliced *m, int64_t block_begin, unsigned blocks, i
 #define LSK_WAVE_LAUNCH2(CAP, DOT, RUN3, DMA, UNIFORM)                                                             \
     do {                                                                                                           \
         auto kernel = sliced_wave_kernel<T, CAP, DOT, K, RUN3, DMA, UNIFORM>;                                      \
-        if (lds > (size_t(64) << 10))                                                                              \
-            LSK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),                                    \
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));       \
+        if (lds > (size_t(64) << 10)) {                                                                            \
+            static std::atomic<uint64_t> lds_allowed{0};                                                           \
+            if (const int rc_ = lsk::allow_large_lds(reinterpret_cast<const void *>(kernel), lds_allowed, s); rc_ != LSK_OK) \
+                return rc_;                                                                                        \
+        }                                                                                                          \
         kernel<<<blocks, kBlock, lds, s>>>(block_begin, row_begin, row_end, meta, val, m->row_mask, m->table, xa, xb, \
                                            x_shift, x_extent, ya, yb, beta, remap, wa, wb, pa, pb, wave_elems,      \
                                            yw_aligned, static_cast<const T *>(m->uniform), w_is_x);                \
@@ -1702,7 +1710,7 @@ int launch_wave(const lsk_csr_sliced *m, int64_t block_begin, unsigned blocks, i
     } while (0)
     const bool run3 = m->runs_of_three && lsk::options().sliced_runs != 0;
     // the values as scalars, where every list position has one value and the caller asked for it
-    const bool uniform = lsk::options().sliced_uniform != 0 && m->uniform && uniform_verdict(m, /*wait=*/false);
+    const bool uniform = lsk::options().sliced_uniform != 0 && m->uniform && uniform_verdict(m, /*wait=*/false, s);
     if (LSK_UNIFORM_DIRECT && uniform && dma && run3 && m->max_len > 20 && m->max_len <= 27) lds = 0; // (DIRECT in the kernel)
     if (m->max_len <= 8) LSK_WAVE_CAP(8, false);
     else if (m->max_len <= 16) LSK_WAVE_CAP(16, false);
@@ -1829,8 +1837,9 @@ int spmv2(const char *name, const lsk_csr_sliced *m, int64_t row_begin, int64_t 
 #define LSK_SLICED2_LAUNCH(CAP, DOT)                                                                                \
     do {                                                                                                            \
         auto kernel = sliced_spmv2_kernel<T, CAP, DOT>;                                                             \
-        LSK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                    static_cast<int>(lds)));                                                        \
+        static std::atomic<uint64_t> lds_allowed{0};                                                                \
+        if (const int rc_ = lsk::allow_large_lds(reinterpret_cast<const void *>(kernel), lds_allowed, s); rc_ != LSK_OK) \
+            return rc_;                                                                                             \
         kernel<<<blocks, kBlock, lds, s>>>(block_begin, row_begin, row_end, meta, val, m->row_mask, m->table, xa, xb, \
                                            x_shift, x_extent, ya, yb, beta, remap, wa, wb, pa, pb, lds_stride,       \
                                            yw_aligned);                                                             \

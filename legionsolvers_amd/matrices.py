@@ -880,17 +880,35 @@ class COOMatrix(AbstractMatrix, _SlicedCopies):
         binned = None
         binned_mode = os.environ.get("LSK_COO_BINNED", "1")
         if binned_mode != "0" and getattr(be, "coo_binned_create", None) is not None:
-            binned = be.coo_binned_create(self.row32, self.col32, self.val, y_lo, y_hi, x_hi - x_lo + 1,
-                                          self.BINNED_BLOCK_COLS, self.BINNED_TILE_ROWS)
-            if binned is not None:
-                times["binned"] = 0.0 if binned_mode == "2" else timed(lambda: be.coo_binned_spmv(binned, x, y, 0))
+            # (an optional speed probe: when the device has no room for the copy and its sort scratch,
+            # 16 + 24 bytes per entry, set-up goes on with the other forms)
+            try:
+                binned = be.coo_binned_create(self.row32, self.col32, self.val, y_lo, y_hi, x_hi - x_lo + 1,
+                                              self.BINNED_BLOCK_COLS, self.BINNED_TILE_ROWS)
+                if binned is not None:
+                    times["binned"] = 0.0 if binned_mode == "2" else timed(lambda: be.coo_binned_spmv(binned, x, y, 0))
+            except RuntimeError:
+                if binned is not None:
+                    binned.close()
+                binned = None
+                times.pop("binned", None)
+                torch.cuda.empty_cache()
+        if binned is not None and binned_mode != "2" and times.get("rows", float("inf")) < times["binned"]:
+            binned.close()   # it has lost already: lower the peak before the blocked copies are made
+            binned = None
+            del times["binned"]
         order = None
-        if not (binned is not None and binned_mode == "2"):
-            order = be.coo_block_order(self.col32, x_hi - x_lo + 1, self.BLOCK_BYTES // esz)
         blocked = None
-        if order is not None:
-            blocked = tuple(be.gather(t, order) for t in (self.row32, self.col32, self.val))
-            times["column blocks"] = timed(scan(*blocked))
+        if not (binned is not None and binned_mode == "2"):
+            try:
+                order = be.coo_block_order(self.col32, x_hi - x_lo + 1, self.BLOCK_BYTES // esz)
+                if order is not None:
+                    blocked = tuple(be.gather(t, order) for t in (self.row32, self.col32, self.val))
+                    times["column blocks"] = timed(scan(*blocked))
+            except RuntimeError:
+                order = blocked = None
+                times.pop("column blocks", None)
+                torch.cuda.empty_cache()
         if os.environ.get("LSK_TUNE_VERBOSE"):
             print("[lsk] COO forms: " + ", ".join(f"{k} {v:.3f} ms" for k, v in times.items()),
                   file=sys.stderr, flush=True)

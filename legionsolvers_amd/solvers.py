@@ -116,11 +116,17 @@ class GMRESSolver:
         for j in range(self.restart):
             pl.matvec(kb(j + 1), kb(j))
             if self.orthogonalization == "classical":
+                # (in groups of what one multi_dot / multi_axpy call takes: every inner product is still
+                # taken with the same w, and the updates keep their ascending order, so the bits do not
+                # depend on the grouping)
                 basis = [kb(k) for k in range(j + 1)]
-                h = pl.multi_dot(basis, kb(j + 1))
+                group = pl.get_context().backend.MULTI_MAX
+                hs = [pl.multi_dot(basis[g:g + group], kb(j + 1)) for g in range(0, j + 1, group)]
                 for k in range(j + 1):
-                    self.inner_products[k][j] = Scalar(pl.get_context(), h[k:k + 1])
-                pl.multi_axpy(kb(j + 1), h, basis, negate=True)
+                    h = hs[k // group]
+                    self.inner_products[k][j] = Scalar(pl.get_context(), h[k % group:k % group + 1])
+                for g, h in zip(range(0, j + 1, group), hs):
+                    pl.multi_axpy(kb(j + 1), h, basis[g:g + group], negate=True)
             else:
                 for k in range(j + 1):
                     self.inner_products[k][j] = pl.dot(kb(k), kb(j + 1))

@@ -197,3 +197,59 @@ def test_coo_binned_declines_and_argument_errors():
         assert y.tolist() == [5.0, 6.0, 7.0]
     finally:
         _lib.call("lsk_coo_binned_destroy", handle)
+
+
+def test_coo_binned_two_live_copies_of_different_sizes():
+    """The kernels' limit on dynamic LDS belongs to the kernel, not to a copy: a copy with the largest
+    blocks and tiles (160 KiB of LDS in both passes), then a second live copy with small ones, then a
+    product on the large one again -- and a block count beyond what one capped set-up grid covers."""
+    rng = np.random.default_rng(64)
+    n_rows, n_cols, nnz = 50000, 45000, 400000
+    r = rng.integers(0, n_rows, nnz).astype(np.int64)
+    c = rng.integers(0, n_cols, nnz).astype(np.int64)
+    v = rng.standard_normal(nnz)
+    x = rng.standard_normal(n_cols)
+    want = np.zeros(n_rows)
+    oracle.coo_matvec(r, c, v, x, 0, n_cols - 1, want, 0, n_rows - 1)
+    bound = np.zeros(n_rows)
+    oracle.coo_matvec(r, c, np.abs(v), np.abs(x), 0, n_cols - 1, bound, 0, n_rows - 1)
+    rd, cd, vd, xd = dev(r), dev(c), dev(v), dev(x)
+    r32, c32 = compress(rd, 0, n_rows - 1), compress(cd, 0, n_cols - 1)
+    print("case coo_binned two live copies: 20472 x 20472, then 64 x 64", flush=True)
+    code, large = make("f64", r32, c32, vd, 0, n_rows - 1, n_cols, 20472, 20472)
+    assert code == _lib.LSK_OK, _lib.lib().lsk_last_error()
+    code, small = make("f64", r32, c32, vd, 0, n_rows - 1, n_cols, 64, 64)
+    assert code == _lib.LSK_OK, _lib.lib().lsk_last_error()
+    try:
+        for handle in (large, small, large):
+            yd = torch.full((n_rows,), 3.0, dtype=torch.float64, device="cuda")
+            _lib.call("lsk_coo_binned_spmv_f64", handle, P(xd), P(yd), 0, stream())
+            err = np.abs(yd.cpu().numpy() - want)
+            assert np.all(err <= 1e-13 * (bound + 1e-300)), float(err.max())
+    finally:
+        _lib.call("lsk_coo_binned_destroy", small)
+        _lib.call("lsk_coo_binned_destroy", large)
+    # blocks of 8 columns over a wide window with one tile: 2^23 + 1 blocks, more than the 2^23 threads of
+    # the capped set-up grid
+    n_cols2 = 8 * (1 << 23) + 8
+    nnz2 = 20000
+    r2 = rng.integers(0, 100, nnz2).astype(np.int64)
+    c2 = np.sort(rng.integers(0, n_cols2, nnz2)).astype(np.int64)
+    c2[-3:] = n_cols2 - 1 - np.arange(3)             # entries in the very last block
+    v2 = rng.standard_normal(nnz2)
+    print(f"case coo_binned {n_cols2 // 8} blocks of 8 columns", flush=True)
+    x2 = torch.randn(n_cols2, dtype=torch.float64, device="cuda")
+    code, wide = make("f64", compress(dev(r2), 0, 99), compress(dev(c2), 0, n_cols2 - 1), dev(v2), 0, 99, n_cols2, 8, 104)
+    assert code == _lib.LSK_OK, _lib.lib().lsk_last_error()
+    try:
+        assert info(wide)["blocks"] == n_cols2 // 8 and info(wide)["live"] == nnz2
+        yd = torch.zeros(100, dtype=torch.float64, device="cuda")
+        _lib.call("lsk_coo_binned_spmv_f64", wide, P(x2), P(yd), 0, stream())
+        xh = x2.cpu().numpy()
+        want2 = np.zeros(100)
+        oracle.coo_matvec(r2, c2, v2, xh, 0, n_cols2 - 1, want2, 0, 99)
+        bound2 = np.zeros(100)
+        oracle.coo_matvec(r2, c2, np.abs(v2), np.abs(xh), 0, n_cols2 - 1, bound2, 0, 99)
+        assert np.all(np.abs(yd.cpu().numpy() - want2) <= 1e-13 * (bound2 + 1e-300))
+    finally:
+        _lib.call("lsk_coo_binned_destroy", wide)

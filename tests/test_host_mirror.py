@@ -159,6 +159,22 @@ def test_classical_gram_schmidt_gmres_matches_its_oracle(ctx, dtype, spaces):
         GMRESSolver(mpl, 4, "householder")
 
 
+def test_classical_gram_schmidt_takes_restarts_beyond_one_multi_dot_call(ctx, monkeypatch):
+    """A sweep over more basis vectors than one multi_dot / multi_axpy call takes runs in groups: every
+    inner product still from the same w, the updates in the same chain, so the same bits as the oracle."""
+    rects, row, col, val, n = hc.stencil_problem(2, (6, 7), np.float64)
+    rhs = np.random.default_rng(3).standard_normal(n)
+    opl = hc.oracle_planner("csr", rects, row, col, val, n, 3, np.float64, rhs)
+    mpl = hc.mirror_planner(ctx, "csr", rects, row, col, val, n, 3, np.float64, rhs)
+    monkeypatch.setattr(type(ctx.backend), "MULTI_MAX", 3)
+    so, sm = S.GMRESSolver(opl, 8, "classical"), GMRESSolver(mpl, 8, "classical")
+    for _ in range(2):
+        so.step()
+        sm.step()
+    np.testing.assert_array_equal(hc.gather_vector(ctx, mpl.get_vector(0, 0)), opl.get_vector(0, 0))
+    assert [[s.get_value() for s in r] for r in sm.inner_products] == [[float(v) for v in r] for r in so.inner_products]
+
+
 @pytest.mark.parametrize("kind", ["csr", "coo"])
 @pytest.mark.parametrize("pieces", [1, 3])
 def test_transposed_product_matches_oracle(ctx, kind, pieces, monkeypatch):
