@@ -145,7 +145,7 @@ def test_coo_against_csr_at_full_random_size(gpu_ctx, rows):
     rects {32 r, 32 r + 31}; the COO kernel (atomics) and the CSR kernel must agree."""
     from conftest import require_device_memory
     per_row = 32
-    require_device_memory(40, f"random COO against CSR at {rows} rows x {per_row} entries")
+    require_device_memory(60, f"random COO (scan kernel and binned copy) against CSR at {rows} rows x {per_row} entries")
     nnz = rows * per_row
     print(f"case coo vs csr random rows={rows} nnz={nnz}", flush=True)
     g = torch.Generator(device="cuda").manual_seed(20250310)
@@ -180,6 +180,30 @@ def test_coo_against_csr_at_full_random_size(gpu_ctx, rows):
     oracle.coo_matvec(row[:take].cpu().numpy(), col[:take].cpu().numpy(), val[:take].cpu().numpy(),
                       x.owned.cpu().numpy(), 0, rows - 1, want, 0, 4095)
     np.testing.assert_allclose(y_coo.owned[:4096].cpu().numpy(), want, rtol=0, atol=1e-13 * scale)
+    # The form the planner picks for this matrix and the benchmark's BiCGStab steps run on: the binned copy
+    # (954 blocks of 16384 columns x 768 tiles of 20352 rows, 32-bit positions up to 5e8), beta = 0 and 1,
+    # to the same bar; and again after the values were rewritten in place.
+    del coo, y_coo
+    be = gpu_ctx.backend
+    row32, col32 = be.csr_compress_cols(row, 0, rows - 1), be.csr_compress_cols(col, 0, rows - 1)
+    del row
+    print(f"case binned coo copy at full size rows={rows} nnz={nnz}", flush=True)
+    binned = be.coo_binned_create(row32, col32, val, 0, rows - 1, rows)
+    assert binned is not None
+    try:
+        assert binned.live == nnz and binned.blocks == -(-rows // binned.block_cols) and binned.tiles * binned.tile_rows >= rows
+        assert binned.padded_entries < 1.01 * nnz and binned.segments <= binned.blocks * binned.tiles
+        y_bin = torch.full((rows,), 5.0, dtype=torch.float64, device=dev)
+        be.coo_binned_spmv(binned, x.owned, y_bin, 0)
+        assert float((y_bin - y_csr.owned).abs().max()) <= 1e-13 * scale
+        be.coo_binned_spmv(binned, x.owned, y_bin, 1)
+        assert float((y_bin - 2.0 * y_csr.owned).abs().max()) <= 2e-13 * scale
+        val.mul_(-0.375)                                   # exact in binary: the products scale exactly
+        be.coo_binned_update_values(binned, val)
+        be.coo_binned_spmv(binned, x.owned, y_bin, 0)
+        assert float((y_bin + 0.375 * y_csr.owned).abs().max()) <= 1e-13 * scale
+    finally:
+        binned.close()
 
 
 def test_gmres30_7pt_fp32_scaled(gpu_ctx):

@@ -109,7 +109,8 @@ def test_spmv_properties_at_headline_size(gpu_ctx, monkeypatch, n1):
     are positive, A is symmetric (x.Ay == y.Ax), A is linear, and the entry count is
     (3*512-2)^3."""
     from conftest import require_device_memory
-    require_device_memory(150, f"27-point fp64 CSR SpMV properties at {n1}^3 (3 609 741 304 entries)")
+    require_device_memory(190, f"27-point fp64 CSR SpMV properties, two-vector / uniform-coefficient / updated-values "
+                               f"sliced products at {n1}^3 (3 609 741 304 entries)")
     n = n1 ** 3
     print(f"case spmv properties {n1}^3", flush=True)
     dim, offs, cfs = sg.benchmark_stencil(4)
@@ -165,8 +166,64 @@ def test_spmv_properties_at_headline_size(gpu_ctx, monkeypatch, n1):
     assert (s.patterns, s.mixed_blocks, s.masked_waves) == (27, 0, 2 * s.blocks) and s.blocks * s.block_rows == n
     # padding: the two end rows of every grid line have 2/3 of the line's row length (27, 18 or 12)
     assert s.padded_entries == A.nnz + 2 * (9 * (n1 - 2) ** 2 + 6 * 4 * (n1 - 2) + 4 * 4)
-    diff = float((matvec(x).owned - Ax.owned).abs().max())
+    As = matvec(x)
+    diff = float((As.owned - Ax.owned).abs().max())
     assert 0.0 < diff <= 1e-13 * float(Ax.owned.abs().max())
+    # What the benchmark times beyond the plain product, at this size, bit for bit against it:
+    # (a) two right-hand sides in one pass over the values (lsk_csr_sliced_spmv2_*), with the dot shares
+    print(f"case two-vector sliced product {n1}^3", flush=True)
+    from legionsolvers_amd import _lib
+    del Ax
+    x2 = PartitionedVector(gpu_ctx, "x2", ip)
+    x2.owned.copy_(torch.randn(n, generator=g, device="cuda", dtype=torch.float64))
+    As2 = matvec(x2)
+    ya, yb = (torch.full((n,), 9.0, dtype=torch.float64, device="cuda") for _ in range(2))
+    assert be.csr_sliced_spmv2(s, n, [x.owned, x2.owned], [ya, yb], 0) == 0
+    assert torch.equal(ya, As.owned) and torch.equal(yb, As2.owned)
+    slots = be.csr_sliced_dot_slots(s, n)
+    single = [torch.empty(slots, dtype=torch.float64, device="cuda") for _ in range(2)]
+    pair = [torch.empty(slots, dtype=torch.float64, device="cuda") for _ in range(2)]
+    ya.fill_(9.0), yb.fill_(9.0)
+    for xv, out in ((x, single[0]), (x2, single[1])):
+        scratch = torch.empty(n, dtype=torch.float64, device="cuda")
+        assert be.csr_sliced_spmv_dot(s, n, xv.owned, scratch, 0, xv.owned, out) == slots
+        assert torch.equal(scratch, As.owned if xv is x else As2.owned)
+        del scratch
+    assert be.csr_sliced_spmv2(s, n, [x.owned, x2.owned], [ya, yb], 0, [x.owned, x2.owned], pair) == slots
+    assert torch.equal(ya, As.owned) and torch.equal(yb, As2.owned)
+    assert torch.equal(pair[0], single[0]) and torch.equal(pair[1], single[1])
+    del yb, As2, x2, single, pair
+    # (b) the values as scalars (option sliced.uniform): the matrix is a constant-coefficient stencil
+    print(f"case uniform-coefficient sliced product {n1}^3", flush=True)
+    assert s.uniform_values
+    _lib.call("lsk_set_option", b"sliced.uniform", 1)
+    try:
+        ya.fill_(9.0)
+        be.csr_sliced_spmv(s, 0, n, x.owned, ya, 0)
+        assert torch.equal(ya, As.owned)
+        # (c) values rewritten in place, then update_values: equal to a fresh copy of the new values; the
+        # coefficients are no longer uniform, and the option falls back to reading them
+        print(f"case update_values {n1}^3", flush=True)
+        chunk = 1 << 28
+        for a in range(0, A.nnz, chunk):
+            piece = A.val[a:a + chunk]
+            piece.mul_(torch.rand(piece.numel(), generator=g, device="cuda", dtype=torch.float64) + 0.5)
+            del piece
+        A.values_changed()
+        assert not s.uniform_values
+        be.csr_sliced_spmv(s, 0, n, x.owned, ya, 0)
+    finally:
+        _lib.call("lsk_set_option", b"sliced.uniform", 0)
+    fresh = be.csr_sliced_create(n, A.nnz, A.rects, 0, A.col, A.val, 0, 0, n - 1)
+    assert fresh is not None
+    try:
+        y_fresh = torch.full((n,), 9.0, dtype=torch.float64, device="cuda")
+        be.csr_sliced_spmv(fresh, 0, n, x.owned, y_fresh, 0)
+        assert torch.equal(ya, y_fresh) and not torch.equal(ya, As.owned)
+        be.csr_sliced_spmv(s, 0, n, x.owned, ya, 0)          # and without the option
+        assert torch.equal(ya, y_fresh)
+    finally:
+        fresh.close()
 
 
 @pytest.mark.parametrize("sliced", ["0", "1"])
@@ -176,6 +233,7 @@ def test_cg_with_tuned_placement(gpu_ctx, monkeypatch, sliced):
     one on the sliced-pattern copy: same CG history as the oracle, whatever placement it picks."""
     from legionsolvers_amd import CSRMatrix
     monkeypatch.setattr(CSRMatrix, "TUNE_MIN_ROWS", 1)
+    monkeypatch.setenv("LSK_TUNE", "2")   # (placement timing is the default; the redraws are opt-in)
     monkeypatch.setenv("LSK_SLICED", sliced)
     rects, row, col, val, n = hc.stencil_problem(4, (16, 16, 16), np.float64)
     rhs = np.random.default_rng(32).standard_normal(n)
