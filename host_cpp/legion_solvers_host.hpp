@@ -46,6 +46,7 @@ template <typename T> struct Abi;
         static constexpr auto axpy_xpay_dev = lsk_axpy_xpay_dev_##SUF;                             \
         static constexpr auto csr_spmv = lsk_csr_spmv_##SUF;                                       \
         static constexpr auto csr_spmv_c32 = lsk_csr_spmv_c32_##SUF;                               \
+        static constexpr auto csr_spmv_c32_split = lsk_csr_spmv_c32_split_##SUF;                   \
         static constexpr auto csr_spmv_c32_tune = lsk_csr_spmv_c32_tune_##SUF;                     \
         static constexpr auto csr_spmv_tune = lsk_csr_spmv_tune_##SUF;                             \
         static constexpr auto coo_spmv = lsk_coo_spmv_##SUF;                                       \
@@ -577,9 +578,10 @@ public:
                 continue;
             }
             check(lsk_set_option("xcd_remap", p.placement));
-            if (compressed())
-                check(Abi<T>::csr_spmv_c32(rows, p.nnz, p.rowoff.get(), col32_.get() + p.k_lo, val_.get() + p.k_lo,
-                                           src.data(), domain_, dst.piece(c), beta, ctx_->stream()));
+            if (compressed()) // (p.long_rows: rows too long for one wave go to workgroups of their own; null = none)
+                check(Abi<T>::csr_spmv_c32_split(p.long_rows.get(), 0, rows, p.nnz, p.rowoff.get(), col32_.get() + p.k_lo,
+                                                 val_.get() + p.k_lo, src.data(), domain_, dst.piece(c), beta,
+                                                 ctx_->stream()));
             else
                 check(Abi<T>::csr_spmv(rows, p.nnz, rects_.get() + 2 * range_.piece[c].first, p.k_lo,
                                        col_.get() + p.k_lo, val_.get() + p.k_lo, src.data(), 0, domain_ - 1,
@@ -691,6 +693,10 @@ private:
         int64_t k_lo = 0, nnz = 0;
         int placement = 0; // tile -> XCD placement the library measured fastest for this piece
         DeviceArray<uint32_t> rowoff;
+        struct DestroyLongRows {
+            void operator()(lsk_csr_long_rows_t *plan) const { (void)lsk_csr_long_rows_destroy(plan); }
+        };
+        std::unique_ptr<lsk_csr_long_rows_t, DestroyLongRows> long_rows; // lsk_csr_long_rows_create, where it applies
     };
     // Set-up-time choice of the tile placement, per piece of at least kTuneMinRows rows (the
     // library times a few candidates on the piece itself; a speed hint, results do not depend on it).
@@ -812,11 +818,18 @@ private:
             const int rc = lsk_csr_compress_rows_u32(rows, pieces_[c].nnz, rects_.get() + 2 * range_.piece[c].first,
                                                      pieces_[c].k_lo, off.get(), ctx_->stream());
             if (rc == LSK_ERR_UNSUPPORTED) {
-                for (auto &p : pieces_) p.rowoff = DeviceArray<uint32_t>();
+                for (auto &p : pieces_) {
+                    p.rowoff = DeviceArray<uint32_t>();
+                    p.long_rows.reset();
+                }
                 return;
             }
             check(rc);
             pieces_[c].rowoff = std::move(off);
+            lsk_csr_long_rows_t *plan = nullptr;
+            const int lrc = lsk_csr_long_rows_create(rows, pieces_[c].rowoff.get(), 0, ctx_->stream(), &plan);
+            if (lrc != LSK_ERR_UNSUPPORTED) check(lrc); // unsupported: no row beyond a few thousand entries
+            pieces_[c].long_rows.reset(plan);
         }
         col32_ = std::move(col32);
     }

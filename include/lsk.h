@@ -407,6 +407,34 @@ int lsk_csr_spmv_c32_tune_f64(int64_t rows, int64_t nnz, const uint32_t *rowoff3
                               int64_t x_extent, double *y, lsk_stream_t stream, int *remap_out,
                               float *ms_out);
 
+/* Rows far longer than the mean (a power-law row-length distribution).  The reference hands every
+ * matrix to cusparseSpMV(CUSPARSE_SPMV_ALG_DEFAULT), which balances any distribution inside the
+ * library (src/CSRMatrixTasks.cu:117-150).  lsk_csr_spmv_* / lsk_csr_spmv_c32_* give every wave a fixed
+ * number of rows and stream a row that is too long for a wave's LDS buffer through that buffer, which
+ * is right for any matrix but leaves a row of 10^5 .. 10^6 entries to ONE wave.  For such pieces:
+ *   lsk_csr_long_rows_create: from a piece's rowoff32 (rows + 1 offsets, lsk_csr_compress_rows_u32) the
+ *     list of rows longer than `threshold` entries (0: the library's 8192; at least 2048), each cut into
+ *     chunks of 8192 entries.  LSK_ERR_UNSUPPORTED (never aborts) when no row is that long: the caller
+ *     stays with lsk_csr_spmv_c32_*.  Blocks; uses the library's per-device scratch.
+ *   lsk_csr_spmv_c32_split_*: lsk_csr_spmv_c32_* for the rows row_begin .. row_begin + rows - 1 of that
+ *     piece (rowoff32 and y those of row_begin; col32, val, x, nnz as there) with the listed rows left
+ *     out of the tile kernel and multiplied one workgroup per chunk, a row's chunk sums added in chunk
+ *     order by one more small kernel: the same bits on every call, whatever the hardware schedules.
+ *     All other rows get exactly what lsk_csr_spmv_c32_* gives them.  plan = NULL: lsk_csr_spmv_c32_*.
+ *     The chunk sums live in the plan: products through one plan are ordered on one stream.
+ *   lsk_csr_long_rows_info: out4 = {listed rows, chunks, threshold, entries per chunk}. */
+typedef struct lsk_csr_long_rows lsk_csr_long_rows_t;
+int lsk_csr_long_rows_create(int64_t rows, const uint32_t *rowoff32, int64_t threshold, lsk_stream_t stream,
+                             lsk_csr_long_rows_t **out);
+int lsk_csr_long_rows_info(const lsk_csr_long_rows_t *plan, int64_t *out4);
+int lsk_csr_long_rows_destroy(lsk_csr_long_rows_t *plan);
+int lsk_csr_spmv_c32_split_f32(const lsk_csr_long_rows_t *plan, int64_t row_begin, int64_t rows, int64_t nnz,
+                               const uint32_t *rowoff32, const uint32_t *col32, const float *val, const float *x,
+                               int64_t x_extent, float *y, int beta, lsk_stream_t stream);
+int lsk_csr_spmv_c32_split_f64(const lsk_csr_long_rows_t *plan, int64_t row_begin, int64_t rows, int64_t nnz,
+                               const uint32_t *rowoff32, const uint32_t *col32, const double *val, const double *x,
+                               int64_t x_extent, double *y, int beta, lsk_stream_t stream);
+
 /* indptr[i] = rects[i].lo - rects[0].lo for i < rows; indptr[rows] = rects[rows-1].hi + 1
  * - rects[0].lo.  Bit-exact restatement of convertGlobalRowptrToLocalIndPtr
  * (src/CuSPARSEHelpers.hpp:9-31) for callers that want a classic CSR offset array; the

@@ -110,6 +110,11 @@ PROTOTYPES = {
     "lsk_coo_binned_update_values_f64": (_i, [_p, _i64, _p, _p]),
     "lsk_coo_binned_info": (_i, [_p, _p]),
     "lsk_coo_binned_destroy": (_i, [_p]),
+    "lsk_csr_long_rows_create": (_i, [_i64, _p, _i64, _p, _p]),
+    "lsk_csr_long_rows_info": (_i, [_p, _p]),
+    "lsk_csr_long_rows_destroy": (_i, [_p]),
+    "lsk_csr_spmv_c32_split_f32": (_i, [_p, _i64, _i64, _i64, _p, _p, _p, _p, _i64, _p, _i, _p]),
+    "lsk_csr_spmv_c32_split_f64": (_i, [_p, _i64, _i64, _i64, _p, _p, _p, _p, _i64, _p, _i, _p]),
     "lsk_csr_entry_rows_u32": (_i, [_i64, _i64, _p, _i64, _p, _p]),
     "lsk_sorted_key_offsets_u32": (_i, [_i64, _p, _i64, _p, _p]),
     "lsk_inclusive_sum_i64": (_i, [_i64, _p, _p, _p]),

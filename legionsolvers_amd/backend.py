@@ -200,6 +200,27 @@ class HipBackend:
         _lib.call(f"lsk_csr_spmv_{_lib.suffix(val.dtype)}", rows, nnz, _ptr(rects), k_base, _ptr(col),
                   _ptr(val), _ptr(x), x_lo, x_hi, _ptr(y), beta, self.stream())
 
+    def csr_long_rows_create(self, rowoff: torch.Tensor, threshold: int = 0):
+        """The plan for the rows of a piece that are too long for one wave (a LongRows), from the piece's
+        rows + 1 32-bit offsets (csr_compress_rows); None when no row is longer than the threshold (0:
+        the library's).  Synchronises."""
+        handle = ctypes.c_void_p(0)
+        code = self.lib.lsk_csr_long_rows_create(rowoff.numel() - 1, _ptr(rowoff), threshold, self.stream(),
+                                                 ctypes.byref(handle))
+        if code == _lib.LSK_ERR_UNSUPPORTED:
+            return None
+        _lib.check(code)
+        return LongRows(self.lib, handle)
+
+    def csr_spmv_split(self, plan: "LongRows", row_begin: int, rows: int, nnz: int, rowoff: torch.Tensor,
+                       col32: torch.Tensor, val: torch.Tensor, x: torch.Tensor, x_lo: int, x_hi: int, y: torch.Tensor,
+                       beta: int, placement: int = 0) -> None:
+        """csr_spmv on the 32-bit structure for the rows row_begin .. row_begin + rows - 1 of the plan's
+        piece (rowoff, y: those rows'), the rows the plan lists multiplied in chunks by workgroups of their own."""
+        self._place(placement)
+        _lib.call(f"lsk_csr_spmv_c32_split_{_lib.suffix(val.dtype)}", plan.handle, row_begin, rows, nnz, _ptr(rowoff),
+                  _ptr(col32), _ptr(val), _ptr(x), x_hi - x_lo + 1, _ptr(y), beta, self.stream())
+
     def csr_sliced_create(self, rows: int, nnz: int, rects: torch.Tensor, k_base: int, col: torch.Tensor,
                           val: torch.Tensor, row_first: int, x_lo: int, x_hi: int):
         """The sliced-pattern copy of a CSR piece for products against the window x_lo..x_hi (a
@@ -421,6 +442,27 @@ class HipBackend:
         if not bool(live.any()):
             return (0, -1)
         return int(lo[live].min().item()), int(hi[live].max().item())
+
+
+class LongRows:
+    """Owner of one lsk_csr_long_rows_t (device memory held by the library, freed with this object)."""
+
+    def __init__(self, lib, handle):
+        self.lib, self.handle = lib, handle
+        out = (ctypes.c_int64 * 4)()
+        _lib.check(lib.lsk_csr_long_rows_info(handle, out))
+        self.long_rows, self.chunks, self.threshold, self.chunk_entries = (int(v) for v in out)
+
+    def close(self) -> None:
+        if self.handle:
+            self.lib.lsk_csr_long_rows_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class BinnedCoo:

@@ -29,7 +29,23 @@
 #include <cstdio>
 #include <cstdlib>
 
+#include <hipcub/hipcub.hpp>
+
 #include "lsk_common.hpp"
+
+// The rows of a piece that are too long for one wave (lsk_csr_long_rows_create): each is cut into
+// chunks of kLongChunk entries that one workgroup multiplies, and a last small kernel adds a row's
+// chunk sums in chunk order.  Row indices count from the piece's first row, entries from its first entry.
+struct lsk_csr_long_rows {
+    int64_t rows = 0;            // rows of the piece the plan was made for
+    int64_t nlong = 0;           // rows longer than `threshold`
+    int64_t chunks = 0;          // chunks of all of them together
+    int threshold = 0;
+    uint32_t *row = nullptr;         // nlong: the long rows, ascending
+    uint32_t *chunk_first = nullptr; // nlong + 1: first chunk of every long row
+    uint32_t *chunk_row = nullptr;   // chunks: which long row (0 .. nlong) a chunk belongs to
+    void *partial = nullptr;         // chunks sums, 8 bytes each (products through one plan are ordered on one stream)
+};
 
 namespace {
 
@@ -283,12 +299,13 @@ __device__ void wave_rows_direct(int nr, const typename RowField<CT>::type *__re
                                  int64_t nnz, const CT *__restrict__ col,
                                  const T *__restrict__ val, const T *__restrict__ x, int64_t x_lo,
                                  int64_t x_hi, T *__restrict__ y, int beta,
-                                 const T *__restrict__ w = nullptr, T *dot_acc = nullptr) {
+                                 const T *__restrict__ w = nullptr, T *dot_acc = nullptr, int skip_len = 0) {
     const int lane = threadIdx.x % lsk::kWave;
     for (int r = 0; r < nr; ++r) {
         T acc = T(0);
         int64_t lo, hi;
         RowField<CT>::bounds(rects, r, k_base, nnz, lo, hi);
+        if (skip_len > 0 && hi - lo + 1 > skip_len) continue; // the split product's own kernels take this row
         for (int64_t k = lo + lane; k <= hi; k += lsk::kWave) {
             const CT c = col[k - k_base];
             if (ColOps<CT>::in(c, x_lo, x_hi)) acc = fma_t(val[k - k_base], x[ColOps<CT>::off(c, x_lo)], acc);
@@ -490,6 +507,26 @@ __device__ __forceinline__ T fold_range(const T *__restrict__ sp, int e0, int e1
     return acc;
 }
 
+// A row of n entries that is longer than the wave's LDS buffer: streamed through the buffer a
+// bufferful at a time with the same wide loads as a batch of rows (all of a bufferful's col / val
+// units in flight, then its gathers), every lane keeping the sum of its own share of the products;
+// returns this lane's share.  Always with 4 units per lane in flight, whatever the tile path uses: the
+// rare path must stay below the tile path's register peak (an out-of-line call costs far more).
+template <typename T, typename CT, bool NT, int CAPW>
+__device__ __forceinline__ T wave_long_row(int lane, int n, const T *__restrict__ valb,
+                                                     const CT *__restrict__ colb, const T *__restrict__ x,
+                                                     int64_t x_lo, int64_t x_hi, T *__restrict__ sp) {
+    T acc = T(0);
+    for (int s0 = 0; s0 < n; s0 += CAPW) {
+        const int len = n - s0 < CAPW ? n - s0 : CAPW;
+        stream_batch<T, CT, NT, 4>(lane, len, valb + s0, colb + s0, x, x_lo, x_hi, sp);
+        wave_lds_fence();
+        acc += fold_range<T, CAPW>(sp, 0, len, lane, lsk::kWave);
+        wave_lds_fence(); // the next bufferful overwrites the buffer
+    }
+    return acc;
+}
+
 // Wave-tile CSR SpMV: every wave owns ROWS = 1 << LOG_ROWS consecutive rows (1..256) and never
 // meets the other waves of its workgroup (no s_barrier), so a wave that waits on HBM never holds
 // up three others.  Per tile:
@@ -514,7 +551,7 @@ __global__ __launch_bounds__(kBlock, LSK_MIN_WAVES) void csr_spmv_wave_kernel( /
     int64_t rows, const typename RowField<CT>::type *__restrict__ rects, int64_t k_base, int64_t nnz,
     const CT *__restrict__ col, const T *__restrict__ val, const T *__restrict__ x,
     int64_t x_lo, int64_t x_hi, T *__restrict__ y, int beta, int remap,
-    const T *__restrict__ w, T *__restrict__ partials) {
+    const T *__restrict__ w, T *__restrict__ partials, int skip_len) {
     constexpr int ROWS = 1 << LOG_ROWS;
     constexpr int RPL = ROWS > lsk::kWave ? ROWS / lsk::kWave : 1; // rects per lane
     constexpr int GW = ROWS < lsk::kWave ? lsk::kWave / ROWS : 1;  // lanes per row in the fold
@@ -603,7 +640,8 @@ __global__ __launch_bounds__(kBlock, LSK_MIN_WAVES) void csr_spmv_wave_kernel( /
     }
     }
     if (!__all(ok)) {
-        wave_rows_direct<T, CT>(nr, rects + r0, k_base, nnz, col, val, x, x_lo, x_hi, y + r0, beta, wt, &dot_acc);
+        wave_rows_direct<T, CT>(nr, rects + r0, k_base, nnz, col, val, x, x_lo, x_hi, y + r0, beta, wt, &dot_acc,
+                                skip_len);
         if (DOT && lane == 0) *my_partial = dot_acc;
         return;
     }
@@ -631,9 +669,21 @@ __global__ __launch_bounds__(kBlock, LSK_MIN_WAVES) void csr_spmv_wave_kernel( /
             const bool fits = row >= ra && row < nr && rel_end[j] - base <= CAPW;
             m += __popcll(__ballot(fits));
         }
-        if (m == 0) { // this row alone is longer than the buffer
-            wave_rows_direct<T, CT>(1, rects + r0 + ra, k_base, nnz, col, val, x, x_lo, x_hi, y + r0 + ra, beta,
-                                DOT ? wt + ra : nullptr, &dot_acc);
+        if (m == 0) {
+            // this row alone is longer than the buffer: streamed through it (wave_long_row)
+            const int n_row = at_row(rel_end, ra) - base;
+            if (skip_len > 0 && n_row > skip_len) { // left to the split product's own kernels (lsk_csr_spmv_c32_split_*)
+                ra += 1;
+                continue;
+            }
+            T acc = wave_long_row<T, CT, NT, CAPW>(lane, n_row, valb + base, colb + base, x, x_lo, x_hi, sp);
+            acc = lsk::wave_sum(acc);
+            if (lane == 0) {
+                T *yp = y + r0 + ra;
+                const T out = beta ? *yp + acc : acc;
+                *yp = out;
+                if constexpr (DOT) dot_acc += out * wt[ra];
+            }
             ra += 1;
             continue;
         }
@@ -708,7 +758,7 @@ template <typename T, typename CT = int64_t>
 int launch_csr_spmv(const char *name, int64_t rows, int64_t nnz, const void *rects,
                     int64_t k_base, const CT *col, const T *val, const T *x, int64_t x_lo,
                     int64_t x_hi, T *y, int beta, lsk_stream_t stream, const T *w = nullptr,
-                    T *partials = nullptr, int64_t capacity = 0, int64_t *count = nullptr) {
+                    T *partials = nullptr, int64_t capacity = 0, int64_t *count = nullptr, int skip_len = 0) {
     const bool fused = (w != nullptr);
     if (fused) {
         if (!partials || !count) return lsk::fail(LSK_ERR_ARG, "%s: null partials or count", name);
@@ -764,10 +814,10 @@ int launch_csr_spmv(const char *name, int64_t rows, int64_t nnz, const void *rec
         const bool wide = tune.csr_max_units == 0 ? units > 4.0 : tune.csr_max_units == 8;
 #define LSK_CSRW_LAUNCH(L, NT, KMAX)                                                              \
     csr_spmv_wave_kernel<T, CT, L, NT, KMAX, false><<<unsigned(blocks_w), kBlock, 0, s>>>(        \
-        rows, rc, k_base, nnz, col, val, x, x_lo, x_hi, y, beta, lsk::xcd_remap_option(), nullptr, nullptr)
+        rows, rc, k_base, nnz, col, val, x, x_lo, x_hi, y, beta, lsk::xcd_remap_option(), nullptr, nullptr, skip_len)
 #define LSK_CSRW_LAUNCH_DOT(L, KMAX)                                                              \
     csr_spmv_wave_kernel<T, CT, L, false, KMAX, true><<<unsigned(blocks_w), kBlock, 0, s>>>(      \
-        rows, rc, k_base, nnz, col, val, x, x_lo, x_hi, y, beta, lsk::xcd_remap_option(), w, partials)
+        rows, rc, k_base, nnz, col, val, x, x_lo, x_hi, y, beta, lsk::xcd_remap_option(), w, partials, 0)
 #define LSK_CSRW_CASE(L)                                                                          \
     case L:                                                                                       \
         if (fused) {                                                                              \
@@ -927,9 +977,279 @@ int tune_csr_spmv(const char *name, int64_t rows, int64_t nnz, const void *rects
     return LSK_OK;
 }
 
+
+// ---------------------------------------------------------------- rows too long for one wave
+//
+// The wave-tile kernel gives every wave a fixed number of rows; a row of 10^5 or 10^6 entries in a
+// matrix whose mean row has 30 keeps one wave busy for milliseconds after all others have finished.
+// A plan made once per piece lists those rows; the split product leaves them out of the tile kernel,
+// multiplies each in chunks of kLongChunk entries, one workgroup per chunk, and adds a row's chunk sums
+// in chunk order: the result does not depend on how the hardware schedules anything.
+constexpr int kLongThreshold = 8192;    // entries: the default
+constexpr int kLongThresholdMin = 2048; // not below any instance's wave buffer (CAP / 4 <= 1920)
+constexpr int kLongChunk = 8192;
+
+__global__ __launch_bounds__(kBlock) void long_count_kernel(int64_t rows, const uint32_t *__restrict__ off,
+                                                            uint32_t threshold, unsigned int *__restrict__ count) {
+    const int64_t stride = int64_t(gridDim.x) * kBlock;
+    unsigned int mine = 0;
+    for (int64_t r = int64_t(blockIdx.x) * kBlock + threadIdx.x; r < rows; r += stride)
+        mine += (off[r + 1] - off[r] > threshold) ? 1u : 0u;
+    if (mine) atomicAdd(count, mine);
+}
+
+__global__ __launch_bounds__(kBlock) void long_list_kernel(int64_t rows, const uint32_t *__restrict__ off,
+                                                           uint32_t threshold, unsigned int *__restrict__ fill,
+                                                           uint32_t *__restrict__ row_out) {
+    const int64_t stride = int64_t(gridDim.x) * kBlock;
+    for (int64_t r = int64_t(blockIdx.x) * kBlock + threadIdx.x; r < rows; r += stride)
+        if (off[r + 1] - off[r] > threshold) row_out[atomicAdd(fill, 1u)] = static_cast<uint32_t>(r);
+}
+
+// nchunks[q] = chunks of long row q (slot nlong: 0, so that an exclusive sum ends with the total)
+__global__ __launch_bounds__(kBlock) void long_chunks_kernel(int64_t nlong, const uint32_t *__restrict__ row,
+                                                             const uint32_t *__restrict__ off,
+                                                             uint32_t *__restrict__ nchunks) {
+    const int64_t q = int64_t(blockIdx.x) * kBlock + threadIdx.x;
+    if (q > nlong) return;
+    const uint32_t len = q < nlong ? off[row[q] + 1] - off[row[q]] : 0u;
+    nchunks[q] = (len + kLongChunk - 1) / kLongChunk;
+}
+
+__global__ __launch_bounds__(kBlock) void long_chunk_rows_kernel(int64_t nlong, const uint32_t *__restrict__ chunk_first,
+                                                                 uint32_t *__restrict__ chunk_row) {
+    const int64_t q = int64_t(blockIdx.x) * kBlock + threadIdx.x;
+    if (q >= nlong) return;
+    for (uint32_t w = chunk_first[q]; w < chunk_first[q + 1]; ++w) chunk_row[w] = static_cast<uint32_t>(q);
+}
+
+// One chunk of one long row per workgroup: lane t adds the products of the chunk's entries t, t + 256, ...
+// in that order (eight of them in flight), then the lanes of a wave and the four waves are added in a fixed
+// order.  off0: the piece's row offsets (of plan row 0).
+template <typename T>
+__global__ __launch_bounds__(kBlock) void long_chunk_kernel(
+    const uint32_t *__restrict__ lrow, const uint32_t *__restrict__ chunk_first, const uint32_t *__restrict__ chunk_row,
+    const uint32_t *__restrict__ off0, const uint32_t *__restrict__ col, const T *__restrict__ val,
+    const T *__restrict__ x, uint32_t x_last, long long row_begin, long long row_end, T *__restrict__ partial) {
+    __shared__ T s_part[kBlock / lsk::kWave];
+    const uint32_t w = blockIdx.x, q = chunk_row[w], r = lrow[q];
+    if (static_cast<long long>(r) < row_begin || static_cast<long long>(r) >= row_end) return; // uniform
+    const uint32_t lo = off0[r], hi = off0[r + 1];
+    const uint32_t start = lo + (w - chunk_first[q]) * static_cast<uint32_t>(kLongChunk);
+    const uint32_t end = hi - start > static_cast<uint32_t>(kLongChunk) ? start + kLongChunk : hi;
+    constexpr int K = 8;
+    T acc = T(0);
+    for (uint32_t k0 = start + threadIdx.x; k0 < end; k0 += kBlock * K) {
+        T v[K];
+        uint32_t c[K];
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            const uint32_t k = k0 + j * kBlock;
+            const uint32_t kc = k < end ? k : end - 1; // past the end: re-read the last entry, dropped below
+            v[j] = __builtin_nontemporal_load(val + kc);
+            c[j] = __builtin_nontemporal_load(col + kc);
+        }
+        T xv[K];
+#pragma unroll
+        for (int j = 0; j < K; ++j) xv[j] = x[c[j] <= x_last ? c[j] : 0u];
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            const T prod = c[j] <= x_last ? v[j] * xv[j] : T(0); // the CPU body's input-domain guard
+            acc += (k0 + j * kBlock < end) ? prod : T(0);
+        }
+    }
+    acc = lsk::wave_sum(acc);
+    if (threadIdx.x % lsk::kWave == 0) s_part[threadIdx.x / lsk::kWave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        T sum = s_part[0];
+#pragma unroll
+        for (int i = 1; i < kBlock / lsk::kWave; ++i) sum += s_part[i];
+        partial[w] = sum;
+    }
+}
+
+// One wave per long row: its chunk sums in chunk order (lane l takes chunks l, l + 64, ...), then y.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void long_fold_kernel(int64_t nlong, const uint32_t *__restrict__ lrow,
+                                                           const uint32_t *__restrict__ chunk_first,
+                                                           const T *__restrict__ partial, long long row_begin,
+                                                           long long row_end, T *__restrict__ y, int beta) {
+    const int64_t q = int64_t(blockIdx.x) * (kBlock / lsk::kWave) + threadIdx.x / lsk::kWave;
+    if (q >= nlong) return;
+    const long long r = lrow[q];
+    if (r < row_begin || r >= row_end) return;
+    const int lane = threadIdx.x % lsk::kWave;
+    T acc = T(0);
+    for (uint32_t j = chunk_first[q] + lane; j < chunk_first[q + 1]; j += lsk::kWave) acc += partial[j];
+    acc = lsk::wave_sum(acc);
+    if (lane == 0) {
+        T *yp = y + (r - row_begin);
+        *yp = beta ? *yp + acc : acc;
+    }
+}
+
+void release_long_rows(lsk_csr_long_rows *m) {
+    if (!m) return;
+    (void)hipFree(m->row);
+    (void)hipFree(m->chunk_first);
+    (void)hipFree(m->chunk_row);
+    (void)hipFree(m->partial);
+    delete m;
+}
+
+int create_long_rows(int64_t rows, const uint32_t *rowoff, int64_t threshold, lsk_stream_t stream,
+                     lsk_csr_long_rows **out) {
+    const char *name = "lsk_csr_long_rows_create";
+    if (!out) return lsk::fail(LSK_ERR_ARG, "%s: null handle pointer", name);
+    *out = nullptr;
+    if (rows < 0 || threshold < 0) return lsk::fail(LSK_ERR_ARG, "%s: negative size", name);
+    if (threshold == 0) threshold = kLongThreshold;
+    if (threshold < kLongThresholdMin || threshold > 0x3fffffff)
+        return lsk::fail(LSK_ERR_ARG, "%s: threshold %lld (at least %d entries)", name, (long long)threshold, kLongThresholdMin);
+    if (rows == 0) return lsk::decline(LSK_ERR_UNSUPPORTED, "%s: no rows", name);
+    if (!rowoff) return lsk::fail(LSK_ERR_ARG, "%s: null row offsets", name);
+    if (rows > 0xfffffffeLL) return lsk::decline(LSK_ERR_UNSUPPORTED, "%s: %lld rows", name, (long long)rows);
+    hipStream_t s = lsk::as_stream(stream);
+    lsk::DeviceState *st = nullptr;
+    if (int rc = lsk::device_state(&st)) return rc;
+    unsigned int *counter = static_cast<unsigned int *>(st->scratch);
+    const unsigned grid = static_cast<unsigned>(std::min<int64_t>(lsk::ceil_div(rows, kBlock), lsk::kMaxGridBlocks));
+    unsigned int h_count = 0;
+    LSK_HIP(hipMemcpyAsync(counter, &h_count, sizeof(h_count), hipMemcpyHostToDevice, s));
+    long_count_kernel<<<grid, kBlock, 0, s>>>(rows, rowoff, static_cast<uint32_t>(threshold), counter);
+    LSK_LAUNCH_CHECK();
+    LSK_HIP(hipMemcpyAsync(&h_count, counter, sizeof(h_count), hipMemcpyDeviceToHost, s));
+    LSK_HIP(hipStreamSynchronize(s));
+    if (h_count == 0) return lsk::decline(LSK_ERR_UNSUPPORTED, "%s: no row longer than %lld entries", name, (long long)threshold);
+
+    lsk_csr_long_rows *m = new lsk_csr_long_rows;
+    m->rows = rows;
+    m->nlong = h_count;
+    m->threshold = static_cast<int>(threshold);
+    uint32_t *unsorted = nullptr, *nchunks = nullptr;
+    void *temp = nullptr;
+    int status = LSK_OK;
+#define LSK_TRY(expr)                                                                                    \
+    do {                                                                                                 \
+        if (status == LSK_OK) {                                                                          \
+            const hipError_t e_ = (expr);                                                                \
+            if (e_ != hipSuccess) status = lsk::hip_fail(e_, #expr, __FILE__, __LINE__);                 \
+        }                                                                                                \
+    } while (0)
+    const size_t nl = static_cast<size_t>(m->nlong);
+    LSK_TRY(hipMalloc(reinterpret_cast<void **>(&unsorted), nl * sizeof(uint32_t)));
+    LSK_TRY(hipMalloc(reinterpret_cast<void **>(&m->row), nl * sizeof(uint32_t)));
+    LSK_TRY(hipMalloc(reinterpret_cast<void **>(&nchunks), (nl + 1) * sizeof(uint32_t)));
+    LSK_TRY(hipMalloc(reinterpret_cast<void **>(&m->chunk_first), (nl + 1) * sizeof(uint32_t)));
+    unsigned int zero = 0;
+    LSK_TRY(hipMemcpyAsync(counter, &zero, sizeof(zero), hipMemcpyHostToDevice, s));
+    if (status == LSK_OK) {
+        long_list_kernel<<<grid, kBlock, 0, s>>>(rows, rowoff, static_cast<uint32_t>(threshold), counter, unsorted);
+        LSK_TRY(hipGetLastError());
+    }
+    size_t sort_bytes = 0, scan_bytes = 0;
+    LSK_TRY(hipcub::DeviceRadixSort::SortKeys(nullptr, sort_bytes, unsorted, m->row, static_cast<int>(nl), 0, 32, s));
+    LSK_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, nchunks, m->chunk_first, static_cast<int>(nl + 1), s));
+    size_t temp_bytes = std::max(sort_bytes, scan_bytes);
+    LSK_TRY(hipMalloc(&temp, std::max<size_t>(temp_bytes, 1)));
+    size_t tb = temp_bytes;
+    LSK_TRY(hipcub::DeviceRadixSort::SortKeys(temp, tb, unsorted, m->row, static_cast<int>(nl), 0, 32, s));
+    const unsigned lgrid = static_cast<unsigned>(lsk::ceil_div(static_cast<int64_t>(nl) + 1, kBlock));
+    if (status == LSK_OK) {
+        long_chunks_kernel<<<lgrid, kBlock, 0, s>>>(m->nlong, m->row, rowoff, nchunks);
+        LSK_TRY(hipGetLastError());
+    }
+    tb = temp_bytes;
+    LSK_TRY(hipcub::DeviceScan::ExclusiveSum(temp, tb, nchunks, m->chunk_first, static_cast<int>(nl + 1), s));
+    uint32_t h_chunks = 0;
+    LSK_TRY(hipMemcpyAsync(&h_chunks, m->chunk_first + nl, sizeof(h_chunks), hipMemcpyDeviceToHost, s));
+    LSK_TRY(hipStreamSynchronize(s));
+    if (status == LSK_OK) {
+        m->chunks = h_chunks;
+        LSK_TRY(hipMalloc(reinterpret_cast<void **>(&m->chunk_row), std::max<size_t>(h_chunks, 1) * sizeof(uint32_t)));
+        LSK_TRY(hipMalloc(&m->partial, std::max<size_t>(h_chunks, 1) * 8));
+    }
+    if (status == LSK_OK) {
+        long_chunk_rows_kernel<<<lgrid, kBlock, 0, s>>>(m->nlong, m->chunk_first, m->chunk_row);
+        LSK_TRY(hipGetLastError());
+    }
+    LSK_TRY(hipStreamSynchronize(s)); // set-up time: the scratch is freed before returning
+#undef LSK_TRY
+    (void)hipFree(unsorted);
+    (void)hipFree(nchunks);
+    (void)hipFree(temp);
+    if (status != LSK_OK) {
+        release_long_rows(m);
+        return status;
+    }
+    *out = m;
+    return LSK_OK;
+}
+
+// The product of rows row_begin .. row_begin + rows - 1 of the plan's piece; rowoff and y are those of
+// row_begin, col32 / val / x the piece's.
+template <typename T>
+int spmv_c32_split(const char *name, const lsk_csr_long_rows *plan, int64_t row_begin, int64_t rows, int64_t nnz,
+                   const uint32_t *rowoff, const uint32_t *col32, const T *val, const T *x, int64_t x_extent, T *y,
+                   int beta, lsk_stream_t stream) {
+    if (x_extent < 0 || x_extent > 0xffffffffLL) return lsk::fail(LSK_ERR_ARG, "%s: window of %lld columns", name, (long long)x_extent);
+    if (nnz > 0xffffffffLL) return lsk::fail(LSK_ERR_ARG, "%s: %lld entries", name, (long long)nnz);
+    if (!plan)
+        return launch_csr_spmv<T, uint32_t>(name, rows, nnz, rowoff, 0, col32, val, x, 0, x_extent - 1, y, beta, stream);
+    if (row_begin < 0 || rows < 0 || row_begin + rows > plan->rows)
+        return lsk::fail(LSK_ERR_ARG, "%s: rows %lld .. %lld of a plan made for %lld rows", name, (long long)row_begin,
+                         (long long)(row_begin + rows - 1), (long long)plan->rows);
+    const int rc = launch_csr_spmv<T, uint32_t>(name, rows, nnz, rowoff, 0, col32, val, x, 0, x_extent - 1, y, beta,
+                                                stream, nullptr, nullptr, 0, nullptr, plan->threshold);
+    if (rc != LSK_OK || rows == 0 || x_extent == 0 || plan->chunks == 0) return rc; // (an empty window admits no entry)
+    hipStream_t s = lsk::as_stream(stream);
+    long_chunk_kernel<T><<<static_cast<unsigned>(plan->chunks), kBlock, 0, s>>>(
+        plan->row, plan->chunk_first, plan->chunk_row, rowoff - row_begin, col32, val, x,
+        static_cast<uint32_t>(x_extent - 1), row_begin, row_begin + rows, static_cast<T *>(plan->partial));
+    LSK_LAUNCH_CHECK();
+    long_fold_kernel<T><<<static_cast<unsigned>(lsk::ceil_div(plan->nlong, kBlock / lsk::kWave)), kBlock, 0, s>>>(
+        plan->nlong, plan->row, plan->chunk_first, static_cast<const T *>(plan->partial), row_begin, row_begin + rows, y,
+        beta);
+    LSK_LAUNCH_CHECK();
+    return LSK_OK;
+}
+
 } // namespace
 
 extern "C" {
+
+int lsk_csr_long_rows_create(int64_t rows, const uint32_t *rowoff32, int64_t threshold, lsk_stream_t stream,
+                             lsk_csr_long_rows_t **out) {
+    return create_long_rows(rows, rowoff32, threshold, stream, out);
+}
+
+int lsk_csr_long_rows_info(const lsk_csr_long_rows_t *plan, int64_t *out4) {
+    if (!plan || !out4) return lsk::fail(LSK_ERR_ARG, "lsk_csr_long_rows_info: null pointer");
+    out4[0] = plan->nlong;
+    out4[1] = plan->chunks;
+    out4[2] = plan->threshold;
+    out4[3] = kLongChunk;
+    return LSK_OK;
+}
+
+int lsk_csr_long_rows_destroy(lsk_csr_long_rows_t *plan) {
+    release_long_rows(plan);
+    return LSK_OK;
+}
+
+int lsk_csr_spmv_c32_split_f32(const lsk_csr_long_rows_t *plan, int64_t row_begin, int64_t rows, int64_t nnz,
+                               const uint32_t *rowoff32, const uint32_t *col32, const float *val, const float *x,
+                               int64_t x_extent, float *y, int beta, lsk_stream_t stream) {
+    return spmv_c32_split<float>("lsk_csr_spmv_c32_split_f32", plan, row_begin, rows, nnz, rowoff32, col32, val, x,
+                                 x_extent, y, beta, stream);
+}
+int lsk_csr_spmv_c32_split_f64(const lsk_csr_long_rows_t *plan, int64_t row_begin, int64_t rows, int64_t nnz,
+                               const uint32_t *rowoff32, const uint32_t *col32, const double *val, const double *x,
+                               int64_t x_extent, double *y, int beta, lsk_stream_t stream) {
+    return spmv_c32_split<double>("lsk_csr_spmv_c32_split_f64", plan, row_begin, rows, nnz, rowoff32, col32, val, x,
+                                  x_extent, y, beta, stream);
+}
 
 int64_t lsk_csr_spmv_dot_partials(int64_t rows, int64_t nnz, int elem_size) {
     if (rows <= 0) return 1;

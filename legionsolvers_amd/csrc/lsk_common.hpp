@@ -60,7 +60,10 @@ inline int allow_large_lds(const void *kernel, std::atomic<uint64_t> &done, hipS
     if (capturing != hipStreamCaptureStatusNone)
         return fail(LSK_ERR_UNSUPPORTED, "the first launch of this kernel on device %d raises its LDS limit, which cannot be "
                                          "captured: launch the product once before capturing it", dev);
-    LSK_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsBytes));
+    hipFuncAttributes attr;
+    LSK_HIP(hipFuncGetAttributes(&attr, kernel)); // (what the kernel declares statically counts against the CU's LDS too)
+    LSK_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                kMaxLdsBytes - static_cast<int>(attr.sharedSizeBytes)));
     done.fetch_or(bit, std::memory_order_release);
     return LSK_OK;
 }

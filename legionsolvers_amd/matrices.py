@@ -308,6 +308,7 @@ class CSRMatrix(AbstractMatrix, _SlicedCopies):
         self.col32 = None         # compress(): the column field as 32-bit offsets into ...
         self.col32_window = None  # ... this window (x_lo, x_hi)
         self.rowoff = {}          # ... and per piece colour rows + 1 32-bit offsets of the rows' entries
+        self.long_rows = {}       # ... and, for pieces that have them, the plan for rows too long for one wave
         self._init_sliced()
 
     def values_changed(self) -> None:
@@ -344,6 +345,8 @@ class CSRMatrix(AbstractMatrix, _SlicedCopies):
             return override != "0"
         if self.sliced:
             return True   # one lane owns a row there: the shares cost next to nothing
+        if self.long_rows:
+            return False  # the split product has no form that leaves dot shares
         return self.rows > 0 and self.nnz / self.rows <= self.FUSE_DOT_MAX_ROW_LENGTH
 
     def compress(self, x_lo: int, x_hi: int, kernel_partition, range_partition) -> bool:
@@ -360,7 +363,7 @@ class CSRMatrix(AbstractMatrix, _SlicedCopies):
         if (cols is None or rows_of is None or os.environ.get("LSK_COMPRESS", "1") == "0" or x_hi < x_lo
                 or self.nnz == 0 or x_hi - x_lo + 1 > be.COMPRESS_MAX_EXTENT):
             return False
-        rowoff = {}
+        rowoff, long_rows = {}, {}
         with self._stage("compress_32bit"):
             for i, c in enumerate(kernel_partition.colors):
                 p = range_partition.pieces[c]
@@ -373,7 +376,12 @@ class CSRMatrix(AbstractMatrix, _SlicedCopies):
                 if off is None:
                     return False
                 rowoff[c] = off
-            self.rowoff = rowoff
+                planner = getattr(be, "csr_long_rows_create", None)
+                if planner is not None and os.environ.get("LSK_SPLIT_ROWS", "1") != "0":
+                    plan = planner(off)   # None for nearly every matrix: no row beyond a few thousand entries
+                    if plan is not None:
+                        long_rows[c] = plan
+            self.rowoff, self.long_rows = rowoff, long_rows
             self.col32 = cols(self.col, x_lo, x_hi)
             self.col32_window = (int(x_lo), int(x_hi))
         return True
@@ -625,6 +633,11 @@ class CSRMatrix(AbstractMatrix, _SlicedCopies):
                     else:
                         off, n_arr = (ka - self.k_base) if n_run else 0, n_run
                     # (nnz = the entries of THESE rows: the kernel sizes its tiles by nnz / rows)
+                    if rowf.dtype == torch.int32 and c in self.long_rows:
+                        be.csr_spmv_split(self.long_rows[c], ra, rb - ra, n_run, rowf, col[off:off + n_arr],
+                                          self.val[off:off + n_arr], x, x_lo, x_hi, dst._piece(i)[ra:rb], beta,
+                                          self.placement.get(c, 0))
+                        continue
                     be.csr_spmv(rb - ra, n_run, rowf, ka if n_run else self.k_base,
                                 col[off:off + n_arr], self.val[off:off + n_arr], x, x_lo, x_hi,
                                 dst._piece(i)[ra:rb], beta, self.placement.get(c, 0))
@@ -646,6 +659,9 @@ class CSRMatrix(AbstractMatrix, _SlicedCopies):
             if fused:
                 buf = dst._partials("mv", i, be.csr_spmv_dot_slots(rows, nnz, self.dtype))
                 pieces.append((buf, be.csr_spmv_dot(*args, dot_with._piece(i), buf, self.placement.get(c, 0))))
+            elif rowf.dtype == torch.int32 and c in self.long_rows:
+                be.csr_spmv_split(self.long_rows[c], 0, rows, nnz, rowf, col[off:off + nnz], self.val[off:off + nnz],
+                                  x, x_lo, x_hi, dst._piece(i), beta, self.placement.get(c, 0))
             else:
                 be.csr_spmv(*args, self.placement.get(c, 0))
         if fused and last_phase:

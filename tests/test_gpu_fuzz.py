@@ -41,6 +41,10 @@ def row_lengths(rng, kind, rows):
         return np.minimum(lens, 5000)
     if kind == "long":
         return rng.integers(600, 2500, size=rows)
+    if kind == "power-law":   # mean ~30, a few rows of tens of thousands of entries (many bufferfuls of a wave)
+        lens = (10.0 * rng.random(rows) ** (-1.0 / 1.5)).astype(np.int64)
+        lens[rng.integers(0, rows, size=3)] = rng.integers(20000, 70000, size=3)
+        return np.minimum(lens, 70000)
     if kind == "mostly-empty":
         lens = np.zeros(rows, dtype=np.int64)
         lens[rng.integers(0, rows, size=max(rows // 20, 1))] = rng.integers(1, 50)
@@ -48,7 +52,7 @@ def row_lengths(rng, kind, rows):
     raise ValueError(kind)
 
 
-KINDS = ["tiny", "stencil-like", "uniform", "heavy-tail", "long", "mostly-empty"]
+KINDS = ["tiny", "stencil-like", "uniform", "heavy-tail", "long", "mostly-empty", "power-law"]
 
 
 @pytest.mark.parametrize("suf", ["f32", "f64"])
@@ -58,6 +62,8 @@ def test_spmv_random_structures(gpu_ctx, suf, kind):
     for seed in range(6):
         rng = np.random.default_rng(1000 * KINDS.index(kind) + seed)
         rows = int(rng.integers(1, 40 if kind == "long" else 3000))
+        if kind == "power-law":
+            rows = int(rng.integers(300, 2000))
         n_cols = int(rng.integers(1, 4000))
         lens = row_lengths(rng, kind, rows)
         pre, post = int(rng.integers(0, 50)), int(rng.integers(0, 50))  # the piece sits inside larger arrays
@@ -120,6 +126,42 @@ def test_spmv_random_structures(gpu_ctx, suf, kind):
         _lib.call(f"lsk_csr_spmv_c32_dot_{suf}", rows, nnz, P(off32), P(c32), P(vd), P(xd), x_hi - x_lo + 1, P(yd),
                   beta, P(wd), P(partials), slots, ctypes.byref(count), stream())
         assert torch.equal(yd, got64) and torch.equal(partials, part64)
+        # rows too long for one wave: the split product (one workgroup per chunk of such a row, chunk sums
+        # added in chunk order) -- every other row bit for bit as above, the long ones to the oracle's bar,
+        # the same bits on every call, and a run of rows from the middle of the piece
+        plan = ctypes.c_void_p(0)
+        code = _lib.lib().lsk_csr_long_rows_create(rows, P(off32), 0, stream(), ctypes.byref(plan))
+        assert code == (_lib.LSK_OK if lens.max() > 8192 else _lib.LSK_ERR_UNSUPPORTED), (code, int(lens.max()))
+        if code == _lib.LSK_OK:
+            try:
+                info = (ctypes.c_int64 * 4)()
+                _lib.call("lsk_csr_long_rows_info", plan, info)
+                long_mask = lens > 8192
+                assert (info[0], info[1]) == (int(long_mask.sum()), int(((lens[long_mask] + 8191) // 8192).sum()))
+                split_y = []
+                for _ in range(2):
+                    yd = dev(y0)
+                    _lib.call(f"lsk_csr_spmv_c32_split_{suf}", plan, 0, rows, nnz, P(off32), P(c32), P(vd), P(xd),
+                              x_hi - x_lo + 1, P(yd), beta, stream())
+                    split_y.append(yd)
+                assert torch.equal(split_y[0], split_y[1])
+                short = torch.from_numpy(~long_mask).cuda()
+                assert torch.equal(split_y[0][short], got64[short])
+                err = np.abs(split_y[0].cpu().numpy().astype(np.float64) - want.astype(np.float64))
+                assert np.all(err <= lim), ("split", float(err.max()), int(np.argmax(err - lim)))
+                ra, rb = rows // 3, rows - rows // 4
+                yd = dev(y0)
+                _lib.call(f"lsk_csr_spmv_c32_split_{suf}", plan, ra, rb - ra, int(lens[ra:rb].sum()), P(off32[ra:]), P(c32),
+                          P(vd), P(xd), x_hi - x_lo + 1, P(yd[ra:]), beta, stream())
+                # (a run of rows has tiles of its own, so its ordinary rows agree with the whole product's to
+                # rounding; the listed rows are cut into the same chunks either way)
+                in_run = torch.from_numpy(long_mask & (np.arange(rows) >= ra) & (np.arange(rows) < rb)).cuda()
+                assert torch.equal(yd[in_run], split_y[0][in_run])
+                err = np.abs(yd[ra:rb].cpu().numpy().astype(np.float64) - want[ra:rb].astype(np.float64))
+                assert np.all(err <= lim[ra:rb]), ("split run", float(err.max()))
+                assert torch.equal(yd[:ra].cpu(), torch.from_numpy(y0[:ra])) and torch.equal(yd[rb:].cpu(), torch.from_numpy(y0[rb:]))
+            finally:
+                _lib.call("lsk_csr_long_rows_destroy", plan)
         # the same entries as COO (row-sorted, then shuffled), accumulating into y0
         live = lens.sum()
         if live:

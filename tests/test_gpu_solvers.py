@@ -750,3 +750,48 @@ def test_fused_dot_bets_come_back_after_plain_products(gpu_ctx):
     for _ in range(40):
         solver.step()
     assert pl._fused_dot_used - used >= 15, (used, pl._fused_dot_used, pl._fused_dot_issued)
+
+
+@pytest.mark.parametrize("pieces", [1, 3])
+def test_planner_splits_rows_too_long_for_one_wave(gpu_ctx, monkeypatch, pieces):
+    """A matrix with a power-law row-length distribution through the planner: the pieces that hold rows of
+    tens of thousands of entries get the long-row plan at set-up, every product goes through the split
+    product, and CG-shaped planner calls (product, dot, axpy) follow the oracle; LSK_SPLIT_ROWS=0 gives the
+    plain product and the same values to rounding."""
+    rng = np.random.default_rng(71)
+    n = 2400
+    lens = np.minimum((10.0 * rng.random(n) ** (-1.0 / 1.5)).astype(np.int64), n)
+    lens[[5, 1300, 2399]] = [2400, 2100, 1999]
+    lens = np.repeat(lens, 1)
+    # rows of up to 2400 entries are not "long" for the library's 8192: tile the pattern to make them so
+    reps = 5
+    starts = np.concatenate([[0], np.cumsum(lens * reps)])
+    rects = np.stack([starts[:-1], starts[1:] - 1], axis=1).astype(np.int64)
+    nnz = int(starts[-1])
+    col = rng.integers(0, n, size=nnz).astype(np.int64)
+    val = rng.standard_normal(nnz)
+    row = np.repeat(np.arange(n, dtype=np.int64), lens * reps)
+    rhs = rng.standard_normal(n)
+    print(f"case planner long rows pieces={pieces} nnz={nnz} longest={int((lens * reps).max())}", flush=True)
+    results = []
+    for split in ("1", "0"):
+        monkeypatch.setenv("LSK_SPLIT_ROWS", split)
+        opl = hc.oracle_planner("csr", rects, row, col, val, n, pieces, np.float64, rhs)
+        mpl = hc.mirror_planner(gpu_ctx, "csr", rects, row, col, val, n, pieces, np.float64, rhs)
+        matrix = mpl.row_partitioned_matrices[0].matrix
+        assert not matrix.sliced and matrix.col32 is not None
+        assert bool(matrix.long_rows) == (split == "1")
+        if split == "1":
+            assert sum(p.long_rows for p in matrix.long_rows.values()) == int((lens * reps > 8192).sum()) >= 3
+            assert not matrix.fuses_dot()
+        opl.allocate_workspace(2)
+        mpl.allocate_workspace(2)
+        for pl in (opl, mpl):
+            pl.matvec(2, 1)                  # w2 <- A rhs
+            pl.matvec(3, 2)                  # w3 <- A w2
+            pl.axpy(3, pl.dot(2, 3), 1)      # w3 += (w2 . w3) rhs
+        want = opl.get_vector(3, 0)
+        got = mpl.get_vector(3, 0).to_host().numpy()
+        assert np.abs(got - want).max() <= 1e-11 * np.abs(want).max()
+        results.append(got)
+    assert np.abs(results[0] - results[1]).max() <= 1e-11 * np.abs(results[0]).max()
