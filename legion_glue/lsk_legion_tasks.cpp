@@ -7,26 +7,41 @@
 // (TaskBaseClasses.hpp, LegionUtilities.hpp, ...), neither of which is available where liblsk.so
 // is built.  It is the stub a LegionSolvers maintainer adds, together with three widened
 // preprocessor guards (src/TaskBaseClasses.hpp:211,304, src/LegionUtilities.hpp:68,
-// src/Initialize.cpp:14,484: `LEGION_USE_CUDA` -> `LEGION_USE_CUDA || LEGION_USE_HIP`) and a
-// `Legion_USE_HIP` branch in CMakeLists.txt that adds this file and links liblsk.so in place of
-// cudart/cublas/cusparse (CMakeLists.txt:35-60).  The member names keep the
+// src/Initialize.cpp:14,484: `LEGION_USE_CUDA` -> `LEGION_USE_CUDA || LEGION_USE_HIP`) and the
+// `Legion_USE_HIP` branch of legion_glue/LegionUseHIP.cmake, which adds this file and links liblsk.so
+// in place of cudart/cublas/cusparse (CMakeLists.txt:35-60).  The member names keep the
 // reference's `cuda_task_body`, because that is the name TaskTDI::preregister and
 // HasCUDAVariantMixin look for (src/TaskBaseClasses.hpp:211-223, src/MetaprogrammingUtilities.hpp:
 // 123-145).
+//
+// What it takes from Legion / Realm beyond what the reference's own .cu files use.  These are ASSUMED,
+// by analogy with the CUDA module the reference calls (realm/cuda/cuda_module.h, used at
+// src/CUDAUtilities.cpp:7,70-74), and have to be checked against the Legion that is installed:
+//   #include <realm/hip/hip_module.h>
+//   Realm::Runtime::get_runtime().get_module<Realm::Hip::HipModule>("hip")
+//   Realm::Hip::HipModule::get_task_hip_stream()          (CUDA: get_task_cuda_stream)
+//   Realm::Hip::HipModule::set_task_ctxsync_required(bool) (CUDA: the same name)
+//   hipGetDevice() inside a TOC_PROC task naming the processor's GPU (Realm makes it current, as the
+//     CUDA module does for cudaGetDevice)
+// Everything else (accessors, get_bounds, task->futures, preregister_task) is what the reference's
+// CPU and CUDA bodies already use.
 #include <cstdlib>
 #include <map>
 #include <mutex>
 #include <utility>
 
+#include <hip/hip_runtime_api.h>
 #include <legion.h>
 #include <realm/hip/hip_module.h>
 
 #include "COOMatrixTasks.hpp"
 #include "CSRMatrixTasks.hpp"
+#include "CudaLibs.hpp"   // LoadCUDALibsTask (its includes of cuda_runtime / cublas / cusparse go behind the widened guard)
 #include "LegionUtilities.hpp"
 #include "LinearAlgebraTasks.hpp"
 
 #include "lsk.h"
+#include "lsk_legion.h"
 
 namespace LegionSolvers {
 
@@ -166,7 +181,7 @@ const lsk_csr_sliced_t *sliced_structure(const int64_t *rects, int64_t rows, int
 
 } // namespace
 
-// See the note above sliced_table.
+// See the note above sliced_table; declared in legion_glue/lsk_legion.h.
 void lsk_legion_matrix_values_changed(const void *col_ptr) {
     std::lock_guard<std::mutex> lock(table_mutex);
     for (auto &entry : sliced_table)
@@ -304,13 +319,72 @@ void COOMatvecTask<LEGION_SOLVERS_KDR_TEMPLATE_ARGS>::cuda_task_body(LEGION_SOLV
         reinterpret_cast<ENTRY_T *>(y.ptr(out_bounds.lo)), out_bounds.lo[0], out_bounds.hi[0], task_stream()));
 }
 
-// CSRRmatvecTask / COORmatvecTask stay assert(false), as in the reference
-// (src/CSRMatrixTasks.cu:159-164, src/COOMatrixTasks.cu:149-154).
+// The transposed products are registered (src/Initialize.cpp:464-479) and never launched; their
+// bodies stay what the reference's are (src/CSRMatrixTasks.cu:159-164, src/COOMatrixTasks.cu:149-154).
+// (liblsk has transposed products -- a set-up-time transposition onto lsk_csr_spmv_c32_* -- for the day a
+// solver launches these tasks; a task body has no place to keep that set-up, see INTEGRATION.md.)
+LEGION_SOLVERS_KDR_TEMPLATE
+void CSRRmatvecTask<LEGION_SOLVERS_KDR_TEMPLATE_ARGS>::cuda_task_body(LEGION_SOLVERS_TASK_ARGS) { assert(false); }
 
-// The explicit instantiations are the reference's own lists (src/LinearAlgebraTasks.cu:241-366,
-// src/CSRMatrixTasks.cu:167-172, src/COOMatrixTasks.cu:157-162), unchanged.
+LEGION_SOLVERS_KDR_TEMPLATE
+void COORmatvecTask<LEGION_SOLVERS_KDR_TEMPLATE_ARGS>::cuda_task_body(LEGION_SOLVERS_TASK_ARGS) { assert(false); }
 
-// LoadCUDALibsTask::task_body (src/CudaLibs.cu:11-20) becomes: lsk_init(device ordinal of the
-// executing processor) -- there are no library handles left to warm.
+// LoadCUDALibsTask (src/CudaLibs.cu:11-20 warms the stream and the cuBLAS / cuSPARSE handles of every
+// GPU): there are no library handles left; what is worth doing before the first timed task is the
+// library's per-device set-up (its reduction scratch, the address of its static scratch array).  The
+// registration and loadCUDALibs() stay the reference's (src/CudaLibs.cu:23-66); only this body changes.
+/* static */
+LoadCUDALibsTask::return_type LoadCUDALibsTask::task_body(const Legion::Task *, const std::vector<Legion::PhysicalRegion> &,
+                                                          Legion::Context, Legion::Runtime *) {
+    int device = 0;
+    if (hipGetDevice(&device) != hipSuccess) assert(false);
+    check(lsk_init(device));
+    (void)task_stream();
+}
+
+// Explicit instantiations: the same set the reference's .cu files instantiate, under the same switches
+// (src/LinearAlgebraTasks.cu:241-366: entry types x index types x dimensions 1..LEGION_SOLVERS_MAX_DIM;
+// src/CSRMatrixTasks.cu:167-172 and src/COOMatrixTasks.cu:157-162: <T, 1, 1, 1, long long x 3>).
+#define LSK_BLAS1_BODIES(T, DIM, I)                                                    \
+    template void ScalTask<T, DIM, I>::cuda_task_body(LEGION_SOLVERS_TASK_ARGS);       \
+    template void AxpyTask<T, DIM, I>::cuda_task_body(LEGION_SOLVERS_TASK_ARGS);       \
+    template void XpayTask<T, DIM, I>::cuda_task_body(LEGION_SOLVERS_TASK_ARGS);       \
+    template T DotTask<T, DIM, I>::cuda_task_body(LEGION_SOLVERS_TASK_ARGS);
+#if LEGION_SOLVERS_MAX_DIM >= 3
+#define LSK_BLAS1_DIMS(T, I) LSK_BLAS1_BODIES(T, 1, I) LSK_BLAS1_BODIES(T, 2, I) LSK_BLAS1_BODIES(T, 3, I)
+#elif LEGION_SOLVERS_MAX_DIM >= 2
+#define LSK_BLAS1_DIMS(T, I) LSK_BLAS1_BODIES(T, 1, I) LSK_BLAS1_BODIES(T, 2, I)
+#else
+#define LSK_BLAS1_DIMS(T, I) LSK_BLAS1_BODIES(T, 1, I)
+#endif
+#ifdef LEGION_SOLVERS_USE_S32_INDICES
+#define LSK_BLAS1_S32(T) LSK_BLAS1_DIMS(T, int)
+#else
+#define LSK_BLAS1_S32(T)
+#endif
+#ifdef LEGION_SOLVERS_USE_U32_INDICES
+#define LSK_BLAS1_U32(T) LSK_BLAS1_DIMS(T, unsigned)
+#else
+#define LSK_BLAS1_U32(T)
+#endif
+#ifdef LEGION_SOLVERS_USE_S64_INDICES
+#define LSK_BLAS1_S64(T) LSK_BLAS1_DIMS(T, long long)
+#else
+#define LSK_BLAS1_S64(T)
+#endif
+#define LSK_MATRIX_BODIES(T)                                                                                              \
+    template void CSRMatvecTask<T, 1, 1, 1, long long, long long, long long>::cuda_task_body(LEGION_SOLVERS_TASK_ARGS);  \
+    template void CSRRmatvecTask<T, 1, 1, 1, long long, long long, long long>::cuda_task_body(LEGION_SOLVERS_TASK_ARGS); \
+    template void COOMatvecTask<T, 1, 1, 1, long long, long long, long long>::cuda_task_body(LEGION_SOLVERS_TASK_ARGS);  \
+    template void COORmatvecTask<T, 1, 1, 1, long long, long long, long long>::cuda_task_body(LEGION_SOLVERS_TASK_ARGS);
+#ifdef LEGION_SOLVERS_USE_F32
+LSK_BLAS1_S32(float) LSK_BLAS1_U32(float) LSK_BLAS1_S64(float)
+#endif
+#ifdef LEGION_SOLVERS_USE_F64
+LSK_BLAS1_S32(double) LSK_BLAS1_U32(double) LSK_BLAS1_S64(double)
+#endif
+// (the reference instantiates the matrix tasks for both entry types whatever LEGION_SOLVERS_USE_F32 / F64 say)
+LSK_MATRIX_BODIES(float)
+LSK_MATRIX_BODIES(double)
 
 } // namespace LegionSolvers
