@@ -285,6 +285,37 @@ def _worker(rank, world, port, out_dir):
         dist.destroy_process_group()
 
 
+def test_planner_bets_are_a_function_of_the_call_sequence():
+    """The planner's fused leaves are bets on the caller's next operation (a product that leaves the
+    shares of the dot that usually follows, an update held back for the dot or the xpay that usually
+    follows), kept up while they are won.  Which kernel adds up a dot product therefore depends on the
+    calls the planner has seen -- and on nothing else: the same sequence of calls gives the same bits,
+    a different history (here: a run of plain products nobody takes a dot of, before the solver starts)
+    gives values that agree to rounding, and with the fused leaves off (Context(fuse=False), LSK_FUSE=0)
+    there is no history at all."""
+    rects, row, col, val, n = hc.stencil_problem(2, (9, 11), np.float64)
+    rhs = np.random.default_rng(17).standard_normal(n)
+
+    def run(prelude, fuse):
+        c = Context(backend=OracleBackend(), fuse=fuse)
+        pl = hc.mirror_planner(c, "csr", rects, row, col, val, n, 3, np.float64, rhs)
+        solver = CGSolver(pl)
+        for _ in range(prelude):       # Q <- A P: CG's first step overwrites Q with the same product
+            pl.matvec(CGSolver.Q, CGSolver.P)
+        for _ in range(6):
+            solver.step()
+        return [s.get_value() for s in solver.residual_norm_squared], pl.get_vector(0, 0).to_host().numpy().copy()
+
+    for prelude in (0, 9):
+        a, b = run(prelude, True), run(prelude, True)
+        assert a[0] == b[0] and np.array_equal(a[1], b[1])
+    plain, after_products = run(0, False), run(9, False)
+    assert plain[0] == after_products[0] and np.array_equal(plain[1], after_products[1])
+    fused, fused_after_products = run(0, True), run(9, True)
+    np.testing.assert_allclose(fused[0], fused_after_products[0], rtol=1e-12)
+    np.testing.assert_allclose(fused[0], plain[0], rtol=1e-12)
+
+
 def _bootstrap_worker(rank, world, port, out_dir):
     """The unique-id bootstrap of the library's RCCL transport over the torch.distributed store: rank 0
     makes the id (ncclGetUniqueId through the C ABI, which needs no GPU), the other reads it."""
