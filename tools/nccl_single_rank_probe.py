@@ -1,9 +1,11 @@
 #!/usr/bin/env python3
-"""The torch.distributed transport of comm.Communicator on ONE rank of RCCL: the dot's all-reduce and a
-halo exchange with itself (send and receive in one group), ordered against kernels on the current stream,
-and what the two calls cost the host and the stream.  (More ranks need more GPUs.)
+"""The two transports of comm.Communicator on ONE rank of RCCL -- torch.distributed (backend nccl) and the
+library's own layer (lsk_allreduce_sum_*, lsk_halo_exchange_* through comm.LskTransport, option
+comm.skip_single_rank = 0 so that RCCL is really called): the dot's all-reduce and a halo exchange with
+itself (send and receive in one group), ordered against kernels on the current stream, and what the two
+calls cost the host and the stream.  (More ranks need more GPUs.)
 
-    python tools/nccl_single_rank_probe.py
+    python tools/nccl_single_rank_probe.py [torch|lsk]      (default: both, one after the other)
 """
 import os
 import sys
@@ -16,15 +18,19 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from legionsolvers_amd.comm import Communicator  # noqa: E402
 
 
-def main():
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29571")
-    torch.cuda.set_device(0)
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
-    comm = Communicator()
-    comm.world_size = 2          # (so that the calls are not short-circuited; the only peer is this rank)
-    comm.backend = "nccl"
+def probe(which):
     dev = torch.device("cuda", 0)
+    if which == "lsk":
+        from legionsolvers_amd import _lib
+        _lib.call("lsk_set_option", b"comm.skip_single_rank", 0)
+        comm = Communicator(transport="lsk")
+        comm.bind_device(dev)
+        assert comm.transport == "lsk" and comm.rccl_ranks == 1
+    else:
+        comm = Communicator(transport="torch")
+        comm.world_size = 2          # (so that the calls are not short-circuited; the only peer is this rank)
+        comm.backend = "nccl"
+    print(f"== transport {which}")
     n = 262657                   # the halo of the 27-point 512^3 problem on 8 ranks, elements per side
     src = torch.arange(n, dtype=torch.float64, device=dev)
     dst = torch.zeros(n, dtype=torch.float64, device=dev)
@@ -66,6 +72,16 @@ def main():
     print(f"results as expected: {ok}")
     print(f"all-reduce of one scalar: {host_ar * 1e6:.1f} us to enqueue, {wall_ar * 1e6:.1f} us per call back to back")
     print(f"exchange of {n} fp64 with itself: {host_ex * 1e6:.1f} us to enqueue, {wall_ex * 1e6:.1f} us per call back to back")
+    comm.close()
+    return ok
+
+
+def main():
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29571")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    ok = all([probe(w) for w in (sys.argv[1:] or ["torch", "lsk"])])
     dist.destroy_process_group()
     return 0 if ok else 1
 
