@@ -369,8 +369,7 @@ int lsk_csr_spmv_tune_f64(int64_t rows, int64_t nnz, const int64_t *rects, int64
  *   lsk_csr_compress_rows_u32: rowoff32[r] = rects[r].lo - k_base for r < rows, rowoff32[rows] =
  *     rects[rows-1].hi + 1 - k_base (rows + 1 values: offsets into the piece's col/val arrays, the
  *     classic CSR row pointer).  Needs rects that are back to back, ascending and inside the piece,
- *     and nnz < 2^32; else LSK_ERR_UNSUPPORTED (blocks until the check has run; uses the library's
- *     per-device scratch).
+ *     and nnz < 2^32; else LSK_ERR_UNSUPPORTED (blocks until the check has run).
  * In both cases a caller that gets LSK_ERR_UNSUPPORTED stays with lsk_csr_spmv_* (that answer never
  * aborts, whatever lsk_set_abort_on_error says).
  * lsk_csr_spmv_c32_* is lsk_csr_spmv_* on those arrays: `x` points at the window's first
@@ -415,7 +414,7 @@ int lsk_csr_spmv_c32_tune_f64(int64_t rows, int64_t nnz, const uint32_t *rowoff3
  *   lsk_csr_long_rows_create: from a piece's rowoff32 (rows + 1 offsets, lsk_csr_compress_rows_u32) the
  *     list of rows longer than `threshold` entries (0: the library's 8192; at least 2048), each cut into
  *     chunks of 8192 entries.  LSK_ERR_UNSUPPORTED (never aborts) when no row is that long: the caller
- *     stays with lsk_csr_spmv_c32_*.  Blocks; uses the library's per-device scratch.
+ *     stays with lsk_csr_spmv_c32_*.  Blocks.
  *   lsk_csr_spmv_c32_split_*: lsk_csr_spmv_c32_* for the rows row_begin .. row_begin + rows - 1 of that
  *     piece (rowoff32 and y those of row_begin; col32, val, x, nnz as there) with the listed rows left
  *     out of the tile kernel and multiplied one workgroup per chunk, a row's chunk sums added in chunk

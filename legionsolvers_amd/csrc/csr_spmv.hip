@@ -1111,17 +1111,23 @@ int create_long_rows(int64_t rows, const uint32_t *rowoff, int64_t threshold, ls
     if (!rowoff) return lsk::fail(LSK_ERR_ARG, "%s: null row offsets", name);
     if (rows > 0xfffffffeLL) return lsk::decline(LSK_ERR_UNSUPPORTED, "%s: %lld rows", name, (long long)rows);
     hipStream_t s = lsk::as_stream(stream);
-    lsk::DeviceState *st = nullptr;
-    if (int rc = lsk::device_state(&st)) return rc;
-    unsigned int *counter = static_cast<unsigned int *>(st->scratch);
+    // a counter of this call's own (set-up time): several host threads may make plans on one device at once
+    unsigned int *counter = nullptr;
+    LSK_HIP(hipMalloc(reinterpret_cast<void **>(&counter), sizeof(unsigned int)));
     const unsigned grid = static_cast<unsigned>(std::min<int64_t>(lsk::ceil_div(rows, kBlock), lsk::kMaxGridBlocks));
     unsigned int h_count = 0;
-    LSK_HIP(hipMemcpyAsync(counter, &h_count, sizeof(h_count), hipMemcpyHostToDevice, s));
-    long_count_kernel<<<grid, kBlock, 0, s>>>(rows, rowoff, static_cast<uint32_t>(threshold), counter);
-    LSK_LAUNCH_CHECK();
-    LSK_HIP(hipMemcpyAsync(&h_count, counter, sizeof(h_count), hipMemcpyDeviceToHost, s));
-    LSK_HIP(hipStreamSynchronize(s));
-    if (h_count == 0) return lsk::decline(LSK_ERR_UNSUPPORTED, "%s: no row longer than %lld entries", name, (long long)threshold);
+    hipError_t e = hipMemcpyAsync(counter, &h_count, sizeof(h_count), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) {
+        long_count_kernel<<<grid, kBlock, 0, s>>>(rows, rowoff, static_cast<uint32_t>(threshold), counter);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(&h_count, counter, sizeof(h_count), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess || h_count == 0) {
+        (void)hipFree(counter);
+        if (e != hipSuccess) return lsk::hip_fail(e, "counting the long rows", __FILE__, __LINE__);
+        return lsk::decline(LSK_ERR_UNSUPPORTED, "%s: no row longer than %lld entries", name, (long long)threshold);
+    }
 
     lsk_csr_long_rows *m = new lsk_csr_long_rows;
     m->rows = rows;
@@ -1179,6 +1185,7 @@ int create_long_rows(int64_t rows, const uint32_t *rowoff, int64_t threshold, ls
     (void)hipFree(unsorted);
     (void)hipFree(nchunks);
     (void)hipFree(temp);
+    (void)hipFree(counter);
     if (status != LSK_OK) {
         release_long_rows(m);
         return status;
@@ -1339,18 +1346,20 @@ int lsk_csr_compress_rows_u32(int64_t rows, int64_t nnz, const int64_t *rects, i
     if (!rects) return lsk::fail(LSK_ERR_ARG, "lsk_csr_compress_rows_u32: null rects");
     if (!lsk::aligned16(rects))
         return lsk::fail(LSK_ERR_ALIGN, "lsk_csr_compress_rows_u32: rects must be 16-byte aligned");
-    lsk::DeviceState *st = nullptr;
-    if (int rc = lsk::device_state(&st)) return rc;
-    int *flag = static_cast<int *>(st->scratch);
+    // a flag of this call's own (set-up time): several host threads may compress pieces on one device at once
+    int *flag = nullptr;
+    LSK_HIP(hipMalloc(reinterpret_cast<void **>(&flag), sizeof(int)));
     clear_flag_kernel<<<1, 1, 0, s>>>(flag);
     int64_t blocks = lsk::ceil_div(rows, kBlock);
     if (blocks > lsk::kMaxGridBlocks) blocks = lsk::kMaxGridBlocks;
     compress_rows_kernel<<<static_cast<unsigned>(blocks), kBlock, 0, s>>>(
         rows, nnz, reinterpret_cast<const Rect *>(rects), k_base, rowoff32, flag);
-    LSK_LAUNCH_CHECK();
     int bad = 0;
-    LSK_HIP(hipMemcpyAsync(&bad, flag, sizeof(bad), hipMemcpyDeviceToHost, s));
-    LSK_HIP(hipStreamSynchronize(s));
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(&bad, flag, sizeof(bad), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(flag);
+    if (e != hipSuccess) return lsk::hip_fail(e, "lsk_csr_compress_rows_u32", __FILE__, __LINE__);
     if (bad)
         return lsk::decline(LSK_ERR_UNSUPPORTED,
                             "lsk_csr_compress_rows_u32: rects are not back to back inside the piece");

@@ -299,6 +299,21 @@ def test_rccl_layer_single_rank():
     torch.cuda.synchronize()
     assert buf.tolist() == [1.5, 2.5]
     _lib.check(lib.lsk_comm_destroy(comm))
+    # a communicator given up without waiting (what a rank does whose peers never came): the next one works
+    _lib.check(lib.lsk_comm_unique_id(uid))
+    _lib.check(lib.lsk_comm_init_rank(ctypes.byref(comm), 1, 0, uid))
+    _lib.check(lib.lsk_comm_abort(comm))
+    _lib.check(lib.lsk_comm_abort(None))
+    _lib.check(lib.lsk_comm_unique_id(uid))
+    _lib.check(lib.lsk_comm_init_rank(ctypes.byref(comm), 1, 0, uid))
+    _lib.check(lib.lsk_set_option(b"comm.skip_single_rank", 0))
+    try:
+        _lib.check(lib.lsk_allreduce_sum_f64(comm, P(buf), 2, stream()))
+    finally:
+        _lib.check(lib.lsk_set_option(b"comm.skip_single_rank", 1))
+    torch.cuda.synchronize()
+    assert buf.tolist() == [1.5, 2.5]
+    _lib.check(lib.lsk_comm_destroy(comm))
 
 
 @pytest.mark.parametrize("suf", ["f32", "f64"])
