@@ -524,6 +524,17 @@ int lsk_coo_binned_create_f64(int64_t nnz, const uint32_t *row32, const uint32_t
                               lsk_stream_t stream, lsk_coo_binned_t **out);
 int lsk_coo_binned_spmv_f32(const lsk_coo_binned_t *m, const float *x, float *y, int beta, lsk_stream_t stream);
 int lsk_coo_binned_spmv_f64(const lsk_coo_binned_t *m, const double *x, double *y, int beta, lsk_stream_t stream);
+/* The same product in two calls, for a caller whose x arrives in parts (one process per GPU: the columns
+ * a rank owns are there, the others are on their way; under Legion the READ_ONLY ghost requirement makes
+ * the whole of x arrive before the task starts, src/COOMatrix.cpp:179-188).  phase 0: the first pass for
+ * the blocks of columns that lie wholly inside col_lo .. col_hi (counted from the x window's first
+ * column), reading x only there; phase 1: the first pass for all other blocks, then the second pass, which
+ * writes y.  Phase 0 then phase 1 on one stream = lsk_coo_binned_spmv_* (the same products from the first
+ * pass; the second pass adds them in the hardware's order, as always). */
+int lsk_coo_binned_spmv_phase_f32(const lsk_coo_binned_t *m, const float *x, float *y, int beta, int phase,
+                                  int64_t col_lo, int64_t col_hi, lsk_stream_t stream);
+int lsk_coo_binned_spmv_phase_f64(const lsk_coo_binned_t *m, const double *x, double *y, int beta, int phase,
+                                  int64_t col_lo, int64_t col_hi, lsk_stream_t stream);
 int lsk_coo_binned_update_values_f32(lsk_coo_binned_t *m, int64_t nnz, const float *val, lsk_stream_t stream);
 int lsk_coo_binned_update_values_f64(lsk_coo_binned_t *m, int64_t nnz, const double *val, lsk_stream_t stream);
 int lsk_coo_binned_info(const lsk_coo_binned_t *m, int64_t *out8);

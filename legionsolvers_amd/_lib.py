@@ -106,6 +106,8 @@ PROTOTYPES = {
     "lsk_coo_binned_create_f64": (_i, [_i64, _p, _p, _p, _i64, _i64, _i64, _i, _i, _p, _p]),
     "lsk_coo_binned_spmv_f32": (_i, [_p, _p, _p, _i, _p]),
     "lsk_coo_binned_spmv_f64": (_i, [_p, _p, _p, _i, _p]),
+    "lsk_coo_binned_spmv_phase_f32": (_i, [_p, _p, _p, _i, _i, _i64, _i64, _p]),
+    "lsk_coo_binned_spmv_phase_f64": (_i, [_p, _p, _p, _i, _i, _i64, _i64, _p]),
     "lsk_coo_binned_update_values_f32": (_i, [_p, _i64, _p, _p]),
     "lsk_coo_binned_update_values_f64": (_i, [_p, _i64, _p, _p]),
     "lsk_coo_binned_info": (_i, [_p, _p]),

@@ -374,6 +374,13 @@ class HipBackend:
         _lib.call(f"lsk_coo_binned_spmv_{_lib.suffix(binned.dtype)}", binned.handle, _ptr(x), _ptr(y), beta,
                   self.stream())
 
+    def coo_binned_spmv_phase(self, binned: "BinnedCoo", x: torch.Tensor, y: torch.Tensor, beta: int, phase: int,
+                              col_lo: int, col_hi: int) -> None:
+        """coo_binned_spmv in two calls: phase 0 multiplies the blocks of columns wholly inside col_lo .. col_hi
+        (window-relative; x is read only there), phase 1 the others and writes y."""
+        _lib.call(f"lsk_coo_binned_spmv_phase_{_lib.suffix(binned.dtype)}", binned.handle, _ptr(x), _ptr(y), beta, phase,
+                  col_lo, col_hi, self.stream())
+
     def coo_binned_update_values(self, binned: "BinnedCoo", val: torch.Tensor) -> None:
         """Copies the entry values into the binned copy again (same rows and columns, new values)."""
         _lib.call(f"lsk_coo_binned_update_values_{_lib.suffix(binned.dtype)}", binned.handle, val.numel(), _ptr(val),

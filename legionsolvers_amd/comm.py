@@ -241,7 +241,9 @@ class Communicator:
             if self.world_size > 1:
                 from torch.distributed.distributed_c10d import _get_default_store
                 store = _get_default_store()
-            tag = "world" if self.group is None else f"group{id(self.group):x}"
+            # (a key every rank of the group forms alike: its members' global ranks)
+            tag = "world" if self.group is None else "ranks" + "-".join(
+                str(r) for r in dist.get_process_group_ranks(self.group))
             self.lsk = LskTransport(self.rank, self.world_size, device, store, tag)
             self.lsk.self_check()
         except Exception as exc:  # noqa: BLE001

@@ -44,6 +44,7 @@ struct lsk_coo_binned {
     uint32_t *unit = nullptr;    // 4 per unit: block, first entry, end, stride of its runs
     uint32_t *segptr = nullptr;  // ntiles + 1
     uint32_t *segs = nullptr;    // 2 per segment: first entry, length
+    std::vector<uint32_t> unit_first; // host: first unit of every block of columns (nblocks + 1; units are in block order)
 };
 
 namespace {
@@ -535,7 +536,9 @@ int create(const char *name, int64_t nnz, const uint32_t *row32, const uint32_t 
     if (status == LSK_OK) {
         // the workgroups of pass 1: a block's entries in equal runs of at most kUnitEntries
         std::vector<uint32_t> h_unit;
+        m->unit_first.assign(static_cast<size_t>(nblocks) + 1, 0);
         for (int64_t c = 0; c < nblocks; ++c) {
+            m->unit_first[c] = static_cast<uint32_t>(h_unit.size() / 4);
             const long long n = h_starts[c + 1] - h_starts[c];
             if (n <= 0) continue;
             const long long parts = lsk::ceil_div(n, kUnitEntries);
@@ -549,6 +552,7 @@ int create(const char *name, int64_t nnz, const uint32_t *row32, const uint32_t 
             }
         }
         m->units = static_cast<int64_t>(h_unit.size() / 4);
+        m->unit_first[nblocks] = static_cast<uint32_t>(m->units);
         const size_t p = static_cast<size_t>(m->padded);
         LSK_TRY(hipMalloc(&m->val, p * sizeof(T)));
         LSK_TRY(hipMalloc(&m->prod, p * sizeof(T)));
@@ -596,21 +600,42 @@ int create(const char *name, int64_t nnz, const uint32_t *row32, const uint32_t 
     return LSK_OK;
 }
 
+// phase < 0: the whole product.  phase 0: pass 1 of the blocks of columns that lie wholly inside
+// col_lo .. col_hi (window-relative), which reads x only there; phase 1: pass 1 of all other blocks, then
+// pass 2.  Phases 0 and 1 in that order are the whole product (pass 1 writes the same products either way).
 template <typename T>
-int spmv(const char *name, const lsk_coo_binned *m, const T *x, T *y, int beta, lsk_stream_t stream) {
+int spmv(const char *name, const lsk_coo_binned *m, const T *x, T *y, int beta, lsk_stream_t stream, int phase = -1,
+         int64_t col_lo = 0, int64_t col_hi = -1) {
     if (!m) return lsk::fail(LSK_ERR_ARG, "%s: null handle", name);
     if (m->elem_bytes != static_cast<int>(sizeof(T)))
         return lsk::fail(LSK_ERR_ARG, "%s: the copy holds %d-byte values", name, m->elem_bytes);
     if (!x || !y) return lsk::fail(LSK_ERR_ARG, "%s: null vector", name);
     if (beta != 0 && beta != 1) return lsk::fail(LSK_ERR_ARG, "%s: beta must be 0 or 1", name);
+    if (phase > 1) return lsk::fail(LSK_ERR_ARG, "%s: phase %d (0 or 1)", name, phase);
     hipStream_t s = lsk::as_stream(stream);
     if (const int rc = allow_lds<T>(s); rc != LSK_OK) return rc; // (a handle made on another device)
-    if (m->units > 0) {
-        binned_multiply_kernel<T><<<static_cast<unsigned>(m->units), kBinBlock, lds_bytes<T>(m->block_cols), s>>>(
-            m->unit, static_cast<const T *>(m->val), m->lc, x, m->x_extent, m->block_cols, static_cast<T *>(m->prod),
-            lsk::aligned16(x) ? 1 : 0);
-        LSK_LAUNCH_CHECK();
+    // units [u0, u1): those of the blocks inside the interval (none when phase < 0)
+    int64_t u0 = 0, u1 = 0;
+    if (phase >= 0 && col_hi >= col_lo) {
+        const int64_t b0 = std::min<int64_t>(lsk::ceil_div(std::max<int64_t>(col_lo, 0), m->block_cols), m->nblocks);
+        // a block ends at the window's end at the latest: the last one counts as inside when col_hi reaches that end
+        const int64_t b1 = col_hi >= m->x_extent - 1 ? m->nblocks : std::max<int64_t>((col_hi + 1) / m->block_cols, 0);
+        if (b1 > b0) {
+            u0 = m->unit_first[b0];
+            u1 = m->unit_first[std::min<int64_t>(b1, m->nblocks)];
+        }
     }
+    auto multiply = [&](int64_t first, int64_t end) -> int {
+        if (end <= first) return LSK_OK;
+        binned_multiply_kernel<T><<<static_cast<unsigned>(end - first), kBinBlock, lds_bytes<T>(m->block_cols), s>>>(
+            m->unit + 4 * first, static_cast<const T *>(m->val), m->lc, x, m->x_extent, m->block_cols,
+            static_cast<T *>(m->prod), lsk::aligned16(x) ? 1 : 0);
+        LSK_LAUNCH_CHECK();
+        return LSK_OK;
+    };
+    if (phase == 0) return multiply(u0, u1);
+    if (const int rc = multiply(0, u0); rc != LSK_OK) return rc;
+    if (const int rc = multiply(u1, m->units); rc != LSK_OK) return rc;
     binned_reduce_kernel<T><<<static_cast<unsigned>(m->ntiles), kBinBlock, lds_bytes<double>(m->tile_rows), s>>>(
         m->segptr, m->segs, static_cast<const T *>(m->prod), m->lr, y, m->rows, m->tile_rows, beta,
         lsk::aligned16(y) ? 1 : 0);
@@ -654,6 +679,17 @@ int lsk_coo_binned_spmv_f32(const lsk_coo_binned_t *m, const float *x, float *y,
 }
 int lsk_coo_binned_spmv_f64(const lsk_coo_binned_t *m, const double *x, double *y, int beta, lsk_stream_t stream) {
     return spmv<double>("lsk_coo_binned_spmv_f64", m, x, y, beta, stream);
+}
+
+int lsk_coo_binned_spmv_phase_f32(const lsk_coo_binned_t *m, const float *x, float *y, int beta, int phase,
+                                  int64_t col_lo, int64_t col_hi, lsk_stream_t stream) {
+    if (phase < 0) return lsk::fail(LSK_ERR_ARG, "lsk_coo_binned_spmv_phase_f32: phase %d (0 or 1)", phase);
+    return spmv<float>("lsk_coo_binned_spmv_phase_f32", m, x, y, beta, stream, phase, col_lo, col_hi);
+}
+int lsk_coo_binned_spmv_phase_f64(const lsk_coo_binned_t *m, const double *x, double *y, int beta, int phase,
+                                  int64_t col_lo, int64_t col_hi, lsk_stream_t stream) {
+    if (phase < 0) return lsk::fail(LSK_ERR_ARG, "lsk_coo_binned_spmv_phase_f64: phase %d (0 or 1)", phase);
+    return spmv<double>("lsk_coo_binned_spmv_phase_f64", m, x, y, beta, stream, phase, col_lo, col_hi);
 }
 
 int lsk_coo_binned_update_values_f32(lsk_coo_binned_t *m, int64_t nnz, const float *val, lsk_stream_t stream) {

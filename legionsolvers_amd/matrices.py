@@ -982,10 +982,30 @@ class COOMatrix(AbstractMatrix, _SlicedCopies):
             return True  # (the binned copy's second pass writes every row of the piece)
         return self.sliced_window == (x_lo, x_hi) and all(c in self.sliced for c in live)
 
-    def matvec(self, dst, x, x_lo, x_hi, kernel_partition, beta=1, range_partition=None):
+    def phases(self, x_lo, x_hi, kernel_partition, range_partition) -> bool:
+        """Whether matvec(phase=...) is available for this window: the one local piece goes through its
+        binned copy, whose first pass can start on the columns that are already there."""
+        live = [c for c in kernel_partition.colors if range_partition.pieces[c].volume > 0]
+        return (self.binned is not None and self.binned_window == (x_lo, x_hi) and live == [self.binned_color]
+                and getattr(self.ctx.backend, "coo_binned_spmv_phase", None) is not None
+                and os.environ.get("LSK_OVERLAP", "1") != "0")
+
+    def matvec(self, dst, x, x_lo, x_hi, kernel_partition, beta=1, range_partition=None, phase=None, own=None):
         """COOMatrix::matvec (src/COOMatrix.cpp:144-191): accumulates; dst must hold the
-        values to add to (the planner zero-fills it).  beta = 0 where overwrites() says so."""
+        values to add to (the planner zero-fills it).  beta = 0 where overwrites() says so.
+        phase, own (only where phases() says so): phase 0 multiplies what reads only the columns
+        own = (lo, hi) (global; the ones this rank holds before the ghost cells have arrived), phase 1
+        the rest and writes dst; both in that order are the whole product."""
         range_partition = range_partition or dst.index_partition
+        if phase is not None:
+            if not self.phases(x_lo, x_hi, kernel_partition, range_partition) or own is None:
+                raise ValueError("this COO product cannot be taken in phases")
+            i = kernel_partition.colors.index(self.binned_color)
+            if phase == 1 and getattr(dst, "_touch", None) is not None:
+                dst._touch()
+            self.ctx.backend.coo_binned_spmv_phase(self.binned, x, dst._piece(i), beta, phase, own[0] - x_lo,
+                                                   own[1] - x_lo)
+            return
         if beta != 1 and not (beta == 0 and self.overwrites(x_lo, x_hi, kernel_partition, range_partition)):
             raise ValueError("COO matvec accumulates (beta = 1)")
         touch = getattr(dst, "_touch", None)

@@ -373,8 +373,19 @@ class SquarePlanner:
             x, x_lo, x_hi, handle = self._gather_ghost(e, src)
             comm = self.ctx.comm
             if isinstance(e.matrix, COOMatrix):
+                overwrites = first and e.matrix.overwrites(x_lo, x_hi, e.kernel_partition, dst.index_partition)
+                if (overwrites and handle is not None
+                        and e.matrix.phases(x_lo, x_hi, e.kernel_partition, dst.index_partition)):
+                    # an unstructured matrix reads all of x: what reads only the columns this rank owns is
+                    # multiplied while the others' parts are on their way, the rest once they are here
+                    own = (src.own_lo, src.own_hi)
+                    e.matrix.matvec(dst, x, x_lo, x_hi, e.kernel_partition, 0, phase=0, own=own)
+                    comm.exchange_finish(handle)
+                    e.matrix.matvec(dst, x, x_lo, x_hi, e.kernel_partition, 0, phase=1, own=own)
+                    self.coo_products_in_phases = getattr(self, "coo_products_in_phases", 0) + 1
+                    continue
                 comm.exchange_finish(handle)
-                if first and e.matrix.overwrites(x_lo, x_hi, e.kernel_partition, dst.index_partition):
+                if overwrites:
                     e.matrix.matvec(dst, x, x_lo, x_hi, e.kernel_partition, 0)
                     continue
                 if first:

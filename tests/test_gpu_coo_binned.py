@@ -253,3 +253,48 @@ def test_coo_binned_two_live_copies_of_different_sizes():
         assert np.all(np.abs(yd.cpu().numpy() - want2) <= 1e-13 * (bound2 + 1e-300))
     finally:
         _lib.call("lsk_coo_binned_destroy", wide)
+
+
+@pytest.mark.parametrize("suf", ["f32", "f64"])
+def test_coo_binned_product_in_two_phases(suf):
+    """lsk_coo_binned_spmv_phase_*: phase 0 (the blocks of columns wholly inside an interval, reading x only
+    there) then phase 1 (the rest, and the second pass) give the whole product -- whatever
+    the interval, with x outside it still missing (NaN) during phase 0."""
+    npdt, tdt, tol = DT[suf]
+    rng = np.random.default_rng(65)
+    n_rows, n_cols, nnz = 5000, 4100, 90000
+    r = rng.integers(0, n_rows, nnz).astype(np.int64)
+    c = rng.integers(0, n_cols, nnz).astype(np.int64)
+    v = rng.standard_normal(nnz).astype(npdt)
+    x = rng.standard_normal(n_cols).astype(npdt)
+    rd, cd, vd, xd = dev(r), dev(c), dev(v), dev(x)
+    code, handle = make(suf, compress(rd, 0, n_rows - 1), compress(cd, 0, n_cols - 1), vd, 0, n_rows - 1, n_cols, 256, 512)
+    assert code == _lib.LSK_OK
+    try:
+        whole = torch.full((n_rows,), 3.0, dtype=tdt, device="cuda")
+        _lib.call(f"lsk_coo_binned_spmv_{suf}", handle, P(xd), P(whole), 0, stream())
+        # intervals: a rank's share in the middle, from the start, to the end (the ragged last block), inside one
+        # block (nothing to do early), empty, everything, and reaching outside the window
+        for lo, hi in ((1024, 2999), (0, 1500), (2000, n_cols - 1), (300, 400), (5, 4), (0, n_cols - 1), (-50, n_cols + 50)):
+            for beta in (0, 1):
+                print(f"case coo_binned phases {suf} columns [{lo},{hi}] beta={beta}", flush=True)
+                y = torch.full((n_rows,), 3.0, dtype=tdt, device="cuda")
+                early = torch.full_like(xd, float("nan"))
+                a, b = max(lo, 0), min(hi, n_cols - 1)
+                if b >= a:
+                    early[a:b + 1] = xd[a:b + 1]
+                _lib.call(f"lsk_coo_binned_spmv_phase_{suf}", handle, P(early), P(y), beta, 0, lo, hi, stream())
+                early.copy_(xd)                                  # the rest of x "arrives"
+                _lib.call(f"lsk_coo_binned_spmv_phase_{suf}", handle, P(early), P(y), beta, 1, lo, hi, stream())
+                # (the first pass writes the same products either way; the second adds them with LDS atomics in
+                # the hardware's order, so two runs of the same product agree to rounding, like the plain entry point)
+                want = whole + 3.0 if beta else whole
+                err = (y.double() - want.double()).abs().max().item()
+                assert err <= 100 * tol * float(whole.abs().max()), (lo, hi, err)
+                assert not bool(torch.isnan(y).any())
+        lib = _lib.lib()
+        y = torch.zeros(n_rows, dtype=tdt, device="cuda")
+        assert getattr(lib, f"lsk_coo_binned_spmv_phase_{suf}")(handle, P(xd), P(y), 0, 2, 0, 10, stream()) == _lib.LSK_ERR_ARG
+        assert getattr(lib, f"lsk_coo_binned_spmv_phase_{suf}")(handle, P(xd), P(y), 0, -1, 0, 10, stream()) == _lib.LSK_ERR_ARG
+    finally:
+        _lib.call("lsk_coo_binned_destroy", handle)

@@ -163,3 +163,46 @@ def test_two_systems_share_a_pass_across_ranks(monkeypatch, world, pieces, n1):
         assert a["history"] == c["history"], f"rank {r}: scalars differ with scalar coefficients"
         for s in range(2):
             assert np.array_equal(a["sols"][s], c["sols"][s]), f"rank {r}: solution {s} differs with scalar coefficients"
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_unstructured_coo_starts_on_its_own_columns_across_ranks(monkeypatch, world):
+    """An unstructured COO matrix reads all of x on every rank.  On the binned copy the first pass of the
+    blocks of columns a rank owns is launched while the other ranks' parts of x are still on their way,
+    the rest and the second pass once they are here (SquarePlanner.matvec, lsk_coo_binned_spmv_phase_*):
+    BiCGStab across the ranks follows the oracle's single-process run."""
+    from legionsolvers_amd import COOMatrix
+    monkeypatch.setenv("LSK_TUNE", "0")
+    monkeypatch.setenv("LSK_COO_BLOCK", "1")
+    monkeypatch.setenv("LSK_COO_BINNED", "2")
+    monkeypatch.setattr(COOMatrix, "BLOCK_MIN_WINDOW", 0)
+    monkeypatch.setattr(COOMatrix, "BINNED_BLOCK_COLS", 256)
+    monkeypatch.setattr(COOMatrix, "BINNED_TILE_ROWS", 512)
+    rng = np.random.default_rng(83)
+    n, per, steps = 24001, 12, 5   # (at least 2^16 entries per rank, or the planner leaves the row order alone)
+    row = np.repeat(np.arange(n), per).astype(np.int64)
+    col = rng.integers(0, n, size=n * per).astype(np.int64)
+    col[::per] = np.arange(n)                      # a dominant diagonal keeps the system well posed
+    val = rng.uniform(-1, 1, size=n * per)
+    val[::per] = 2.0 * per
+    rhs = rng.standard_normal(n)
+    print(f"case thread ranks unstructured coo world={world}", flush=True)
+    opl = hc.oracle_planner("coo", None, row, col, val, n, world, np.float64, rhs)
+    so = S.BiCGStabSolver(opl)
+    for _ in range(steps):
+        so.step()
+    want = opl.get_vector(0, 0)
+
+    def body(ctx):
+        mpl = hc.mirror_planner(ctx, "coo", None, row, col, val, n, world, np.float64, rhs)
+        matrix = mpl.row_partitioned_matrices[0].matrix
+        assert matrix.binned is not None
+        sm = BiCGStabSolver(mpl)
+        for _ in range(steps):
+            sm.step()
+        v = mpl.get_vector(0, 0)
+        return v.to_host().numpy().copy(), (v.own_lo, v.own_hi), getattr(mpl, "coo_products_in_phases", 0)
+
+    for sol, (lo, hi), phased in run_ranks(world, body):
+        assert phased >= 2 * steps, phased          # both products of every step went in two phases
+        assert np.abs(sol - want[lo:hi + 1]).max() <= 1e-9 * np.abs(want).max()
