@@ -9,6 +9,6 @@ for n in "$@"; do
 import sys, json
 for l in sys.stdin:
     if l.startswith('{'):
-        d = json.loads(l); print('$n', {k: v for k, v in d.items() if 'dot' in k or k in ('sliced_ms', 'wave_dma_form_ms', 'wave_form_ms', 'block_form_ms')})
+        d = json.loads(l); print('$n', {k: v for k, v in d.items() if k.startswith('pair') or k in ('sliced_ms', 'wave_dma_form_ms', 'wave_dma_form_dot_w_is_x_ms')})
 " || exit 1
 done
