@@ -345,8 +345,13 @@ def main():
         traffic_source = ("recorded, not measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
                           "tools/pmc_spmv.py, profiles/spmv_hbm_traffic.json")
 
+    # (the optional legs below step the solver, which every rank must do or none: they go by what holds on
+    # all ranks, not on this one)
+    sliced_everywhere = all(ctx.comm.all_gather_object(sliced))
+    uniform_everywhere = all(ctx.comm.all_gather_object(
+        sliced and all(p.uniform_values for p in matrix.sliced.values())))
     with_redraws = None
-    if args.redraws and sliced:
+    if args.redraws and sliced_everywhere:
         before = dict(matrix.setup_seconds)
         matrix.tune_sliced_copies(redraws=int(os.environ.get("LSK_TUNE_REDRAWS", matrix.SLICED_REDRAWS)))
         for key, v in matrix.setup_seconds.items():
@@ -358,7 +363,7 @@ def main():
     # reference's benchmark is a constant-coefficient stencil, the sliced-pattern copy finds that out bit by
     # bit at set-up, and the product then reads no value array at all.  Not the default: reported beside it.
     uniform = None
-    if sliced and all(p.uniform_values for p in matrix.sliced.values()):
+    if uniform_everywhere:
         from legionsolvers_amd import _lib
         _lib.call("lsk_set_option", b"sliced.uniform", 1)
         try:
