@@ -226,6 +226,148 @@ def test_spmv_properties_at_headline_size(gpu_ctx, monkeypatch, n1):
         fresh.close()
 
 
+def test_a_piece_of_more_than_2_to_the_32_entries(gpu_ctx, monkeypatch):
+    """One piece with more entries than 32-bit offsets can address (27-point stencil on 544^3: 4 330 747 000
+    entries, 161 M rows; the reference's int64 kernel coordinates exist for exactly this).  The products on
+    the arrays as handed over must be right (row sums, symmetry), the 32-bit copy of the structure must be
+    declined, not wrapped around, and whatever the planner picks instead must agree with the plain product
+    and run CG like the plain arrays do."""
+    from conftest import require_device_memory
+    n1 = 544
+    n = n1 ** 3
+    require_device_memory(200, f"27-point fp64 CSR products and CG on one piece of {(3 * n1 - 2) ** 3} entries "
+                               f"(more than 2^32) at {n1}^3")
+    print(f"case more than 2^32 entries {n1}^3", flush=True)
+    monkeypatch.setenv("LSK_TUNE", "0")
+    dim, offs, cfs = sg.benchmark_stencil(4)
+    ip = IndexPartition.equal(IndexSpace(0, n - 1), 1)
+    A = sg.create_linearized_csr_stencil_matrix(gpu_ctx, (n1, n1, n1), offs, cfs, ip)
+    assert A.nnz == (3 * n1 - 2) ** 3 and A.nnz > 2 ** 32
+    kp = A.create_kernel_partition_from_range_partition(ip)
+    assert kp.intervals == [(0, A.nnz - 1)]
+    # the last rect ends at the last entry: the generator's offsets did not wrap
+    assert A.rects[-1].tolist()[1] == A.nnz - 1 and int(A.col[-1]) == n - 1
+
+    def matvec(x):
+        y = PartitionedVector(gpu_ctx, "y", ip)
+        A.matvec(y, x.owned, 0, n - 1, kp, 0)
+        return y
+
+    ones = PartitionedVector(gpu_ctx, "ones", ip)
+    ones.constant_fill(1.0)
+    rowsum = matvec(ones).owned.view(n1, n1, n1)
+    assert float(rowsum[1:-1, 1:-1, 1:-1].abs().max()) <= 1e-14
+    assert float(rowsum[0].min()) > 0.1 and float(rowsum[-1].min()) > 0.1 and float(rowsum[:, :, -1].min()) > 0.1
+    del rowsum
+    g = torch.Generator(device="cuda").manual_seed(11)
+    x = PartitionedVector(gpu_ctx, "x", ip)
+    y = PartitionedVector(gpu_ctx, "yv", ip)
+    x.owned.copy_(torch.randn(n, generator=g, device="cuda", dtype=torch.float64))
+    y.owned.copy_(torch.randn(n, generator=g, device="cuda", dtype=torch.float64))
+    Ax, Ay = matvec(x), matvec(y)
+    xAy, yAx = x.dot(Ay).get_value(), y.dot(Ax).get_value()
+    assert abs(xAy - yAx) <= 1e-12 * (x.dot(x).get_value() * Ay.dot(Ay).get_value()) ** 0.5
+    # the fused product + dot on the same arrays: same y, the dot to rounding
+    be = gpu_ctx.backend
+    slots = be.csr_spmv_dot_slots(n, A.nnz, torch.float64)
+    partials = torch.empty(slots, dtype=torch.float64, device="cuda")
+    yd = torch.full((n,), 9.0, dtype=torch.float64, device="cuda")
+    count = be.csr_spmv_dot(n, A.nnz, A.rects, 0, A.col, A.val, x.owned, 0, n - 1, yd, 0, y.owned, partials)
+    assert torch.equal(yd, Ax.owned)
+    assert abs(float(partials[:count].sum()) - yAx) <= 1e-12 * abs(yAx) + 1e-6
+    del yd, partials, Ay, y
+    # registered with a planner: 32-bit offsets cannot hold this piece (declined, not wrapped around); the
+    # sliced-pattern copy counts entries in 64 bits and is made; its product equals the plain one to rounding
+    from legionsolvers_amd import benchmark_stencil as bs
+    _, planner, solver = bs.build_problem(gpu_ctx, 4, n1, n1, n1, 1, 1, torch.float64, num_systems=1, matrix=A)
+    assert A.col32 is None and not A.rowoff
+    assert A.sliced and A.sliced_window == (0, n - 1)
+    s = A.sliced[0]
+    assert s.patterns == 27 and s.padded_entries > 2 ** 32
+    As = matvec(x)
+    diff = float((As.owned - Ax.owned).abs().max())
+    assert 0.0 < diff <= 1e-13 * float(Ax.owned.abs().max())
+    del As, Ax, x, ones
+    # CG, three steps: on the copy, then on the arrays as handed over
+    histories = []
+    for _ in range(3):
+        solver.step()
+    histories.append([r.get_value() for r in solver.residual_norm_squared])
+    del planner, solver
+    held, A.sliced_window = A.sliced_window, None
+    monkeypatch.setenv("LSK_SLICED", "0")   # (registering the matrix again must not make the copy again)
+    try:
+        _, planner, solver = bs.build_problem(gpu_ctx, 4, n1, n1, n1, 1, 1, torch.float64, num_systems=1, matrix=A)
+        assert A.sliced_window is None and A.col32 is None
+        for _ in range(3):
+            solver.step()
+        histories.append([r.get_value() for r in solver.residual_norm_squared])
+    finally:
+        A.sliced_window = held
+    assert len(histories[0]) == 4 and histories[0][0] == float(n)
+    assert all(np.isfinite(h) and h > 0.0 for h in histories[0])
+    np.testing.assert_allclose(histories[0], histories[1], rtol=1e-10)
+
+
+def test_a_coo_piece_of_more_than_2_to_the_32_entries(gpu_ctx, monkeypatch):
+    """The same for the COO form (row, col int64 and val: 104 GB): the scan kernel on the arrays as handed
+    over against row sums and symmetry, then the planner's choice for that piece against it in CG."""
+    from conftest import require_device_memory
+    from legionsolvers_amd import benchmark_stencil as bs
+    n1 = 544
+    n = n1 ** 3
+    require_device_memory(230, f"27-point fp64 COO products and CG on one piece of {(3 * n1 - 2) ** 3} entries "
+                               f"(more than 2^32) at {n1}^3")
+    print(f"case coo more than 2^32 entries {n1}^3", flush=True)
+    monkeypatch.setenv("LSK_TUNE", "0")
+    dim, offs, cfs = sg.benchmark_stencil(4)
+    ip = IndexPartition.equal(IndexSpace(0, n - 1), 1)
+    A = sg.create_linearized_coo_stencil_matrix(gpu_ctx, (n1, n1, n1), offs, cfs, ip, torch.float64)
+    assert A.nnz == (3 * n1 - 2) ** 3 and A.nnz > 2 ** 32
+    assert int(A.row[-1]) == n - 1 and int(A.col[-1]) == n - 1 and int(A.row[2 ** 32]) > 0
+    kp = A.create_kernel_partition_from_range_partition(ip)
+    assert kp.intervals == [(0, A.nnz - 1)]
+
+    def matvec(x):
+        y = PartitionedVector(gpu_ctx, "y", ip)
+        y.zero_fill()
+        A.matvec(y, x.owned, 0, n - 1, kp, 1)
+        return y
+
+    ones = PartitionedVector(gpu_ctx, "ones", ip)
+    ones.constant_fill(1.0)
+    rowsum = matvec(ones).owned.view(n1, n1, n1)
+    assert float(rowsum[1:-1, 1:-1, 1:-1].abs().max()) <= 1e-14
+    assert float(rowsum[0].min()) > 0.1 and float(rowsum[-1].min()) > 0.1 and float(rowsum[:, :, -1].min()) > 0.1
+    del rowsum, ones
+    g = torch.Generator(device="cuda").manual_seed(12)
+    x = PartitionedVector(gpu_ctx, "x", ip)
+    y = PartitionedVector(gpu_ctx, "yv", ip)
+    x.owned.copy_(torch.randn(n, generator=g, device="cuda", dtype=torch.float64))
+    y.owned.copy_(torch.randn(n, generator=g, device="cuda", dtype=torch.float64))
+    Ax, Ay = matvec(x), matvec(y)
+    xAy, yAx = x.dot(Ay).get_value(), y.dot(Ax).get_value()
+    assert abs(xAy - yAx) <= 1e-12 * (x.dot(x).get_value() * Ay.dot(Ay).get_value()) ** 0.5
+    del Ax, Ay, x, y
+    histories = []
+    for plain in (False, True):
+        if plain:
+            monkeypatch.setenv("LSK_SLICED", "0")
+            monkeypatch.setenv("LSK_COMPRESS", "0")
+            A.sliced_window = A.col32_window = None   # (what the first registration made stays unused)
+        _, planner, solver = bs.build_problem(gpu_ctx, 4, n1, n1, n1, 1, 1, torch.float64, num_systems=1, matrix=A)
+        if plain:
+            assert A.sliced_window is None and A.col32_window is None and A.binned is None
+        else:   # a row-sorted stencil: the sliced-pattern copy, entries counted in 64 bits
+            assert A.sliced and A.sliced_window == (0, n - 1) and A.sliced[0].padded_entries > 2 ** 32
+        for _ in range(3):
+            solver.step()
+        histories.append([r.get_value() for r in solver.residual_norm_squared])
+        del planner, solver
+    assert histories[0][0] == float(n) and all(np.isfinite(h) and h > 0.0 for h in histories[0])
+    np.testing.assert_allclose(histories[0], histories[1], rtol=1e-10)
+
+
 @pytest.mark.parametrize("sliced", ["0", "1"])
 def test_cg_with_tuned_placement(gpu_ctx, monkeypatch, sliced):
     """The planner's set-up-time placement tuning and array redraws (normally only for pieces of
