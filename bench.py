@@ -227,11 +227,20 @@ def library_option(key: str) -> int:
     return value.value
 
 
-def host_ms_per_step(ctx, world: int) -> float:
+def host_ms_per_step(ctx, world: int):
     """What the host spends enqueueing one CG step: the same solver on a 32^3 grid, where the GPU
     finishes a step's kernels faster than the host issues them, so wall time per step is host time."""
     _, _, solver = bs.build_problem(ctx, 4, 32, 32, 32, world, 1, torch.float64, num_systems=1)
-    return bs.timed_steps(ctx, solver, 20, 500) / 500 * 1e3
+    eager = bs.timed_steps(ctx, solver, 20, 500) / 500 * 1e3
+    if world > 1:
+        return eager, None
+    recorded = solver.capture()   # the same step as one HIP graph launch
+    recorded.replay(20)
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    recorded.replay(500)
+    ctx.synchronize()
+    return eager, (time.perf_counter() - t0) / 500 * 1e3
 
 
 def main():
@@ -295,6 +304,17 @@ def main():
     seconds = bs.timed_steps(ctx, solver, args.warmup, args.steps)
     iters_per_s = args.steps / seconds
     rr = solver.residual_norm_squared[-1].get_value()
+    # the same steps replayed from a HIP graph of one step (one rank; reported beside the headline)
+    graph_rate = None
+    if world == 1:
+        recorded = solver.capture()
+        recorded.replay(max(args.warmup, 1))
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        recorded.replay(args.steps)
+        ctx.synchronize()
+        graph_rate = args.steps / (time.perf_counter() - t0)
+        del recorded
 
     # the dominant kernel against its roofline (this rank's launch), priced on the bytes of the
     # layout it reads: the sliced-pattern copy (values in blocks of 512 rows, no column array), else
@@ -397,7 +417,8 @@ def main():
     os.environ.pop("LSK_PAIR")
     del solver2, planner2
     # (LSK_BENCH_HOST_COST=0 leaves it out: a profile of this run then holds launches of one problem size only)
-    host_ms = host_ms_per_step(ctx, world) if os.environ.get("LSK_BENCH_HOST_COST", "1") != "0" else None
+    host_ms, host_ms_graph = (host_ms_per_step(ctx, world) if os.environ.get("LSK_BENCH_HOST_COST", "1") != "0"
+                              else (None, None))
 
     line = {
         "metric": f"CG iters/sec (fp64) on 3D 27-pt stencil {n1}^3, single system (the reference's BenchmarkStencil "
@@ -431,6 +452,8 @@ def main():
         "value_reference_layout": iters_reference_layout,
         "setup_s": {k: round(v, 3) for k, v in setup_s.items()},
         "host_ms_per_step": host_ms,
+        "host_ms_per_step_graph_replay": host_ms_graph,
+        "value_graph_replay": graph_rate,
         "notes": {
             "two_system_iters_per_s": "the reference's BenchmarkStencil as it runs: two systems on one matrix per step; "
                                       "both products share one pass over the matrix values (lsk_csr_sliced_spmv2_*), each "
@@ -452,7 +475,10 @@ def main():
                        "products repeated until 16 in a row take the same time, at most 8 s -- memory freed by a program "
                        "that ran before is scrubbed in the background and slows whatever runs meanwhile)",
             "host_ms_per_step": "wall time per CG step on a 32^3 grid with the same ranks, where the host, not the GPU, "
-                                "is the limit: what enqueueing one step costs",
+                                "is the limit: what enqueueing one step costs; ..._graph_replay: the same step "
+                                "recorded once as a HIP graph and replayed (CGSolver.capture, one rank)",
+            "value_graph_replay": "the headline's steps replayed from a HIP graph of one step (one rank): the same "
+                                  "kernels, one launch call per step",
         },
         "residual_norm_squared_last": rr,
         "roofline": {

@@ -13,10 +13,10 @@ from .index_space import IndexPartition, IndexSpace, Rect
 from .matrices import AbstractMatrix, COOMatrix, CSRMatrix
 from .partitioned_vector import PartitionedVector
 from .scalar import Scalar
-from .solvers import BiCGStabSolver, CGSolver, GMRESSolver
+from .solvers import BiCGStabSolver, CapturedStep, CGSolver, GMRESSolver
 from .square_planner import SquarePlanner
 
 __all__ = [
     "Context", "IndexPartition", "IndexSpace", "Rect", "AbstractMatrix", "COOMatrix", "CSRMatrix",
-    "PartitionedVector", "Scalar", "BiCGStabSolver", "CGSolver", "GMRESSolver", "SquarePlanner",
+    "PartitionedVector", "Scalar", "BiCGStabSolver", "CapturedStep", "CGSolver", "GMRESSolver", "SquarePlanner",
 ]

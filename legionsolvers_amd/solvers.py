@@ -5,13 +5,57 @@ operations; all scalars are device-resident futures, so a step enqueues without 
 """
 from __future__ import annotations
 
-from typing import List
+from typing import List, Sequence
+
+import torch
 
 from .scalar import Scalar
 from .square_planner import SquarePlanner
 
 SOL = 0
 RHS = 1
+
+
+class CapturedStep:
+    """One step() of a solver recorded as a HIP graph: replay() enqueues the step's kernels with one
+    call instead of one per leaf (a third of the host time per step on small systems, where the
+    host is the limit; nothing changes where the GPU is).  Possible because every scalar of a step
+    lives on the device.  No counterpart in the reference (Legion's tracing, which it leaves off for
+    these loops, plays this role there).
+
+    A step reads scalars the step before made (CG: r.r; BiCGStab: rho, alpha, omega) through the
+    tensors of that step; the recording ends by copying the new values into those tensors, so each
+    replay continues from the one before.  The solver's history lists grow by ONE entry when the
+    step is recorded; after every replay that entry holds the newest value (the history of a
+    replayed run is not kept).  The recording starts and ends at SquarePlanner.settle(): no fused
+    leaf reaches across its ends.  One rank only (the exchanges of a multi-rank step are not
+    recorded), on the device's current stream at replay time; the vectors, the matrix copies and the
+    solver must stay as they were when the step was recorded."""
+
+    def __init__(self, solver, carried: Sequence[List[Scalar]]):
+        planner = solver.planner
+        ctx = planner.get_context()
+        if ctx.world_size != 1:
+            raise NotImplementedError("a step can be recorded on one rank only")
+        if ctx.device.type != "cuda":
+            raise NotImplementedError("a step can be recorded on a GPU only")
+        self.solver = solver
+        planner.settle()
+        ctx.synchronize()
+        before = [scalars[-1] for scalars in carried]
+        self.graph = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream(ctx.device)   # (capture needs a stream of its own; default priority)
+        with torch.cuda.graph(self.graph, stream=side):
+            solver.step()
+            planner.settle()
+            for old, scalars in zip(before, carried):
+                ctx.backend.copy(old.get_future(), scalars[-1].get_future())
+        self.replays = 0
+
+    def replay(self, times: int = 1) -> None:
+        for _ in range(times):
+            self.graph.replay()
+        self.replays += times
 
 
 class CGSolver:
@@ -37,6 +81,11 @@ class CGSolver:
         r_norm2_new = pl.dot(self.R, self.R)
         self.residual_norm_squared.append(r_norm2_new)
         pl.xpay(self.P, r_norm2_new, r_norm2_old, self.R)
+
+    def capture(self) -> CapturedStep:
+        """The next step as a replayable HIP graph (CapturedStep); run a few steps first, so that
+        everything a first launch sets up is in place."""
+        return CapturedStep(self, [self.residual_norm_squared])
 
 
 class BiCGStabSolver:
@@ -76,6 +125,10 @@ class BiCGStabSolver:
         pl.axpy(SOL, self.alpha[-1], self.P)
         pl.axpy(SOL, self.omega[-1], self.R)
         pl.axpy(self.R, -self.omega[-1], self.U)
+
+    def capture(self) -> CapturedStep:
+        """The next step as a replayable HIP graph (CapturedStep); run a few steps first."""
+        return CapturedStep(self, [self.rho, self.alpha, self.omega])
 
 
 class GMRESSolver:
@@ -138,3 +191,8 @@ class GMRESSolver:
         coeff = self.dummy_coefficient
         for j in range(self.restart):
             pl.axpy(SOL, coeff, kb(j))
+
+    def capture(self) -> CapturedStep:
+        """The next restart cycle as a replayable HIP graph (CapturedStep): a cycle reads no scalar of
+        the one before; run one cycle first."""
+        return CapturedStep(self, [])

@@ -170,6 +170,17 @@ class SquarePlanner:
     def _scalar(self, s) -> Scalar:
         return s if isinstance(s, Scalar) else Scalar(self.ctx, s, self.dtype)
 
+    def settle(self) -> None:
+        """Brings every vector's storage up to date and forgets what the fused leaves left for a call that
+        may follow (held-back updates run on their own; partial sums of dot products and the dot shares
+        of the last product are dropped): after it, what the next operation launches depends on nothing
+        an earlier one left behind.  The boundary a recorded step needs (solvers.CapturedStep); values
+        are unchanged, later dots are merely computed afresh."""
+        for v in self.sol_vectors + self.rhs_vectors + [w for row in self.workspace_vectors for w in row]:
+            v._settle()
+            v._ready = None
+        self._fused_dot_pending = None
+
     # -- vector operations over all spaces (src/SquarePlanner.hpp:248-338) -----------------
     def zero_fill(self, vec_idx: int) -> None:
         for i in range(self.get_num_spaces()):

@@ -1,0 +1,89 @@
+"""A solver step recorded as a HIP graph (solvers.CapturedStep): every replay against the oracle's
+step of the same number and against a twin solver stepping eagerly, with eager work and
+synchronisations between the replays."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import solvers as S
+
+import host_cases as hc
+
+from legionsolvers_amd import BiCGStabSolver, CGSolver, GMRESSolver
+
+pytestmark = pytest.mark.gpu
+
+
+def _make(solver_name, planner, oracle_side=False):
+    mod = S if oracle_side else None
+    if solver_name == "cg":
+        return (mod.CGSolver if mod else CGSolver)(planner)
+    if solver_name == "bicgstab":
+        return (mod.BiCGStabSolver if mod else BiCGStabSolver)(planner)
+    return (mod.GMRESSolver if mod else GMRESSolver)(planner, 4)
+
+
+def _scalars(solver_name, solver):
+    if solver_name == "cg":
+        return [solver.residual_norm_squared[-1]]
+    if solver_name == "bicgstab":
+        return [solver.rho[-1], solver.alpha[-1], solver.omega[-1]]
+    return [solver.inner_products[j + 1][j] for j in range(solver.restart)]
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("kind,pieces,spaces", [("csr", 1, 1), ("csr", 3, 2), ("coo", 2, 1)])
+@pytest.mark.parametrize("solver_name", ["cg", "bicgstab", "gmres"])
+def test_replayed_steps_follow_the_oracle_and_the_eager_solver(gpu_ctx, solver_name, kind, pieces, spaces, dtype):
+    print(f"case recorded step {solver_name} {kind} pieces={pieces} spaces={spaces} {np.dtype(dtype).name}", flush=True)
+    rects, row, col, val, n = hc.stencil_problem(4, (7, 9, 11), dtype)
+    rhs = np.random.default_rng(77).standard_normal(n)
+    if solver_name != "cg":
+        spaces = 1
+    opl = hc.oracle_planner(kind, rects, row, col, val, n, pieces, dtype, rhs, spaces)
+    so = _make(solver_name, opl, oracle_side=True)
+    eager = _make(solver_name, hc.mirror_planner(gpu_ctx, kind, rects, row, col, val, n, pieces, dtype, rhs, spaces))
+    mpl = hc.mirror_planner(gpu_ctx, kind, rects, row, col, val, n, pieces, dtype, rhs, spaces)
+    sm = _make(solver_name, mpl)
+    warm, replays = 2, 4
+    for _ in range(warm):
+        so.step()
+        eager.step()
+        sm.step()
+    recorded = sm.capture()
+    entries = len(sm.residual_norm_squared) if solver_name == "cg" else None
+    rtol = 1e-10 if dtype == np.float64 else 2e-3
+    for i in range(replays):
+        so.step()
+        eager.step()
+        recorded.replay()
+        torch.cuda.synchronize()
+        got = [s.get_value() for s in _scalars(solver_name, sm)]
+        np.testing.assert_allclose(got, [float(v) for v in _scalars(solver_name, so)], rtol=rtol,
+                                   err_msg=f"replay {i} against the oracle")
+        np.testing.assert_allclose(got, [s.get_value() for s in _scalars(solver_name, eager)],
+                                   rtol=1e-13 if dtype == np.float64 else 1e-5, err_msg=f"replay {i} against eager steps")
+        for space in range(spaces):
+            want = eager.planner.get_vector(0, space).to_host().numpy().astype(np.float64)
+            sol = mpl.get_vector(0, space).to_host().numpy().astype(np.float64)
+            assert np.abs(sol - want).max() <= (1e-12 if dtype == np.float64 else 1e-4) * max(np.abs(want).max(), 1e-300)
+        # eager work of the program's own between the replays
+        scratch = torch.randn(4096, device="cuda")
+        assert torch.isfinite(scratch.sum()).item()
+    if entries is not None:
+        assert len(sm.residual_norm_squared) == entries   # the history of replayed steps is not kept
+    assert recorded.replays == replays
+    # and eager steps go on from where the replays stopped
+    so.step()
+    sm.step()
+    got = [s.get_value() for s in _scalars(solver_name, sm)]
+    np.testing.assert_allclose(got, [float(v) for v in _scalars(solver_name, so)], rtol=rtol)
+
+
+def test_recording_is_refused_where_it_cannot_work(gpu_ctx, monkeypatch):
+    rects, row, col, val, n = hc.stencil_problem(4, (5, 5, 5), np.float64)
+    mpl = hc.mirror_planner(gpu_ctx, "csr", rects, row, col, val, n, 1, np.float64, np.ones(n), 1)
+    solver = CGSolver(mpl)
+    monkeypatch.setattr(gpu_ctx.comm, "world_size", 2)
+    with pytest.raises(NotImplementedError):
+        solver.capture()
