@@ -11,7 +11,10 @@
 // through the binned copy of the COO matrix, in blocks of -bincols columns and tiles of -binrows rows
 // (0: the library's choice); -cgs 1 gives GMRES the classical Gram-Schmidt option; -pair 0 multiplies the two
 // systems one after the other instead of in one pass over the matrix; -uniform 1 sets the library's option
-// "sliced.uniform" (a constant-coefficient stencil's values as scalars: the products read no value array).
+// "sliced.uniform" (a constant-coefficient stencil's values as scalars: the products read no value array);
+// -graph 1 makes the traces real: the first warm-up trace runs as it is, then the -pt steps of a trace are
+// recorded once as a HIP graph (LegionSolversHost::Trace) and every further trace is one replay (the
+// reference records and replays Legion traces here, :219-222; -history then prints the last values only).
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -28,7 +31,7 @@ namespace {
 struct Args {
     long dim = 1, solver = 1, nx = 16, ny = 16, nz = 16, vp = 4, it = 20, pt = 1;
     long systems = 2, coo = 0, f32 = 0, restart = 10, history = 0, compress = 1, fuse = 1, redraws = 0, adjoint = 0, sliced = 1;
-    long binned = 0, bincols = 0, binrows = 0, cgs = 0, pair = 1, uniform = 0;
+    long binned = 0, bincols = 0, binrows = 0, cgs = 0, pair = 1, uniform = 0, graph = 0;
 };
 
 Args parse(int argc, char **argv) {
@@ -41,7 +44,7 @@ Args parse(int argc, char **argv) {
         {"-redraws", &Args::redraws}, {"-adjoint", &Args::adjoint},
         {"-sliced", &Args::sliced}, {"-binned", &Args::binned}, {"-bincols", &Args::bincols},
         {"-binrows", &Args::binrows}, {"-cgs", &Args::cgs}, {"-pair", &Args::pair},
-        {"-uniform", &Args::uniform}};
+        {"-uniform", &Args::uniform}, {"-graph", &Args::graph}};
     for (int i = 1; i + 1 < argc; i += 2) {
         bool known = false;
         for (const auto &t : table)
@@ -67,19 +70,27 @@ void run(const Context &ctx, const Args &a, Solver &solver, SquarePlanner<T> &pl
     const long num_warmup_traces = 5;
     const long num_traces = (a.it + a.pt - 1) / a.pt;
     ctx.synchronize();
-    for (long i = 0; i < num_warmup_traces; ++i)
-        for (long j = 0; j < a.pt; ++j) solver.step();
+    std::unique_ptr<Trace<T, Solver>> trace;
+    auto one_trace = [&](long i) {
+        if (a.graph && i > 0) {
+            if (!trace) trace = std::make_unique<Trace<T, Solver>>(ctx, planner, solver, a.pt);
+            trace->replay();
+        } else {
+            for (long j = 0; j < a.pt; ++j) solver.step();
+        }
+    };
+    for (long i = 0; i < num_warmup_traces; ++i) one_trace(i);
     ctx.synchronize();
     const auto begin = std::chrono::steady_clock::now();
     std::cout << "Performed " << num_warmup_traces << " warmup traces." << std::endl;
-    for (long i = num_warmup_traces; i < num_traces; ++i)
-        for (long j = 0; j < a.pt; ++j) solver.step();
+    for (long i = num_warmup_traces; i < num_traces; ++i) one_trace(i);
     ctx.synchronize();
     const auto end = std::chrono::steady_clock::now();
     std::cout << "Performed " << (num_traces - num_warmup_traces) << " timed traces." << std::endl;
     const double ns = std::chrono::duration<double, std::nano>(end - begin).count();
     const double ns_per_iter = ns / static_cast<double>(a.pt * std::max<long>(num_traces - num_warmup_traces, 1));
     std::cout << "Achieved " << ns_per_iter / 1.0e6 << "ms per iteration." << std::endl;
+    if (a.graph && trace) std::printf("trace_nodes %lld\n", static_cast<long long>(trace->nodes()));
     if (a.history) {
         print_history(solver);
         const auto x = planner.get_vector(0, 0).to_host();

@@ -93,28 +93,39 @@ public:
     // the device, once per scalar per solver step otherwise).  A recycled slot is rewritten by a
     // kernel enqueued after every reader of its old value: everything runs on the one stream.
     void *acquire_slot() const {
-        if (free_slots_.empty()) {
-            constexpr size_t kChunk = 4096;
-            void *chunk = nullptr;
-            check(lsk_malloc(&chunk, kChunk * 8));
-            chunks_.push_back(chunk);
-            for (size_t i = kChunk; i-- > 0;) free_slots_.push_back(static_cast<char *>(chunk) + 8 * i);
-        }
+        if (free_slots_.empty()) add_slots();
         void *slot = free_slots_.back();
         free_slots_.pop_back();
         return slot;
     }
-    void release_slot(void *slot) const { free_slots_.push_back(slot); }
+    // At least `count` free slots without another allocation (nothing may allocate while a trace records).
+    void reserve_slots(size_t count) const {
+        while (free_slots_.size() < count) add_slots();
+    }
+    void release_slot(void *slot) const { (parked_ ? *parked_ : free_slots_).push_back(slot); }
+    // While a trace records, the scalars of the recorded steps must keep their slots for as long as the
+    // trace may be replayed (a replay writes them again): slots released meanwhile go to `parked`
+    // instead of back into circulation (Trace hands them back when it is destroyed).
+    void park_released_slots(std::vector<void *> *parked) const { parked_ = parked; }
+    void return_slots(const std::vector<void *> &slots) const { free_slots_.insert(free_slots_.end(), slots.begin(), slots.end()); }
     lsk_stream_t stream() const { return stream_; }
     void *workspace() const { return workspace_; }
     size_t workspace_bytes() const { return workspace_bytes_; }
     void synchronize() const { check(lsk_stream_synchronize(stream_)); }
 
 private:
+    void add_slots() const {
+        constexpr size_t kChunk = 4096;
+        void *chunk = nullptr;
+        check(lsk_malloc(&chunk, kChunk * 8));
+        chunks_.push_back(chunk);
+        for (size_t i = kChunk; i-- > 0;) free_slots_.push_back(static_cast<char *>(chunk) + 8 * i);
+    }
     lsk_stream_t stream_ = nullptr;
     void *workspace_ = nullptr;
     size_t workspace_bytes_ = 0;
     mutable std::vector<void *> chunks_, free_slots_;
+    mutable std::vector<void *> *parked_ = nullptr;
 };
 
 // Device memory that frees itself.
@@ -241,6 +252,7 @@ public:
     const EqualPartition &partition() const { return part_; }
     const std::string &name() const { return name_; }
     T *data() const { settle(); return data_.get(); }
+    void settle_now() const { settle(); } // run a held-back update on its own (SquarePlanner::settle)
     T *piece(int c) const { settle(); return raw_piece(c); }
     std::vector<T> to_host() const { settle(); return data_.to_host(*ctx_); }
 
@@ -980,6 +992,14 @@ public:
     // any other operation of the planner, only adds up.  set_fusion(false) launches every leaf as it
     // is asked for.
     void set_fusion(bool on) { fuse_ = on; }
+    // Brings every vector's storage up to date and forgets what a fused leaf left for a call that may
+    // follow: after it, what the next operation launches depends on nothing an earlier one left
+    // behind.  The two ends of a recorded trace (Trace below).
+    void settle() {
+        pending_.reset();
+        for (auto &row : vectors_)
+            for (auto *v : row) v->settle_now();
+    }
     // Whether two systems on one matrix are multiplied in one pass over it (same results either way).
     void set_pairing(bool on) { pair_ = on; }
     long paired_products() const { return paired_products_; } // how many times two products shared a pass
@@ -1263,6 +1283,74 @@ private:
     int restart;
     bool classical_;
     Scalar<T> negative_one, dummy_coefficient;
+};
+
+// The scalars a step reads from the step before it (each solver's history vectors).
+template <typename T> std::vector<std::vector<Scalar<T>> *> carried_scalars(CGSolver<T> &s) { return {&s.residual_norm_squared}; }
+template <typename T> std::vector<std::vector<Scalar<T>> *> carried_scalars(BiCGStabSolver<T> &s) { return {&s.rho, &s.alpha, &s.omega}; }
+template <typename T> std::vector<std::vector<Scalar<T>> *> carried_scalars(GMRESSolver<T> &) { return {}; }
+
+// `steps` solver steps recorded once and replayed with one call each time: what rt->begin_trace /
+// rt->end_trace around the steps are in the reference's benchmark (test/BenchmarkStencil.cpp:219-222),
+// as a HIP graph (lsk_stream_begin_capture / lsk_trace_replay).  Recording executes nothing; every
+// replay() is `steps` steps.  The recording starts and ends at SquarePlanner::settle(), and ends by
+// copying the newest value of every scalar a step reads from the step before (carried_scalars) into
+// the slot the first recorded step read it from, so a replay continues from the one before.  The
+// solver's history vectors grow by `steps` entries when the trace is recorded; after a replay the last
+// entry holds the newest value, and so does the entry the recording started from (the history of
+// replayed steps is not kept).  Run the solver a few
+// steps before recording (a kernel's first launch on a device is not recordable); the vectors, the
+// matrix and the solver must stay as they were for as long as the trace is replayed.
+template <typename T, typename Solver> class Trace {
+public:
+    Trace(const Context &ctx, SquarePlanner<T> &planner, Solver &solver, long steps = 1) : ctx_(&ctx) {
+        planner.settle();
+        ctx.synchronize();
+        const auto carried = carried_scalars<T>(solver);
+        std::vector<Scalar<T>> before;
+        for (auto *history : carried) before.push_back(history->back());
+        ctx.reserve_slots(static_cast<size_t>(steps) * kSlotsPerStep); // (slots released while recording are not reused)
+        ctx.park_released_slots(&parked_);
+        check(lsk_stream_begin_capture(ctx.stream()));
+        int status = LSK_OK;
+        try {
+            for (long i = 0; i < steps; ++i) solver.step();
+            planner.settle();
+            for (size_t i = 0; i < carried.size(); ++i)
+                check(Abi<T>::copy(1, carried[i]->back().get_future(), before[i].writable(), ctx.stream()));
+        } catch (...) {
+            lsk_trace_t *spoiled = nullptr;
+            (void)lsk_stream_end_capture(ctx.stream(), &spoiled);
+            lsk_trace_destroy(spoiled);
+            ctx.park_released_slots(nullptr);
+            ctx.return_slots(parked_);
+            throw;
+        }
+        status = lsk_stream_end_capture(ctx.stream(), &trace_);
+        ctx.park_released_slots(nullptr);
+        keep_ = std::move(before);
+        check(status);
+    }
+    Trace(const Trace &) = delete;
+    Trace &operator=(const Trace &) = delete;
+    ~Trace() {
+        lsk_stream_synchronize(ctx_->stream());
+        lsk_trace_destroy(trace_);
+        ctx_->return_slots(parked_);
+    }
+    void replay() { check(lsk_trace_replay(trace_, ctx_->stream())); }
+    int64_t nodes() const {
+        int64_t out[2] = {0, 0};
+        check(lsk_trace_info(trace_, out));
+        return out[0];
+    }
+
+private:
+    static constexpr size_t kSlotsPerStep = 4096; // more scalars than a step of any of the solvers makes (GMRES(64): ~2300)
+    const Context *ctx_;
+    lsk_trace_t *trace_ = nullptr;
+    std::vector<void *> parked_;
+    std::vector<Scalar<T>> keep_; // the slots the first recorded step reads
 };
 
 } // namespace LegionSolversHost

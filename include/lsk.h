@@ -99,6 +99,29 @@ int lsk_stream_synchronize(lsk_stream_t stream);
  * (src/CUDAUtilities.hpp:25-29), which the reference runs at task exit in debug builds. */
 int lsk_stream_check(lsk_stream_t stream);
 
+/* Traces.  The reference's benchmark wraps every `-pt` solver steps in a Legion trace
+ * (rt->begin_trace / rt->end_trace, test/BenchmarkStencil.cpp:219-222,237-240): the first pass records the
+ * task launches, later passes replay them without the analysis.  Here the counterpart is a HIP graph:
+ * between lsk_stream_begin_capture and lsk_stream_end_capture the leaf calls on `stream` are recorded,
+ * NOT executed; lsk_trace_replay enqueues the whole recording on a stream with one call.  What may be
+ * recorded: every leaf that only enqueues kernels (BLAS-1 with device-resident futures, the scalar
+ * tasks, lsk_sum_partials_*, the products; lsk_memcpy_d2d) once it has run at least once on the device
+ * outside a recording; not the calls that read a result on the host, allocate, synchronise or time
+ * (lsk_dot_host_*, create / update / tune / info calls, lsk_malloc, lsk_stream_synchronize).  A HIP
+ * call that fails inside a recording (an allocation, say) spoils it: lsk_stream_end_capture then returns
+ * an error and no trace, and the stream may stay unusable: destroy it (a call that this library refuses
+ * for its arguments enqueued nothing and spoils nothing).  The recording refers to the device memory its calls were given; the caller keeps that
+ * memory, and what it holds between replays is the caller's business (a solver step that reads a
+ * scalar of the step before needs it where the recorded kernels look for it).  One thread records
+ * on one stream at a time; other threads' launches on other streams go on meanwhile. */
+typedef struct lsk_trace lsk_trace_t;
+int lsk_stream_begin_capture(lsk_stream_t stream);
+int lsk_stream_end_capture(lsk_stream_t stream, lsk_trace_t **trace);
+int lsk_trace_replay(const lsk_trace_t *trace, lsk_stream_t stream);
+/* out2[0] = kernel and copy nodes of the recording, out2[1] = replays so far. */
+int lsk_trace_info(const lsk_trace_t *trace, int64_t *out2);
+int lsk_trace_destroy(lsk_trace_t *trace);
+
 int lsk_memcpy_h2d(void *dst_dev, const void *src_host, size_t bytes, lsk_stream_t stream);
 int lsk_memcpy_d2h(void *dst_host, const void *src_dev, size_t bytes, lsk_stream_t stream);
 int lsk_memcpy_d2d(void *dst_dev, const void *src_dev, size_t bytes, lsk_stream_t stream);

@@ -65,6 +65,11 @@ PROTOTYPES = {
     "lsk_stream_destroy": (_i, [_p]),
     "lsk_stream_synchronize": (_i, [_p]),
     "lsk_stream_check": (_i, [_p]),
+    "lsk_stream_begin_capture": (_i, [_p]),
+    "lsk_stream_end_capture": (_i, [_p, ctypes.POINTER(_p)]),
+    "lsk_trace_replay": (_i, [_p, _p]),
+    "lsk_trace_info": (_i, [_p, _p]),
+    "lsk_trace_destroy": (_i, [_p]),
     "lsk_memcpy_h2d": (_i, [_p, _p, _sz, _p]),
     "lsk_memcpy_d2h": (_i, [_p, _p, _sz, _p]),
     "lsk_memcpy_d2d": (_i, [_p, _p, _sz, _p]),

@@ -117,6 +117,9 @@ def main(argv=None):
     ap.add_argument("-vp", type=int, default=4)
     ap.add_argument("-it", type=int, default=20)
     ap.add_argument("-pt", type=int, default=1)
+    ap.add_argument("-graph", type=int, default=0,
+                    help="1: after the first trace the -pt steps of a trace are recorded once as a HIP graph and every "
+                         "further trace is one replay (one rank), as the reference replays its Legion traces")
     args = ap.parse_args(argv)
     world, local_rank = init_distributed()
     ctx = Context(torch.device("cuda", local_rank))
@@ -125,7 +128,18 @@ def main(argv=None):
     num_traces = (args.it + args.pt - 1) // args.pt
     warm = num_warmup_traces * args.pt
     timed = max(num_traces - num_warmup_traces, 0) * args.pt
-    seconds = timed_steps(ctx, solver, warm, timed)
+    if args.graph:
+        for _ in range(args.pt):     # the first trace as it is
+            solver.step()
+        recorded = solver.capture(args.pt)
+        recorded.replay(num_warmup_traces - 1)
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        recorded.replay(max(num_traces - num_warmup_traces, 0))
+        ctx.synchronize()
+        seconds = time.perf_counter() - t0
+    else:
+        seconds = timed_steps(ctx, solver, warm, timed)
     if ctx.rank == 0:
         print(f"Performed {num_warmup_traces} warmup traces.")
         print(f"Performed {max(num_traces - num_warmup_traces, 0)} timed traces.")

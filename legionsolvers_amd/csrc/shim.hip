@@ -229,6 +229,89 @@ int lsk_stream_check(lsk_stream_t stream) {
     return LSK_OK;
 }
 
+// ---- traces: a recorded sequence of leaf calls as a HIP graph ---------------------------
+
+} // extern "C"
+
+struct lsk_trace {
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    int64_t nodes = 0;
+    mutable int64_t replays = 0;
+};
+
+extern "C" {
+
+int lsk_stream_begin_capture(lsk_stream_t stream) {
+    if (!stream) return lsk::fail(LSK_ERR_ARG, "lsk_stream_begin_capture: the default stream cannot record");
+    hipStreamCaptureStatus status = hipStreamCaptureStatusNone;
+    LSK_HIP(hipStreamIsCapturing(lsk::as_stream(stream), &status));
+    if (status != hipStreamCaptureStatusNone)
+        return lsk::fail(LSK_ERR_ARG, "lsk_stream_begin_capture: the stream is recording already");
+    // thread-local mode: only this thread's unsafe calls (allocation, synchronisation) spoil the recording
+    LSK_HIP(hipStreamBeginCapture(lsk::as_stream(stream), hipStreamCaptureModeThreadLocal));
+    return LSK_OK;
+}
+
+int lsk_stream_end_capture(lsk_stream_t stream, lsk_trace_t **trace) {
+    if (!trace) return lsk::fail(LSK_ERR_ARG, "lsk_stream_end_capture: null output");
+    *trace = nullptr;
+    hipStreamCaptureStatus status = hipStreamCaptureStatusNone;
+    // (asked before HIP is: its refusal to end what never began would stay behind as the thread's last
+    // error; a query that fails itself means a spoiled recording, which must still be ended)
+    if (hipStreamIsCapturing(lsk::as_stream(stream), &status) == hipSuccess && status == hipStreamCaptureStatusNone)
+        return lsk::fail(LSK_ERR_ARG, "lsk_stream_end_capture: the stream is not recording");
+    hipGraph_t graph = nullptr;
+    const hipError_t ended = hipStreamEndCapture(lsk::as_stream(stream), &graph);
+    if (ended != hipSuccess || !graph) {
+        for (int i = 0; i < 4 && hipGetLastError() != hipSuccess; ++i) {} // the spoiled recording's error must not meet a later launch check
+        if (graph) (void)hipGraphDestroy(graph);
+        return lsk::hip_fail(ended != hipSuccess ? ended : hipErrorStreamCaptureInvalidated,
+                             "hipStreamEndCapture (a call inside the recording failed: no trace, and the stream may stay unusable)",
+                             __FILE__, __LINE__);
+    }
+    lsk_trace *t = new lsk_trace;
+    t->graph = graph;
+    size_t n = 0;
+    hipError_t e = hipGraphGetNodes(graph, nullptr, &n);
+    if (e == hipSuccess) e = hipGraphInstantiate(&t->exec, graph, nullptr, nullptr, 0);
+    if (e != hipSuccess) {
+        (void)hipGraphDestroy(graph);
+        delete t;
+        return lsk::hip_fail(e, "hipGraphInstantiate", __FILE__, __LINE__);
+    }
+    t->nodes = static_cast<int64_t>(n);
+    *trace = t;
+    return LSK_OK;
+}
+
+int lsk_trace_replay(const lsk_trace_t *trace, lsk_stream_t stream) {
+    if (!trace || !trace->exec) return lsk::fail(LSK_ERR_ARG, "lsk_trace_replay: null trace");
+    LSK_HIP(hipGraphLaunch(trace->exec, lsk::as_stream(stream)));
+    trace->replays += 1;
+    return LSK_OK;
+}
+
+int lsk_trace_info(const lsk_trace_t *trace, int64_t *out2) {
+    if (!trace || !out2) return lsk::fail(LSK_ERR_ARG, "lsk_trace_info: null pointer");
+    out2[0] = trace->nodes;
+    out2[1] = trace->replays;
+    return LSK_OK;
+}
+
+int lsk_trace_destroy(lsk_trace_t *trace) {
+    if (!trace) return LSK_OK;
+    hipError_t e = hipSuccess;
+    if (trace->exec) e = hipGraphExecDestroy(trace->exec);
+    if (trace->graph) {
+        const hipError_t e2 = hipGraphDestroy(trace->graph);
+        if (e == hipSuccess) e = e2;
+    }
+    delete trace;
+    if (e != hipSuccess) return lsk::hip_fail(e, "lsk_trace_destroy", __FILE__, __LINE__);
+    return LSK_OK;
+}
+
 int lsk_memcpy_h2d(void *dst, const void *src, size_t bytes, lsk_stream_t stream) {
     if (bytes == 0) return LSK_OK;
     if (!dst || !src) return lsk::fail(LSK_ERR_ARG, "lsk_memcpy_h2d: null pointer");

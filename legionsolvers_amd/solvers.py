@@ -17,36 +17,42 @@ RHS = 1
 
 
 class CapturedStep:
-    """One step() of a solver recorded as a HIP graph: replay() enqueues the step's kernels with one
-    call instead of one per leaf (a third of the host time per step on small systems, where the
-    host is the limit; nothing changes where the GPU is).  Possible because every scalar of a step
-    lives on the device.  No counterpart in the reference (Legion's tracing, which it leaves off for
-    these loops, plays this role there).
+    """`steps` step()s of a solver recorded once as a HIP graph; every replay() is those steps again,
+    enqueued with one call.  What rt->begin_trace / rt->end_trace around the steps are in the
+    reference's benchmark (test/BenchmarkStencil.cpp:219-222: the first pass records the task launches,
+    later passes replay them), possible here because every scalar of a step lives on the device.
+    Recording executes nothing.  A third of the host time per step on small systems, where the host is
+    the limit; next to nothing where the GPU is.
 
     A step reads scalars the step before made (CG: r.r; BiCGStab: rho, alpha, omega) through the
-    tensors of that step; the recording ends by copying the new values into those tensors, so each
-    replay continues from the one before.  The solver's history lists grow by ONE entry when the
-    step is recorded; after every replay that entry holds the newest value (the history of a
-    replayed run is not kept).  The recording starts and ends at SquarePlanner.settle(): no fused
-    leaf reaches across its ends.  One rank only (the exchanges of a multi-rank step are not
-    recorded), on the device's current stream at replay time; the vectors, the matrix copies and the
-    solver must stay as they were when the step was recorded."""
+    tensors of that step; the recording ends by copying the newest values into the tensors its first
+    step read, so each replay continues from the one before.  The solver's history lists grow by
+    `steps` entries when the steps are recorded; after every replay the last entry holds the newest
+    value, and so does the entry the recording started from (the history of a replayed run is not
+    kept).  The recording starts and ends at SquarePlanner.settle(): no fused leaf reaches across its
+    ends.  One rank only (the exchanges of a multi-rank step are not recorded); replays go to the
+    device's current stream; run a few steps before recording (a kernel's first launch on a device
+    is not recordable), and leave the vectors, the matrix copies and the solver as they were for as
+    long as the recording is replayed."""
 
-    def __init__(self, solver, carried: Sequence[List[Scalar]]):
+    def __init__(self, solver, carried: Sequence[List[Scalar]], steps: int = 1):
         planner = solver.planner
         ctx = planner.get_context()
         if ctx.world_size != 1:
-            raise NotImplementedError("a step can be recorded on one rank only")
+            raise NotImplementedError("steps can be recorded on one rank only")
         if ctx.device.type != "cuda":
-            raise NotImplementedError("a step can be recorded on a GPU only")
-        self.solver = solver
+            raise NotImplementedError("steps can be recorded on a GPU only")
+        if steps < 1:
+            raise ValueError("at least one step")
+        self.solver, self.steps = solver, int(steps)
         planner.settle()
         ctx.synchronize()
         before = [scalars[-1] for scalars in carried]
         self.graph = torch.cuda.CUDAGraph()
         side = torch.cuda.Stream(ctx.device)   # (capture needs a stream of its own; default priority)
         with torch.cuda.graph(self.graph, stream=side):
-            solver.step()
+            for _ in range(self.steps):
+                solver.step()
             planner.settle()
             for old, scalars in zip(before, carried):
                 ctx.backend.copy(old.get_future(), scalars[-1].get_future())
@@ -82,10 +88,10 @@ class CGSolver:
         self.residual_norm_squared.append(r_norm2_new)
         pl.xpay(self.P, r_norm2_new, r_norm2_old, self.R)
 
-    def capture(self) -> CapturedStep:
-        """The next step as a replayable HIP graph (CapturedStep); run a few steps first, so that
-        everything a first launch sets up is in place."""
-        return CapturedStep(self, [self.residual_norm_squared])
+    def capture(self, steps: int = 1) -> CapturedStep:
+        """The next `steps` steps as a replayable HIP graph (CapturedStep); run a few steps first, so
+        that everything a first launch sets up is in place."""
+        return CapturedStep(self, [self.residual_norm_squared], steps)
 
 
 class BiCGStabSolver:
@@ -126,9 +132,9 @@ class BiCGStabSolver:
         pl.axpy(SOL, self.omega[-1], self.R)
         pl.axpy(self.R, -self.omega[-1], self.U)
 
-    def capture(self) -> CapturedStep:
-        """The next step as a replayable HIP graph (CapturedStep); run a few steps first."""
-        return CapturedStep(self, [self.rho, self.alpha, self.omega])
+    def capture(self, steps: int = 1) -> CapturedStep:
+        """The next `steps` steps as a replayable HIP graph (CapturedStep); run a few steps first."""
+        return CapturedStep(self, [self.rho, self.alpha, self.omega], steps)
 
 
 class GMRESSolver:
@@ -192,7 +198,7 @@ class GMRESSolver:
         for j in range(self.restart):
             pl.axpy(SOL, coeff, kb(j))
 
-    def capture(self) -> CapturedStep:
-        """The next restart cycle as a replayable HIP graph (CapturedStep): a cycle reads no scalar of
-        the one before; run one cycle first."""
-        return CapturedStep(self, [])
+    def capture(self, steps: int = 1) -> CapturedStep:
+        """The next `steps` restart cycles as a replayable HIP graph (CapturedStep): a cycle reads no
+        scalar of the one before; run one cycle first."""
+        return CapturedStep(self, [], steps)

@@ -285,14 +285,16 @@ def test_spmv_properties_7pt_fp32_768(gpu_ctx, monkeypatch, n1):
     assert diff <= 2e-6 * float(Ax.owned.abs().max())
 
 
+@pytest.mark.parametrize("graph", [0, 1])
 @pytest.mark.parametrize("solver", [1, 2, 3])
-def test_benchmark_stencil_cli(solver, capsys):
+def test_benchmark_stencil_cli(solver, graph, capsys):
     """The BenchmarkStencil program with the reference's flags (test/BenchmarkStencil.cpp:36-60)
-    and its closing lines (:213-227), CG / BiCGStab / GMRES on a small 27-point problem."""
+    and its closing lines (:213-227), CG / BiCGStab / GMRES on a small 27-point problem; -graph 1: its
+    traces recorded once and replayed."""
     from legionsolvers_amd import benchmark_stencil as bs
-    print(f"case BenchmarkStencil cli solver={solver}", flush=True)
+    print(f"case BenchmarkStencil cli solver={solver} graph={graph}", flush=True)
     bs.main(["-dim", "4", "-nx", "16", "-ny", "12", "-nz", "20", "-vp", "4", "-solver", str(solver),
-             "-it", "12", "-pt", "2"])
+             "-it", "12", "-pt", "2", "-graph", str(graph)])
     out = capsys.readouterr().out
     assert "Performed 5 warmup traces." in out
     assert "Performed 1 timed traces." in out

@@ -161,3 +161,28 @@ def test_scalar_coefficients_print_the_same(solver):
         flags = ("-dim", dim, "-nx", grid[0], "-ny", grid[1], "-nz", grid[2], "-vp", vp, "-solver", solver, "-it", 7,
                  "-restart", 4, "-history", 1)
         assert run(*flags, "-uniform", 1)[2] == run(*flags)[2]
+
+
+@pytest.mark.parametrize("solver,pt", [(1, 1), (1, 3), (2, 2), (3, 1)])
+@pytest.mark.parametrize("coo", [0, 1])
+def test_traces_recorded_as_hip_graphs_print_the_same(solver, pt, coo):
+    """-graph 1: the first trace of -pt steps runs as it is, the next is recorded as a HIP graph
+    (LegionSolversHost::Trace over lsk_stream_begin_capture / lsk_trace_replay) and every further trace is one
+    replay, where the reference replays a Legion trace (test/BenchmarkStencil.cpp:219-222): the same last
+    scalars and the same solution as the steps launched one by one, up to the order of the sums where a
+    fused leaf would have reached across the end of a trace."""
+    flags = ("-dim", 4, "-nx", 11, "-ny", 12, "-nz", 13, "-vp", 3, "-solver", solver, "-it", 7 * pt, "-pt", pt,
+             "-restart", 4, "-history", 1, "-coo", coo)
+    hist_e, sums_e, _ = run(*flags)
+    hist_g, sums_g, raw = run(*flags, "-graph", 1)
+    nodes = int([l for l in raw if l.startswith("trace_nodes")][0].split()[1])
+    assert nodes >= 4 * pt   # a CG step is at least a product, two updates and a fold
+    if solver in (1, 2):
+        # the history holds the start, the first trace's steps and the LAST replay's steps; the entry the
+        # recording started from is where every replay leaves its newest value for the next one
+        assert len(hist_g) == 1 + 2 * pt and len(hist_e) == 1 + 7 * pt
+        np.testing.assert_allclose(hist_g[:pt], hist_e[:pt], rtol=1e-12)
+        np.testing.assert_allclose(hist_g[1 + pt:], hist_e[-pt:], rtol=1e-9)
+        assert hist_g[pt] == hist_g[-1]
+    np.testing.assert_allclose(sums_g["solution_sum_of_squares"], sums_e["solution_sum_of_squares"], rtol=1e-9)
+    assert abs(sums_g["solution_sum"] - sums_e["solution_sum"]) <= 1e-9 * abs(sums_e["solution_sum"]) + 1e-12

@@ -80,6 +80,28 @@ def test_replayed_steps_follow_the_oracle_and_the_eager_solver(gpu_ctx, solver_n
     np.testing.assert_allclose(got, [float(v) for v in _scalars(solver_name, so)], rtol=rtol)
 
 
+@pytest.mark.parametrize("solver_name", ["cg", "bicgstab"])
+def test_a_recording_of_several_steps(gpu_ctx, solver_name):
+    """capture(steps=3): every replay is three steps; the carried scalars come from the LAST of them."""
+    rects, row, col, val, n = hc.stencil_problem(4, (6, 7, 8), np.float64)
+    rhs = np.random.default_rng(78).standard_normal(n)
+    so = _make(solver_name, hc.oracle_planner("csr", rects, row, col, val, n, 2, np.float64, rhs, 1), oracle_side=True)
+    sm = _make(solver_name, hc.mirror_planner(gpu_ctx, "csr", rects, row, col, val, n, 2, np.float64, rhs, 1))
+    for _ in range(2):
+        so.step()
+        sm.step()
+    recorded = sm.capture(steps=3)
+    for i in range(3):
+        for _ in range(3):
+            so.step()
+        recorded.replay()
+        torch.cuda.synchronize()
+        np.testing.assert_allclose([s.get_value() for s in _scalars(solver_name, sm)],
+                                   [float(v) for v in _scalars(solver_name, so)], rtol=1e-9, err_msg=f"replay {i}")
+    with pytest.raises(ValueError):
+        sm.capture(steps=0)
+
+
 def test_recording_is_refused_where_it_cannot_work(gpu_ctx, monkeypatch):
     rects, row, col, val, n = hc.stencil_problem(4, (5, 5, 5), np.float64)
     mpl = hc.mirror_planner(gpu_ctx, "csr", rects, row, col, val, n, 1, np.float64, np.ones(n), 1)
@@ -87,3 +109,61 @@ def test_recording_is_refused_where_it_cannot_work(gpu_ctx, monkeypatch):
     monkeypatch.setattr(gpu_ctx.comm, "world_size", 2)
     with pytest.raises(NotImplementedError):
         solver.capture()
+
+
+def test_c_abi_trace_records_and_replays(gpu_ctx):
+    """lsk_stream_begin_capture / lsk_stream_end_capture / lsk_trace_replay through ctypes on a stream of
+    the library's own: recording executes nothing, every replay is the recorded leaves once more, with
+    eager work and synchronisations between the replays; misuse is refused."""
+    import ctypes
+    from legionsolvers_amd import _lib
+    P = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+    stream = ctypes.c_void_p(0)
+    _lib.call("lsk_stream_create", ctypes.byref(stream))
+    n = 100003
+    x = torch.arange(n, dtype=torch.float64, device="cuda") / n
+    y = torch.zeros(n, dtype=torch.float64, device="cuda")
+    alpha = torch.tensor([0.5], dtype=torch.float64, device="cuda")
+    out = torch.zeros(1, dtype=torch.float64, device="cuda")
+    ws = torch.empty(int(_lib.lib().lsk_dot_workspace_bytes(0)), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+
+    def leaves():
+        # y <- y + alpha x, then out <- y . x
+        _lib.call("lsk_axpy_dev_f64", n, 1, P(alpha), None, None, None, P(x), P(y), stream)
+        _lib.call("lsk_dot_f64", n, P(y), P(x), P(out), P(ws), ws.numel(), stream)
+
+    leaves()                                   # once eagerly: first launches are not recordable
+    _lib.call("lsk_stream_synchronize", stream)
+    y.zero_()
+    torch.cuda.synchronize()
+    trace = ctypes.c_void_p(0)
+    _lib.call("lsk_stream_begin_capture", stream)
+    with pytest.raises(_lib.LskError):          # (the stream is recording already)
+        _lib.call("lsk_stream_begin_capture", stream)
+    leaves()
+    _lib.call("lsk_stream_end_capture", stream, ctypes.byref(trace))
+    assert trace.value
+    _lib.call("lsk_stream_synchronize", stream)
+    assert float(y.abs().max()) == 0.0          # recording executed nothing
+    info = (ctypes.c_int64 * 2)()
+    _lib.call("lsk_trace_info", trace, info)
+    assert info[0] >= 2 and info[1] == 0
+    xx = float((x.double() * x.double()).sum())
+    for k in range(1, 5):
+        _lib.call("lsk_trace_replay", trace, stream)
+        _lib.call("lsk_stream_synchronize", stream)
+        assert torch.equal(y, (0.5 * k) * x) or float((y - 0.5 * k * x).abs().max()) <= 1e-15
+        assert abs(float(out) - 0.5 * k * xx) <= 1e-12 * xx
+        assert torch.isfinite(torch.randn(1000, device="cuda").sum()).item()   # eager work between the replays
+    _lib.call("lsk_trace_info", trace, info)
+    assert info[1] == 4
+    _lib.call("lsk_trace_destroy", trace)
+    # ending a recording that was never begun is an error, not a crash
+    other = ctypes.c_void_p(0)
+    with pytest.raises(_lib.LskError):
+        _lib.call("lsk_stream_end_capture", stream, ctypes.byref(other))
+    assert not other.value
+    with pytest.raises(_lib.LskError):
+        _lib.call("lsk_trace_replay", None, stream)
+    _lib.call("lsk_stream_destroy", stream)
