@@ -8,7 +8,12 @@
  * EXPECTED_CG_OUTPUT (test_all.py:130-133): 100 4900 4704 4512 4324 4140 3960 3784 3612 3444 3280.
  *
  *   gcc -O2 -I include examples/cg_c_abi.c -L legionsolvers_amd -llsk -Wl,-rpath,'$ORIGIN/../legionsolvers_amd' -o examples/cg_c_abi
- *   examples/cg_c_abi [N] [iterations]
+ *   examples/cg_c_abi [N] [iterations] [trace]
+ *
+ * With a third argument the steps after the first are ONE recorded step replayed (lsk_stream_begin_capture /
+ * lsk_trace_replay: what rt->begin_trace / end_trace around solver.step() are in the reference's benchmark,
+ * test/BenchmarkStencil.cpp:219-222): the step works between two fixed scalar slots and ends by moving the
+ * new r.r into the old one's place; the history is copied out after every replay.  Same output.
  */
 #include <stdint.h>
 #include <stdio.h>
@@ -28,6 +33,7 @@
 int main(int argc, char **argv) {
     const int64_t n = argc > 1 ? atoll(argv[1]) : 100;
     const int iterations = argc > 2 ? atoi(argv[2]) : 10;
+    const int traced = argc > 3;
     if (n < 1 || iterations < 0) return 2;
     const int64_t nnz = 3 * n - 2;
 
@@ -56,7 +62,7 @@ int main(int argc, char **argv) {
     CHECK(lsk_malloc(&d_p, vec));
     CHECK(lsk_malloc(&d_q, vec));
     CHECK(lsk_malloc(&d_r, vec));
-    CHECK(lsk_malloc(&d_scal, sizeof(double) * (size_t)(iterations + 3)));
+    CHECK(lsk_malloc(&d_scal, sizeof(double) * (size_t)(iterations + 5)));
     CHECK(lsk_malloc(&d_work, ws));
     CHECK(lsk_memcpy_h2d(d_rects, rects, sizeof(int64_t) * 2 * (size_t)n, s));
     CHECK(lsk_memcpy_h2d(d_col, col, sizeof(int64_t) * (size_t)nnz, s));
@@ -74,15 +80,38 @@ int main(int argc, char **argv) {
     CHECK(lsk_copy_f64(n, b, p, s));
     CHECK(lsk_copy_f64(n, b, r, s));
     CHECK(lsk_dot_f64(n, r, r, rr, d_work, ws, s));
-    for (int it = 0; it < iterations; ++it) {
-        /* Q = A P (beta = 0 replaces the reference's zero fill + accumulate) */
-        CHECK(lsk_csr_spmv_f64(n, nnz, d_rects, 0, d_col, d_val, p, 0, n - 1, q, 0, s));
-        CHECK(lsk_dot_f64(n, p, q, pq, d_work, ws, s));
-        /* x += (rr/pq) P;  R += (-1 * rr / pq) Q;  rr' = R.R;  P = R + (rr'/rr) P */
-        CHECK(lsk_axpy_dev_f64(n, 2, rr + it, pq, NULL, NULL, p, x, s));
-        CHECK(lsk_axpy_dev_f64(n, 3, minus_one, rr + it, pq, NULL, q, r, s));
-        CHECK(lsk_dot_f64(n, r, r, rr + it + 1, d_work, ws, s));
-        CHECK(lsk_xpay_dev_f64(n, 2, rr + it + 1, rr + it, NULL, NULL, r, p, s));
+    /* one step from the r.r in *old to the r.r in *new_ */
+#define CG_STEP(old, new_)                                                                        \
+    do {                                                                                          \
+        /* Q = A P (beta = 0 replaces the reference's zero fill + accumulate) */                  \
+        CHECK(lsk_csr_spmv_f64(n, nnz, d_rects, 0, d_col, d_val, p, 0, n - 1, q, 0, s));          \
+        CHECK(lsk_dot_f64(n, p, q, pq, d_work, ws, s));                                           \
+        /* x += (rr/pq) P;  R += (-1 * rr / pq) Q;  rr' = R.R;  P = R + (rr'/rr) P */             \
+        CHECK(lsk_axpy_dev_f64(n, 2, (old), pq, NULL, NULL, p, x, s));                            \
+        CHECK(lsk_axpy_dev_f64(n, 3, minus_one, (old), pq, NULL, q, r, s));                       \
+        CHECK(lsk_dot_f64(n, r, r, (new_), d_work, ws, s));                                       \
+        CHECK(lsk_xpay_dev_f64(n, 2, (new_), (old), NULL, NULL, r, p, s));                        \
+    } while (0)
+    if (!traced || iterations < 2) {
+        for (int it = 0; it < iterations; ++it) CG_STEP(rr + it, rr + it + 1);
+    } else {
+        /* the first step as it is (a kernel's first launch on a device is not recordable); then one step
+         * between the fixed slots cur and next_, ending with cur <- next_, recorded once and replayed */
+        double *cur = minus_one + 1, *next_ = minus_one + 2;
+        CG_STEP(rr, rr + 1);
+        CHECK(lsk_memcpy_d2d(cur, rr + 1, sizeof(double), s));
+        CHECK(lsk_stream_synchronize(s));
+        lsk_trace_t *trace = NULL;
+        CHECK(lsk_stream_begin_capture(s));
+        CG_STEP(cur, next_);
+        CHECK(lsk_copy_f64(1, next_, cur, s));
+        CHECK(lsk_stream_end_capture(s, &trace));
+        for (int it = 1; it < iterations; ++it) {
+            CHECK(lsk_trace_replay(trace, s));
+            CHECK(lsk_memcpy_d2d(rr + it + 1, cur, sizeof(double), s));
+        }
+        CHECK(lsk_stream_synchronize(s));
+        CHECK(lsk_trace_destroy(trace));
     }
     double *hist = malloc(sizeof(double) * (size_t)(iterations + 1));
     CHECK(lsk_memcpy_d2h(hist, rr, sizeof(double) * (size_t)(iterations + 1), s));
