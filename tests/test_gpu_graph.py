@@ -102,6 +102,67 @@ def test_a_recording_of_several_steps(gpu_ctx, solver_name):
         sm.capture(steps=0)
 
 
+def test_recorded_steps_through_the_binned_coo_copy(gpu_ctx, monkeypatch):
+    """BiCGStab on an unstructured COO matrix whose products go through the binned copy (two passes through
+    LDS, a kernel pair with a raised LDS limit): recorded after two eager steps, replays follow the oracle."""
+    from legionsolvers_amd import COOMatrix
+    monkeypatch.setenv("LSK_COO_BLOCK", "1")
+    monkeypatch.setenv("LSK_COO_BINNED", "2")
+    monkeypatch.setattr(COOMatrix, "BLOCK_MIN_WINDOW", 0)
+    monkeypatch.setattr(COOMatrix, "BINNED_BLOCK_COLS", 256)
+    monkeypatch.setattr(COOMatrix, "BINNED_TILE_ROWS", 512)
+    rng = np.random.default_rng(39)
+    n, per = 6000, 12
+    row = np.repeat(np.arange(n), per).astype(np.int64)
+    col = rng.integers(0, n, size=n * per).astype(np.int64)
+    col[::per] = np.arange(n)
+    val = rng.uniform(-1, 1, size=n * per)
+    val[::per] = 2.0 * per
+    rhs = rng.standard_normal(n)
+    so = S.BiCGStabSolver(hc.oracle_planner("coo", None, row, col, val, n, 1, np.float64, rhs))
+    mpl = hc.mirror_planner(gpu_ctx, "coo", None, row, col, val, n, 1, np.float64, rhs)
+    assert mpl.row_partitioned_matrices[0].matrix.binned is not None
+    sm = BiCGStabSolver(mpl)
+    for _ in range(2):
+        so.step()
+        sm.step()
+    recorded = sm.capture()
+    for i in range(4):
+        so.step()
+        recorded.replay()
+        torch.cuda.synchronize()
+        np.testing.assert_allclose([s.get_value() for s in _scalars("bicgstab", sm)],
+                                   [float(v) for v in _scalars("bicgstab", so)], rtol=1e-9, err_msg=f"replay {i}")
+    want = so.planner.get_vector(0, 0)
+    got = mpl.get_vector(0, 0).to_host().numpy()
+    assert np.abs(got - want).max() <= 1e-9 * np.abs(want).max()
+
+
+@pytest.mark.parametrize("sliced,compress", [("0", "1"), ("0", "0")])
+def test_recorded_steps_on_the_general_csr_kernels(gpu_ctx, monkeypatch, sliced, compress):
+    """CG with the sliced-pattern copy off: the products of the recorded step run on the 32-bit copy of
+    the structure, or on the int64 arrays as handed over."""
+    monkeypatch.setenv("LSK_SLICED", sliced)
+    monkeypatch.setenv("LSK_COMPRESS", compress)
+    rects, row, col, val, n = hc.stencil_problem(4, (9, 8, 7), np.float64)
+    rhs = np.random.default_rng(79).standard_normal(n)
+    so = S.CGSolver(hc.oracle_planner("csr", rects, row, col, val, n, 3, np.float64, rhs))
+    mpl = hc.mirror_planner(gpu_ctx, "csr", rects, row, col, val, n, 3, np.float64, rhs)
+    matrix = mpl.row_partitioned_matrices[0].matrix
+    assert not matrix.sliced and (matrix.col32 is not None) == (compress == "1")
+    sm = CGSolver(mpl)
+    for _ in range(2):
+        so.step()
+        sm.step()
+    recorded = sm.capture()
+    for i in range(4):
+        so.step()
+        recorded.replay()
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(sm.residual_norm_squared[-1].get_value(), float(so.residual_norm_squared[-1]),
+                                   rtol=1e-10, err_msg=f"replay {i}")
+
+
 def test_recording_is_refused_where_it_cannot_work(gpu_ctx, monkeypatch):
     rects, row, col, val, n = hc.stencil_problem(4, (5, 5, 5), np.float64)
     mpl = hc.mirror_planner(gpu_ctx, "csr", rects, row, col, val, n, 1, np.float64, np.ones(n), 1)
