@@ -388,7 +388,7 @@ public:
     }
 
 private:
-    static constexpr int kPartials = 2048; // partial sums a fused leaf writes per piece, at most
+    static constexpr int kPartials = LSK_MAX_PARTIALS; // partial sums a fused leaf writes per piece, at most
     struct Deferred {
         PartitionedVector *z, *p; // z <- fma(alpha, p, z), not launched yet
         std::vector<Scalar<T>> scalars;

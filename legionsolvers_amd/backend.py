@@ -98,7 +98,7 @@ class HipBackend:
         _lib.call(f"lsk_xpay_dev_{_lib.suffix(y.dtype)}", y.numel(), nf, *p, _ptr(x), _ptr(y), self.stream())
 
     # -- fused forms -----------------------------------------------------------------------
-    SQNORM_SLOTS = 2048  # partial sums lsk_axpy_sqnorm_* writes at most
+    SQNORM_SLOTS = 16384  # partial sums lsk_axpy_sqnorm_* / lsk_axpy_dot_dev_* write at most (LSK_MAX_PARTIALS)
 
     def axpy_sqnorm(self, y: torch.Tensor, futs, x: torch.Tensor, partials: torch.Tensor) -> int:
         """y <- fma(alpha, x, y); partials[:count] <- shares of sum(y_new^2).  Returns count."""

@@ -402,6 +402,8 @@ __global__ __launch_bounds__(kBlock) void axpy_sqnorm_kernel(int64_t n, Alpha<T>
     if (threadIdx.x == 0) out[blockIdx.x] = total;
 }
 
+constexpr int64_t kMaxPartials = 16384; // partial sums a fused update leaves at most (LSK_MAX_PARTIALS)
+
 template <typename T>
 int launch_axpy_sqnorm(const char *name, int64_t n, Alpha<T> a, const T *x, T *y, T *partials,
                        int64_t capacity, int *count, lsk_stream_t stream, const T *w = nullptr) {
@@ -419,12 +421,20 @@ int launch_axpy_sqnorm(const char *name, int64_t n, Alpha<T> a, const T *x, T *y
     constexpr int VN = Vec<T>::N;
     if (w == y) w = nullptr; // the vector's own squared norm
     const bool vec = lsk::aligned16(y) && lsk::aligned16(x) && (!w || lsk::aligned16(w));
-    const int blocks = vec ? stream_grid(n / VN + 1) : stream_grid(n);
-    if (capacity < blocks)
-        return lsk::fail(LSK_ERR_ARG, "%s: room for %lld partial sums, %d needed", name, (long long)capacity, blocks);
+    const bool nt = vec && stream_past_caches(n, sizeof(T));
+    // Vectors that no cache holds run faster the more workgroups share them (one 16 KiB chunk each: 3-5 % over
+    // 2048 looping workgroups, tools/blas1_shapes.py); every workgroup leaves one partial sum, so the room the
+    // caller offers decides: 2048 slots are always enough, up to kMaxPartials are used when they are there.
+    const int least = vec ? stream_grid(n / VN + 1) : stream_grid(n);
+    if (capacity < least)
+        return lsk::fail(LSK_ERR_ARG, "%s: room for %lld partial sums, %d needed", name, (long long)capacity, least);
+    int blocks = least;
+    if (nt) {
+        const int64_t most = std::min<int64_t>(std::min<int64_t>(stream_grid(n / VN + 1, true), capacity), kMaxPartials);
+        if (most > blocks) blocks = static_cast<int>(most);
+    }
     hipStream_t s = lsk::as_stream(stream);
     const int form = lsk::options().blas1_form;
-    const bool nt = vec && stream_past_caches(n, sizeof(T));
     if (w) {
         if (nt) axpy_sqnorm_kernel<T, V, VN, true, true><<<blocks, kBlock, 0, s>>>(n, a, x, y, partials, form, w);
         else if (vec) axpy_sqnorm_kernel<T, V, VN, true><<<blocks, kBlock, 0, s>>>(n, a, x, y, partials, form, w);
