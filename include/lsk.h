@@ -250,12 +250,12 @@ int lsk_xpay_dev_f64(int64_t n, int nf, const double *f0, const double *f1, cons
 /* Fused axpy and squared norm: y <- fma(alpha, x, y) exactly as lsk_axpy_* / lsk_axpy_dev_*, and
  * partials[0 .. *count) <- per-workgroup shares of sum_i y_new[i]^2 (`capacity` is the room in
  * `partials`: 2048 slots are always enough; vectors of 256 MiB and more use up to LSK_MAX_PARTIALS =
- * 16384 when they are there, a few per cent faster, and the count -- hence the order of the sum --
+ * 65536 when they are there, a few per cent faster, and the count -- hence the order of the sum --
  * follows the room offered; *count is written on the host).  lsk_sum_partials_* turns them into
  * the dot product y.y when the caller wants it.  Saves the second pass over y that AxpyTask
  * followed by DotTask(v, v) makes (src/CGSolver.hpp:49-51: r <- r - alpha q; r.r).  No
  * counterpart in the reference, whose tasks are launched one by one. */
-#define LSK_MAX_PARTIALS 16384
+#define LSK_MAX_PARTIALS 65536
 int lsk_axpy_sqnorm_f32(int64_t n, float alpha, const float *x, float *y, float *partials,
                         int64_t capacity, int *count, lsk_stream_t stream);
 int lsk_axpy_sqnorm_f64(int64_t n, double alpha, const double *x, double *y, double *partials,

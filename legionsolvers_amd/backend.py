@@ -98,7 +98,12 @@ class HipBackend:
         _lib.call(f"lsk_xpay_dev_{_lib.suffix(y.dtype)}", y.numel(), nf, *p, _ptr(x), _ptr(y), self.stream())
 
     # -- fused forms -----------------------------------------------------------------------
-    SQNORM_SLOTS = 16384  # partial sums lsk_axpy_sqnorm_* / lsk_axpy_dot_dev_* write at most (LSK_MAX_PARTIALS)
+    SQNORM_SLOTS = 65536  # partial sums lsk_axpy_sqnorm_* / lsk_axpy_dot_dev_* write at most (LSK_MAX_PARTIALS)
+
+    def sqnorm_slots(self, t: torch.Tensor) -> int:
+        """Room to offer for the partial sums of a fused update of `t`: 2048 always suffice; a vector that no
+        cache holds is updated a few per cent faster with one workgroup (one partial sum) per 16 KiB."""
+        return min(max(t.numel() * t.element_size() // 16384 + 1, 2048), self.SQNORM_SLOTS)
 
     def axpy_sqnorm(self, y: torch.Tensor, futs, x: torch.Tensor, partials: torch.Tensor) -> int:
         """y <- fma(alpha, x, y); partials[:count] <- shares of sum(y_new^2).  Returns count."""

@@ -402,7 +402,7 @@ __global__ __launch_bounds__(kBlock) void axpy_sqnorm_kernel(int64_t n, Alpha<T>
     if (threadIdx.x == 0) out[blockIdx.x] = total;
 }
 
-constexpr int64_t kMaxPartials = 16384; // partial sums a fused update leaves at most (LSK_MAX_PARTIALS)
+constexpr int64_t kMaxPartials = LSK_MAX_PARTIALS; // partial sums a fused update leaves at most (LSK_MAX_PARTIALS)
 
 template <typename T>
 int launch_axpy_sqnorm(const char *name, int64_t n, Alpha<T> a, const T *x, T *y, T *partials,

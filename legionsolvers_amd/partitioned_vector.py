@@ -256,7 +256,7 @@ class PartitionedVector:
             if not self.piece_sizes[i]:
                 pieces.append((None, 0))
             elif fused:
-                buf = self._partials("sq", i, be.SQNORM_SLOTS)
+                buf = self._partials("sq", i, be.sqnorm_slots(self._piece(i)))
                 pieces.append((buf, be.axpy_sqnorm(self._piece(i), futs, x._piece(i), buf)))
             else:
                 be.axpy(self._piece(i), futs, x._piece(i))
@@ -308,7 +308,7 @@ class PartitionedVector:
                     if not z.piece_sizes[i]:
                         be.sum_partials(0, None, dst)
                         continue
-                    buf = z._partials("ad", i, be.SQNORM_SLOTS)
+                    buf = z._partials("ad", i, be.sqnorm_slots(z._piece(i)))
                     count = be.axpy_dot(z._piece(i), futs, d.p._piece(i), None if other is z else other._piece(i), buf)
                     be.sum_partials(count, buf, dst)
                 if n > 1:

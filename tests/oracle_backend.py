@@ -62,6 +62,9 @@ class OracleBackend:
     # fused forms: one partial sum each, formed by the oracle's own sequential dot
     SQNORM_SLOTS = 1
 
+    def sqnorm_slots(self, t):
+        return 1
+
     def axpy_sqnorm(self, y, futs, x, partials):
         self.axpy(y, futs, x)
         partials[0] = float(oracle.dot(_np(y), _np(y)))
