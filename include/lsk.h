@@ -303,7 +303,7 @@ int lsk_axpy_xpay_dev_f64(int64_t n, int nfa, const double *a0, const double *a1
  *   lsk_multi_axpy_*: y <- fma(c_{k-1}, x[k-1], ... fma(c_0, x[0], y)) with c_j = coef_dev[j], or
  *     -coef_dev[j] when negate != 0: element for element the chain of AxpyTasks y <- y + c_j x[j],
  *     j ascending (bit-identical to k calls of lsk_axpy_dev_*).  partials != NULL: also partials[0 ..
- *     *count) <- per-workgroup shares of sum(y_new^2) (at most 2048), as lsk_axpy_sqnorm_*. */
+ *     *count) <- per-workgroup shares of sum(y_new^2), as lsk_axpy_sqnorm_* (same rule for the room). */
 size_t lsk_multi_dot_workspace_bytes(int k);
 int lsk_multi_dot_f32(int64_t n, int k, const float *const *v, const float *w, float *results_dev,
                       void *workspace, size_t workspace_bytes, lsk_stream_t stream);

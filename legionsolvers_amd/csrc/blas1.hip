@@ -795,11 +795,18 @@ int launch_multi_axpy(const char *name, int64_t n, int k, const T *const *v, con
     constexpr int VN = Vec<T>::N;
     bool vec = lsk::aligned16(w);
     for (int j = 0; j < k; ++j) vec = vec && lsk::aligned16(v[j]);
-    const int blocks = vec ? multi_grid(n / VN + 1) : multi_grid(n);
+    int blocks = vec ? multi_grid(n / VN + 1) : multi_grid(n);
     if (partials && capacity < blocks)
         return lsk::fail(LSK_ERR_ARG, "%s: room for %lld partial sums, %d needed", name, (long long)capacity, blocks);
     hipStream_t s = lsk::as_stream(stream);
     const bool nt = vec && stream_past_caches(n, sizeof(T));
+    // (vectors that no cache holds: one trip per workgroup, as the plain element-wise streams -- as far as the
+    // caller has room for the partial sums, where it wants them: see launch_axpy_sqnorm)
+    if (nt) {
+        int64_t most = std::min<int64_t>(lsk::ceil_div(n / VN + 1, int64_t(kBlock) * 2), int64_t(1) << 30);
+        if (partials) most = std::min<int64_t>(std::min<int64_t>(most, capacity), kMaxPartials);
+        if (most > blocks) blocks = static_cast<int>(most);
+    }
     const int groups = k == 0 ? 1 : (k + kGroup - 1) / kGroup;
     for (int gi = 0; gi < groups; ++gi) {
         const int j0 = gi * kGroup;

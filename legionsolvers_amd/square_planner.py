@@ -312,7 +312,7 @@ class SquarePlanner:
                 if not dst.piece_sizes[p]:
                     pieces.append((None, 0))
                     continue
-                buf = dst._partials("sq", p, 2048)   # (lsk_multi_axpy_* leaves at most 2048)
+                buf = dst._partials("sq", p, be.sqnorm_slots(dst._piece(p)))
                 pieces.append((buf, be.multi_axpy(dst._piece(p), coef, views[p], negate, buf)))
             dst._note_ready(dst, pieces)
 
