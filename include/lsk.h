@@ -70,7 +70,10 @@ void lsk_set_abort_on_error(int enable);
  * "sliced.dma" (1, the default: the wave-staged form sends the windows from memory straight into LDS | 0
  * through registers), "sliced.runs" (1, the default: it reads lists of runs of three run by run | 0 entry
  * by entry), "sliced.pair_form" (lsk_csr_sliced_spmv2_*: 1 wave-staged, one vector after the other | 0
- * both vectors' windows in LDS at once | -1, the default: 1 where that form serves the structure).  No counterpart in the reference
+ * both vectors' windows in LDS at once | -1, the default: 1 where that form serves the structure), "debug.sync" (0, the
+ * default | 1, also LSK_DEBUG_SYNC=1 in the environment: every launch is followed by a synchronisation of the device
+ * and an error check, so an asynchronous fault is reported by the call that caused it: CHECK_CUDA_STREAM of the
+ * reference's debug builds, src/CUDAUtilities.cpp:110-122; not while a stream records).  No counterpart in the reference
  * (cuSPARSE picks its own algorithm behind CUSPARSE_SPMV_ALG_DEFAULT).  All other options
  * are process-wide and read at launch time without synchronisation: set them between launches. */
 int lsk_set_option(const char *key, int value);

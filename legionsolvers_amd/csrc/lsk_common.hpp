@@ -29,7 +29,19 @@ int hip_fail(hipError_t status, const char *expr, const char *file, int line);
     } while (false)
 
 // After a kernel launch: surfaces launch-configuration errors without synchronising.
-#define LSK_LAUNCH_CHECK() LSK_HIP(hipGetLastError())
+// After every launch: the launch's own status and, with option "debug.sync" (LSK_DEBUG_SYNC=1), the whole
+// device waited for and its pending asynchronous error reported at THIS call site -- what the reference's
+// debug builds do at task exit (CHECK_CUDA_STREAM, src/CUDAUtilities.cpp:110-122).
+#define LSK_LAUNCH_CHECK()                                                                           \
+    do {                                                                                             \
+        LSK_HIP(hipGetLastError());                                                                  \
+        if (lsk::debug_sync()) {                                                                     \
+            LSK_HIP(hipDeviceSynchronize());                                                         \
+            LSK_HIP(hipGetLastError());                                                              \
+        }                                                                                            \
+    } while (false)
+
+bool debug_sync(); // option "debug.sync"
 
 constexpr int kBlock = 256;          // threads per workgroup: 4 wave64
 constexpr int kWave = 64;            // CDNA wavefront width
@@ -104,6 +116,7 @@ struct Options {
     // Two right-hand sides: 1 wave-staged, one vector after the other through one LDS area; 0 both
     // vectors' windows in LDS at once (block-staged); -1: 1 where the wave-staged form serves.
     int sliced_pair_form = -1;
+    int debug_sync = 0;       // every launch followed by a device synchronisation and an error check
 };
 Options &options();
 

@@ -57,10 +57,13 @@ Options &options() {
             if (v == 0 || v == 4 || v == 8) o.csr_max_units = v;
         }
         if (const char *e = std::getenv("LSK_COO_VARIANT")) o.coo_variant = std::atoi(e) != 0;
+        if (const char *e = std::getenv("LSK_DEBUG_SYNC")) o.debug_sync = std::atoi(e) != 0;
         return o;
     }();
     return opts;
 }
+
+bool debug_sync() { return options().debug_sync != 0; }
 
 int &xcd_remap_option() {
     static const int initial = [] {
@@ -131,6 +134,8 @@ int lsk_set_option(const char *key, int value) {
         o.sliced_runs = value != 0;
     } else if (!std::strcmp(key, "sliced.uniform")) {
         o.sliced_uniform = value != 0;
+    } else if (!std::strcmp(key, "debug.sync")) {
+        o.debug_sync = value != 0;
     } else if (!std::strcmp(key, "sliced.pair_form")) {
         if (value < -1 || value > 1) return lsk::fail(LSK_ERR_ARG, "sliced.pair_form must be -1, 0 or 1");
         o.sliced_pair_form = value;
@@ -157,6 +162,7 @@ int lsk_get_option(const char *key, int *value) {
     else if (!std::strcmp(key, "sliced.runs")) *value = o.sliced_runs;
     else if (!std::strcmp(key, "sliced.uniform")) *value = o.sliced_uniform;
     else if (!std::strcmp(key, "sliced.pair_form")) *value = o.sliced_pair_form;
+    else if (!std::strcmp(key, "debug.sync")) *value = o.debug_sync;
     else return lsk::fail(LSK_ERR_ARG, "lsk_get_option: unknown key '%s'", key);
     return LSK_OK;
 }
@@ -244,6 +250,9 @@ extern "C" {
 
 int lsk_stream_begin_capture(lsk_stream_t stream) {
     if (!stream) return lsk::fail(LSK_ERR_ARG, "lsk_stream_begin_capture: the default stream cannot record");
+    if (lsk::debug_sync())
+        return lsk::fail(LSK_ERR_UNSUPPORTED, "lsk_stream_begin_capture: option debug.sync is on (every launch waits for "
+                                              "the device, which a recording cannot hold)");
     hipStreamCaptureStatus status = hipStreamCaptureStatusNone;
     LSK_HIP(hipStreamIsCapturing(lsk::as_stream(stream), &status));
     if (status != hipStreamCaptureStatusNone)

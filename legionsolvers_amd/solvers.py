@@ -44,6 +44,12 @@ class CapturedStep:
             raise NotImplementedError("steps can be recorded on a GPU only")
         if steps < 1:
             raise ValueError("at least one step")
+        import ctypes
+        from . import _lib
+        on = ctypes.c_int(0)
+        _lib.call("lsk_get_option", b"debug.sync", ctypes.byref(on))
+        if on.value:
+            raise RuntimeError("option debug.sync is on: every launch waits for the device, which a recording cannot hold")
         self.solver, self.steps = solver, int(steps)
         planner.settle()
         ctx.synchronize()

@@ -228,3 +228,35 @@ def test_c_abi_trace_records_and_replays(gpu_ctx):
     with pytest.raises(_lib.LskError):
         _lib.call("lsk_trace_replay", None, stream)
     _lib.call("lsk_stream_destroy", stream)
+
+
+def test_debug_sync_checks_every_launch_and_refuses_recordings(gpu_ctx):
+    """Option debug.sync (LSK_DEBUG_SYNC=1): every launch is followed by a device synchronisation and an error
+    check (the reference's debug builds do it at task exit, src/CUDAUtilities.cpp:110-122).  Same results; a
+    recording is refused while it is on."""
+    import ctypes
+    from legionsolvers_amd import _lib
+    rects, row, col, val, n = hc.stencil_problem(4, (6, 7, 8), np.float64)
+    rhs = np.random.default_rng(80).standard_normal(n)
+    histories = []
+    for on in (0, 1):
+        _lib.call("lsk_set_option", b"debug.sync", on)
+        try:
+            got = ctypes.c_int(-1)
+            _lib.call("lsk_get_option", b"debug.sync", ctypes.byref(got))
+            assert got.value == on
+            sm = CGSolver(hc.mirror_planner(gpu_ctx, "csr", rects, row, col, val, n, 2, np.float64, rhs, 1))
+            for _ in range(5):
+                sm.step()
+            histories.append([s.get_value() for s in sm.residual_norm_squared])
+            if on:
+                with pytest.raises(RuntimeError):
+                    sm.capture()
+                stream = ctypes.c_void_p(0)
+                _lib.call("lsk_stream_create", ctypes.byref(stream))
+                with pytest.raises(_lib.LskError):
+                    _lib.call("lsk_stream_begin_capture", stream)
+                _lib.call("lsk_stream_destroy", stream)
+        finally:
+            _lib.call("lsk_set_option", b"debug.sync", 0)
+    assert histories[0] == histories[1]
