@@ -745,7 +745,7 @@ int pick_log_rows_per_wave(int64_t rows, int64_t nnz) {
     int log_rw = 8;
     while (log_rw > 0 && double(1 << log_rw) > want_w) --log_rw;
     const int forced = lsk::options().csr_log_rw;
-    if (forced >= 0 && forced < log_rw) log_rw = forced; // only smaller tiles fit
+    if (forced >= 0 && forced <= 8) log_rw = forced; // (a tile larger than the buffer is taken in several batches)
     return log_rw;
 }
 

@@ -37,7 +37,10 @@ def main():
     ap.add_argument("--dtype", default="f64")
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--threshold", type=int, default=0, help="rows longer than this go to the split product's chunk kernels (0: the library's default)")
+    ap.add_argument("--log-rows", type=int, default=-1, help="option csr.log_rows_per_wave (rows per wave = 2^k; -1: from the mean row length)")
     args = ap.parse_args()
+    if args.log_rows >= 0:
+        _lib.call("lsk_set_option", b"csr.log_rows_per_wave", args.log_rows)
     def note(what):
         torch.cuda.synchronize()
         print(f"[skewed_rows] {what}", file=sys.stderr, flush=True)
@@ -95,7 +98,7 @@ def main():
         _lib.call(f"lsk_csr_spmv_{suf}", rows, nnz, P(rects), 0, P(col), P(val), P(x), 0, rows - 1, P(y), 0, stream)
 
     out = {"rows": rows, "entries": nnz, "mean_row": nnz / rows, "longest_rows": top, "columns": args.columns,
-           "dtype": args.dtype, "threshold": int(info[2]) if code == _lib.LSK_OK else None}
+           "dtype": args.dtype, "threshold": int(info[2]) if code == _lib.LSK_OK else None, "log_rows_per_wave": args.log_rows}
     tol = 1e-13 if s == 8 else 2e-6
     out["rows_listed_for_the_split_product"], out["their_chunks"] = int(info[0]), int(info[1])
     forms = [("c32", c32, nnz * (4 + s) + rows * (4 + 2 * s)), ("int64", i64, nnz * (8 + s) + rows * (16 + 2 * s))]
