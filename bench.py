@@ -22,7 +22,7 @@ Besides the contract's fields the line carries:
                 rank 0 at N = 1 only
   transport, rccl_ranks   what carries the halo exchange and the dots' all-reduce between ranks, and how
                 many ranks the RCCL communicator behind it reports (null on one rank)
-  value_reference_layout, setup_s, host_ms_per_step, value_with_redraws (--redraws)   see "notes" in the line
+  value_reference_layout, value_graph_replay, setup_s, host_ms_per_step, value_with_redraws (--redraws)   see "notes" in the line
 """
 from __future__ import annotations
 
@@ -74,6 +74,9 @@ def launch_ranks_if_needed(argv) -> None:
 
 if __name__ == "__main__":
     launch_ranks_if_needed(sys.argv[1:])
+    # (ranks of one node share device memory handles through dmabuf on these machines; the variable is
+    # exported there already, this only covers an environment that lost it)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
