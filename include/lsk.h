@@ -62,7 +62,7 @@ void lsk_set_abort_on_error(int enable);
  * the mean row length, else 0..8), "csr.max_units" (16-byte units per lane the wave-tile form
  * keeps in flight: 0 = chosen from the mean tile size, 4 or 8), "blas1.form" (0 grid-strided | 1 contiguous chunk per
  * workgroup, default 1), "blas1.nontemporal" (whether the BLAS-1 streams go past the caches: 1 | 0 |
- * -1 = for vectors of 256 MiB and more, the default), "coo.variant" (0 workgroup chunks through LDS | 1 wave-wide segmented
+ * -1 = for vectors of 128 MiB and more, the default), "coo.variant" (0 workgroup chunks through LDS | 1 wave-wide segmented
  * scan, default 1), "comm.skip_single_rank" (1, the default: lsk_allreduce_sum_* / lsk_allgather_* on a
  * one-rank communicator answer without calling RCCL | 0: they enqueue the RCCL collective all the
  * same), "sliced.form" (sliced-pattern product: 1, the default: every wave stages the windows of x of its
@@ -252,7 +252,7 @@ int lsk_xpay_dev_f64(int64_t n, int nf, const double *f0, const double *f1, cons
 
 /* Fused axpy and squared norm: y <- fma(alpha, x, y) exactly as lsk_axpy_* / lsk_axpy_dev_*, and
  * partials[0 .. *count) <- per-workgroup shares of sum_i y_new[i]^2 (`capacity` is the room in
- * `partials`: 2048 slots are always enough; vectors of 256 MiB and more use up to LSK_MAX_PARTIALS =
+ * `partials`: 2048 slots are always enough; vectors of 128 MiB and more use up to LSK_MAX_PARTIALS =
  * 65536 when they are there, a few per cent faster, and the count -- hence the order of the sum --
  * follows the room offered; *count is written on the host).  lsk_sum_partials_* turns them into
  * the dot product y.y when the caller wants it.  Saves the second pass over y that AxpyTask

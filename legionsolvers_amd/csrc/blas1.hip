@@ -140,11 +140,15 @@ __global__ __launch_bounds__(kBlock) void ew_kernel(int64_t n, Alpha<T> a, const
 }
 
 // Whether a stream over n elements uses the nontemporal accesses: option "blas1.nontemporal" (1, 0,
-// or -1 = for vectors of 256 MiB and more, which no cache holds from one kernel to the next).
+// or -1 = for vectors of 128 MiB and more: two of them no longer fit the 256 MiB last-level cache together, so
+// what a kernel leaves behind does not serve the next one.  Measured (tools/exp/nt_threshold_exp.py): CG on the 27-point
+// stencil steps 13 % faster with the streaming form at 128 MiB vectors, 9 % at 250 MiB, 2-3 % at 54-86 MiB, equally fast
+// at 31 MiB; BiCGStab on the random COO matrix with 119 MiB vectors 1.5 % SLOWER (the binned product finds less of x in
+// the cache).
 inline bool stream_past_caches(int64_t n, size_t elem_bytes) {
     const int opt = lsk::options().blas1_nontemporal;
     if (opt >= 0) return opt != 0;
-    return static_cast<double>(n) * static_cast<double>(elem_bytes) >= 256.0 * 1024.0 * 1024.0;
+    return static_cast<double>(n) * static_cast<double>(elem_bytes) >= 128.0 * 1024.0 * 1024.0;
 }
 
 // Workgroups of an element-wise stream over `accesses` accesses (4 per lane and trip).  Vectors that no

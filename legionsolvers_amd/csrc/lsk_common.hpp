@@ -102,7 +102,7 @@ struct Options {
     int csr_log_rw = -1;     // log2 rows per wave for the wave-tile form; -1 = from the mean row length
     int csr_max_units = 0;   // 16-byte units per lane in flight in the wave-tile form: 0 = by tile size, 4 or 8
     int blas1_form = 1;      // 0: grid-strided accesses, 1: contiguous chunk per workgroup
-    int blas1_nontemporal = -1; // BLAS-1 streams past the caches: 1, 0, -1 = for vectors of 256 MiB and more
+    int blas1_nontemporal = -1; // BLAS-1 streams past the caches: 1, 0, -1 = for vectors of 128 MiB and more
     int coo_variant = 1;     // 0: workgroup chunks through LDS, 1: wave-wide segmented scan
     int comm_skip_single_rank = 1; // one-rank communicators: answer without calling RCCL
     // Sliced-pattern product: 1 wave-staged (every wave stages the windows of x of its own rows and

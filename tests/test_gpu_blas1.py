@@ -476,7 +476,7 @@ def test_random_fill_bit_exact_and_partition_independent(gpu_ctx, suf):
 
 @pytest.mark.parametrize("suf", ["f32", "f64"])
 def test_nontemporal_streams_give_the_same_bits(suf):
-    """Option blas1.nontemporal = 1 (what vectors of 256 MiB and more get by default): every stream
+    """Option blas1.nontemporal = 1 (what vectors of 128 MiB and more get by default): every stream
     kernel's nontemporal instance gives the bits of the plain one."""
     npdt, tdt = DT[suf]
     rng = np.random.default_rng(31)
