@@ -319,7 +319,7 @@ int lsk_multi_axpy_f64(int64_t n, int k, const double *const *x, const double *c
 
 /* *result_dev <- partials[0] + ... + partials[count-1], in an order fixed by `count` alone (so
  * bit-reproducible): the second stage of the fused forms (lsk_axpy_sqnorm_*, lsk_csr_spmv_dot_*).
- * Counts above 8192 take two kernel stages through `workspace` (lsk_dot_workspace_bytes(0)
+ * Counts above 65536 take two kernel stages through `workspace` (lsk_dot_workspace_bytes(0)
  * bytes; NULL = the library's own per-device scratch, then not concurrently with other calls
  * that use it). */
 int lsk_sum_partials_f32(int64_t count, const float *partials, float *result_dev, void *workspace,

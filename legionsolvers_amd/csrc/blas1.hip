@@ -287,6 +287,37 @@ __global__ __launch_bounds__(kBlock) void fold_kernel(int count, const T *__rest
     if (threadIdx.x == 0) *out = finish(total, fin);
 }
 
+// The same for counts that one small workgroup would take too long over and a first stage of its own is
+// too much for (a kernel more on a solver step's critical path): 1024 threads, each adds its share of the
+// partials left to right with eight loads in flight, then butterfly inside each wave and waves 0..15 left to
+// right.  The order depends on the count alone.
+constexpr int kWideFold = 1024;
+template <typename T>
+__global__ __launch_bounds__(kWideFold) void fold_wide_kernel(int count, const T *__restrict__ partials,
+                                                              T *__restrict__ out, int fin) {
+    __shared__ T s_wave[kWideFold / lsk::kWave];
+    T acc = T(0);
+    int i = threadIdx.x;
+    for (; i + 7 * kWideFold < count; i += 8 * kWideFold) {
+        T v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = partials[i + u * kWideFold];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += v[u];
+    }
+    for (; i < count; i += kWideFold) acc += partials[i];
+    acc = lsk::wave_sum(acc);
+    const int lane = threadIdx.x % lsk::kWave, wave = threadIdx.x / lsk::kWave;
+    if (lane == 0) s_wave[wave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        T total = T(0);
+#pragma unroll
+        for (int w = 0; w < kWideFold / lsk::kWave; ++w) total += s_wave[w];
+        *out = finish(total, fin);
+    }
+}
+
 template <typename T>
 __global__ void store_scalar_kernel(T *out, T value) { *out = value; }
 
@@ -551,7 +582,9 @@ __global__ __launch_bounds__(kBlock) void sum_kernel(int64_t count, int64_t per,
     if (threadIdx.x == 0) out[blockIdx.x] = total;
 }
 
-// *result <- sum of `count` partial sums, in an order fixed by count alone.
+// *result <- sum of `count` partial sums, in an order fixed by count alone: up to 8192 by one workgroup of 256,
+// up to kWideFoldMax by one of 1024, beyond that in two stages.
+constexpr int64_t kWideFoldMax = 65536;
 template <typename T>
 int launch_sum_partials(const char *name, int64_t count, const T *partials, T *result, void *workspace,
                         size_t workspace_bytes, lsk_stream_t stream) {
@@ -564,7 +597,9 @@ int launch_sum_partials(const char *name, int64_t count, const T *partials, T *r
         return LSK_OK;
     }
     if (!partials) return lsk::fail(LSK_ERR_ARG, "%s: null partials", name);
-    if (count > 4 * lsk::kMaxGridBlocks) { // two stages
+    if (count > 4 * lsk::kMaxGridBlocks && count <= kWideFoldMax) {
+        fold_wide_kernel<T><<<1, kWideFold, 0, s>>>(static_cast<int>(count), partials, result, FIN_NONE);
+    } else if (count > 4 * lsk::kMaxGridBlocks) { // two stages
         const size_t need = size_t(lsk::kMaxGridBlocks) * sizeof(T);
         T *stage = static_cast<T *>(workspace);
         if (stage) {

@@ -363,11 +363,12 @@ def test_axpy_sqnorm_and_sum_partials(suf, offset):
 
 @pytest.mark.parametrize("suf", ["f32", "f64"])
 def test_sum_partials_two_stage(suf):
-    """Counts that take the two-stage path, against an exactly rounded sum."""
+    """Counts on either side of the one-workgroup (8192), wide one-workgroup (65536) and two-stage paths,
+    against an exactly rounded sum."""
     npdt, tdt = DT[suf]
     tol = 1e-13 if suf == "f64" else 2e-6
     rng = np.random.default_rng(19)
-    for count in (0, 1, 255, 8192, 8193, 100_003, 4_194_304):
+    for count in (0, 1, 255, 8192, 8193, 9000, 32768, 65535, 65536, 65537, 100_003, 4_194_304):
         v = rng.standard_normal(count).astype(npdt)
         print(f"case sum_partials_{suf} count={count}", flush=True)
         out = torch.full((1,), -1.0, dtype=tdt, device="cuda")
