@@ -384,7 +384,7 @@ def test_cg_with_tuned_placement(gpu_ctx, monkeypatch, sliced):
     matrix = mpl.row_partitioned_matrices[0].matrix
     chosen = matrix.sliced_placement if sliced == "1" else matrix.placement
     assert bool(matrix.sliced) == (sliced == "1")
-    assert sorted(chosen) == [0, 1] and all(v in (0, 16, 64, 256, 1024, 4096) for v in chosen.values())
+    assert sorted(chosen) == [0, 1] and all(v in (0, 2, 4, 16, 64, 256, 1024, 4096) for v in chosen.values())
     so, sm = S.CGSolver(opl), CGSolver(mpl)
     for _ in range(8):
         so.step()

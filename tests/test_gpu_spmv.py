@@ -849,7 +849,7 @@ def sliced_pair_case(suf, handle, rows, br, xd, x_size, y0, wd, shares_a, tag, m
     _lib.call(f"lsk_csr_sliced_tune2_{suf}", handle, P(xd), P(xb), P(ya), P(yb), stream(), ctypes.byref(remap), ctypes.byref(ms))
     now = ctypes.c_int(-2)
     _lib.call("lsk_get_option", b"xcd_remap", ctypes.byref(now))
-    assert remap.value in (0, 16, 64, 256, 1024, 4096) and ms.value > 0.0 and now.value == held.value, f"{tag}: tune2"
+    assert remap.value in (0, 2, 4, 16, 64, 256, 1024, 4096) and ms.value > 0.0 and now.value == held.value, f"{tag}: tune2"
     for got, xv in ((ya, xd), (yb, xb)):
         yd = dev(y0)
         _lib.call(f"lsk_csr_sliced_spmv_{suf}", handle, 0, rows, P(xv), P(yd), 0, stream())
