@@ -29,11 +29,17 @@ def _env(extra):
     return env
 
 
-def test_solvers_two_ranks_one_gpu():
+@pytest.mark.parametrize("transport,ranks", [("torch", 2), ("lsk-over-stand-in", 2), ("lsk-over-stand-in", 4)])
+def test_solvers_two_ranks_one_gpu(transport, ranks):
+    """transport "lsk-over-stand-in": the library's own transport (comm.LskTransport: id bootstrap over the store,
+    self-check, halo exchange on its second stream ordered with events) with two ranks, above a stand-in for the
+    six RCCL entry points that moves the bytes over gloo (tests/standin/standin_rccl.py): everything of the
+    N > 1 path but RCCL itself."""
     port = str(_free_port())
+    extra = {"LSK_TEST_STANDIN_RCCL": "1", "LSK_TRANSPORT": "lsk"} if transport != "torch" else {}
     procs = [subprocess.Popen([sys.executable, "-u", os.path.join(HERE, "two_rank_worker.py")],
-                              env=_env({"MASTER_PORT": port, "WORLD_SIZE": "2", "RANK": str(r), "LOCAL_RANK": str(r)}),
-                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+                              env=_env({"MASTER_PORT": port, "WORLD_SIZE": str(ranks), "RANK": str(r), "LOCAL_RANK": str(r), **extra}),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(ranks)]
     outs = []
     for p in procs:
         try:
@@ -80,3 +86,21 @@ def test_bench_starts_its_own_ranks_two_ranks_one_gpu():
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["steps"] == 3 and line["config"]["pieces"] == 2 and line["value"] > 0
     assert line["transport"] == "torch" and line["rccl_ranks"] is None    # gloo rehearsal: RCCL cannot share a card
+
+
+def test_bench_two_ranks_on_the_library_transport_over_the_stand_in():
+    """bench.py under the driver's launch line for N = 2 with the library's own transport above the stand-in for
+    its RCCL entry points (tests/standin/: loaded through PYTHONPATH's sitecustomize): the line reports
+    transport "lsk" and the two ranks the communicator counts."""
+    env = _env({"LSK_TEST_STANDIN_RCCL": "1", "LSK_TRANSPORT": "lsk"})
+    env["PYTHONPATH"] = os.path.join(HERE, "standin") + os.pathsep + env.get("PYTHONPATH", "")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--grid", "48"]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=400, cwd=REPO)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["value"] > 0 and line["config"]["pieces"] == 2
+    assert line["transport"] == "lsk" and line["rccl_ranks"] == 2 and line["transport_note"] is None
