@@ -291,6 +291,9 @@ def main():
     # CG's first step overwrites Q with the same product.
     planner.matvec(CGSolver.Q, CGSolver.P)
     ctx.comm.all_reduce_sum(torch.zeros(1, dtype=torch.float64, device=ctx.device))  # likewise the dots' all-reduce
+    ctx.synchronize()
+    if "placement_tuner" in matrix.setup_seconds:   # (a large piece's first product times the placements once more, on p and q)
+        setup_s["placement_tuner"] = matrix.setup_seconds["placement_tuner"]
     # (one rank: the matrix's own product, not the planner's -- the planner keeps count of the dot shares its
     # products leave and nobody uses, and would stop fusing them in; more ranks: a copy of this rank's part of a
     # vector, which needs no other rank -- a GPU that just ran a smaller case of the scaling series is in the same

@@ -585,6 +585,9 @@ public:
     }
     bool compressed() const { return col32_.size() > 0; }
     bool sliced() const { return !sliced_.empty(); }
+    // Whether the first product of a large piece times the placements once more on the vectors it is given
+    // (see place_on_these_vectors); a recording must not contain it: Trace runs its steps after a warm-up.
+    void set_placement_on_vectors(bool on) { place_on_vectors_ = on; }
     bool accumulates_only() const override { return false; }
     void matvec(PartitionedVector<T> &dst, const PartitionedVector<T> &src, int beta) const override {
         if (!(dst.partition() == range_) || src.partition().n != domain_)
@@ -594,6 +597,7 @@ public:
             if (rows <= 0) continue;
             const Piece &p = pieces_[c];
             if (sliced() && sliced_[c].handle) {
+                if (beta == 0) place_on_these_vectors(c, rows, src.data(), dst.piece(c));
                 check(lsk_set_option("xcd_remap", sliced_[c].placement));
                 check(Abi<T>::csr_sliced_spmv(sliced_[c].handle, 0, rows, src.data(), dst.piece(c), beta, ctx_->stream()));
                 continue;
@@ -628,6 +632,7 @@ public:
             const int64_t rows = range_.volume(c);
             if (rows <= 0) continue;
             int64_t count = 0;
+            place_on_these_vectors(c, rows, src.data(), dst.piece(c));
             check(lsk_set_option("xcd_remap", sliced_[c].placement));
             check(Abi<T>::csr_sliced_spmv_dot(sliced_[c].handle, 0, rows, src.data(), dst.piece(c), 0, w.piece(c), shares,
                                               shares_of(c, rows), &count, ctx_->stream()));
@@ -745,12 +750,25 @@ private:
         }
         return total;
     }
+    // The placement of a large piece's sliced product, timed once more on the first vectors it is really
+    // multiplied with (every row of y is about to be overwritten): which placement is fastest depends on where
+    // x and y lie in HBM as much as on the matrix (on the 27-point 512^3 matrix set-up's choice on temporary
+    // vectors was 3-4 % off the best in three processes of five), and a solver multiplies the same few vectors
+    // over and over.
+    void place_on_these_vectors(int c, int64_t rows, const T *x, T *y) const {
+        const Sliced &s = sliced_[c];
+        if (!place_on_vectors_ || s.placed_on_vectors || rows < kTuneMinRows) return;
+        s.placed_on_vectors = true;
+        float ms = 0.0f;
+        check(Abi<T>::csr_sliced_tune(s.handle, x, y, ctx_->stream(), &s.placement, &ms));
+    }
     // The sliced-pattern copy of a piece (lsk_csr_sliced_*): for matrices whose rows repeat a few
     // column patterns, the product then reads no column array at all and sums every row in entry
     // order, bit for bit the loop of src/CSRMatrixTasks.cpp:73-91.
     struct Sliced {
         lsk_csr_sliced_t *handle = nullptr;
-        int placement = 0;
+        mutable int placement = 0;
+        mutable bool placed_on_vectors = false; // place_on_these_vectors has run for this piece
         mutable int pair_placement = -1; // of the two-vector product; -1: not chosen yet (matvec_pair does)
         Sliced() = default;
         Sliced(Sliced &&o) noexcept : handle(o.handle), placement(o.placement), pair_placement(o.pair_placement) {
@@ -862,6 +880,7 @@ private:
     DeviceArray<uint32_t> col32_;
     std::vector<Piece> pieces_;
     std::vector<Sliced> sliced_;
+    bool place_on_vectors_ = true; // (see set_placement_on_vectors)
     mutable std::unique_ptr<Transposed<T>> transposed_;
 };
 

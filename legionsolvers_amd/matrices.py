@@ -264,6 +264,24 @@ class _SlicedCopies:
             print(f"[lsk] sliced product steady again {limit - (deadline - time.monotonic()):.1f} s "
                   f"after the redraws", file=sys.stderr, flush=True)
 
+    def _place_on_these_vectors(self, c: int, sliced, rows: int, x: torch.Tensor, y: torch.Tensor) -> None:
+        """The workgroup placement of a large piece's product, timed once more on the first vectors it is
+        really multiplied with (every row of y is about to be overwritten anyway): which placement is fastest
+        depends on where x and y lie in HBM as much as on the matrix -- on the 27-point 512^3 matrix the
+        choice made on set-up's temporary vectors was 3 % off the best in one process of two
+        (tools/exp/cg_by_placement.py) -- and a solver multiplies the same few vectors over and over (CG:
+        always p -> q).  Once per piece; not while the stream records; LSK_TUNE=0 leaves it out."""
+        done = self.__dict__.setdefault("_placed_on_vectors", set())
+        if c in done or rows < self.TUNE_MIN_ROWS:
+            return
+        done.add(c)
+        tuner = getattr(self.ctx.backend, "csr_sliced_tune", None)
+        if (tuner is None or os.environ.get("LSK_TUNE", "1") == "0" or not x.is_cuda
+                or torch.cuda.is_current_stream_capturing()):
+            return
+        with self._stage("placement_tuner"):
+            self.sliced_placement[c], _ = tuner(sliced, x, y)
+
     def time_piece(self, i: int, c: int, x: torch.Tensor, y: torch.Tensor, reps: int = 3) -> float:
         """Milliseconds of the sliced-pattern product of local piece i (colour c) with the window x
         and the output piece y."""
@@ -609,6 +627,8 @@ class CSRMatrix(AbstractMatrix, _SlicedCopies):
             r0 = p.lo[0] - self.row_lo
             k_lo, k_hi = kernel_partition.intervals[i]
             nnz = max(k_hi - k_lo + 1, 0)
+            if c in sliced and beta == 0:
+                self._place_on_these_vectors(c, sliced[c], rows, x, dst._piece(i))
             if split is not None and i in split:
                 if fused:  # every run's shares side by side in one buffer, whichever phase launches it
                     slots = ([be.csr_sliced_dot_slots(sliced[c], rb, ra) for _, ra, rb, _, _ in split[i]] if c in sliced
