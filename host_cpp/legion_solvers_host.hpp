@@ -656,17 +656,19 @@ public:
         for (int c = 0; c < range_.colors(); ++c) {
             const int64_t rows = range_.volume(c);
             if (rows <= 0) continue;
-            if (sliced_[c].pair_placement < 0) {
+            const int untimed = sliced_[c].placement ? sliced_[c].placement : 64; // (only round robin is slow)
+            const bool timed_later = sliced_[c].pair_placement < 0 && recording(); // (timing waits for the device)
+            if (sliced_[c].pair_placement < 0 && !timed_later) {
                 // two windows of x compete for each XCD's L2: the pair gets a placement of its own, timed once
                 // on the vectors at hand (the destinations are about to be overwritten anyway)
-                sliced_[c].pair_placement = sliced_[c].placement ? sliced_[c].placement : 64; // (only round robin is slow)
+                sliced_[c].pair_placement = untimed;
                 if (rows >= kTuneMinRows) {
                     float ms = 0.0f;
                     check(Abi<T>::csr_sliced_tune2(sliced_[c].handle, src_a.data(), src_b.data(), dst_a.piece(c),
                                                    dst_b.piece(c), ctx_->stream(), &sliced_[c].pair_placement, &ms));
                 }
             }
-            check(lsk_set_option("xcd_remap", sliced_[c].pair_placement));
+            check(lsk_set_option("xcd_remap", timed_later ? untimed : sliced_[c].pair_placement));
             int status;
             int64_t count = 0;
             if (w_a)
@@ -755,9 +757,14 @@ private:
     // x and y lie in HBM as much as on the matrix (on the 27-point 512^3 matrix set-up's choice on temporary
     // vectors was 3-4 % off the best in three processes of five), and a solver multiplies the same few vectors
     // over and over.
+    bool recording() const { // timing waits for the device, which a trace that is being recorded cannot hold
+        int yes = 0;
+        check(lsk_stream_is_recording(ctx_->stream(), &yes));
+        return yes != 0;
+    }
     void place_on_these_vectors(int c, int64_t rows, const T *x, T *y) const {
         const Sliced &s = sliced_[c];
-        if (!place_on_vectors_ || s.placed_on_vectors || rows < kTuneMinRows) return;
+        if (!place_on_vectors_ || s.placed_on_vectors || rows < kTuneMinRows || recording()) return;
         s.placed_on_vectors = true;
         float ms = 0.0f;
         check(Abi<T>::csr_sliced_tune(s.handle, x, y, ctx_->stream(), &s.placement, &ms));

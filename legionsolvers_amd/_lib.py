@@ -67,6 +67,7 @@ PROTOTYPES = {
     "lsk_stream_check": (_i, [_p]),
     "lsk_stream_begin_capture": (_i, [_p]),
     "lsk_stream_end_capture": (_i, [_p, ctypes.POINTER(_p)]),
+    "lsk_stream_is_recording": (_i, [_p, ctypes.POINTER(ctypes.c_int)]),
     "lsk_trace_replay": (_i, [_p, _p]),
     "lsk_trace_info": (_i, [_p, _p]),
     "lsk_trace_destroy": (_i, [_p]),

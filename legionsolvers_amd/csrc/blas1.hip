@@ -875,6 +875,7 @@ int dot_host(const char *name, int64_t n, const T *v, const T *w, T *result_host
     if (!result_host) return lsk::fail(LSK_ERR_ARG, "%s: null result", name);
     *result_host = T(0);
     if (n == 0) return LSK_OK;
+    LSK_NOT_WHILE_RECORDING(name, stream);
     lsk::DeviceState *st = nullptr;
     int rc = lsk::device_state(&st);
     if (rc != LSK_OK) return rc;

@@ -934,6 +934,7 @@ int tune_csr_spmv(const char *name, int64_t rows, int64_t nnz, const void *rects
                   lsk_stream_t stream, int *remap_out, float *ms_out) {
     static const int candidates[] = {0, 16, 64, 256, 1024, 4096};
     constexpr int kWarm = 2, kTimed = 5;
+    LSK_NOT_WHILE_RECORDING(name, stream);
     int &placement = lsk::xcd_remap_option();
     const int saved = placement;
     hipStream_t s = lsk::as_stream(stream);

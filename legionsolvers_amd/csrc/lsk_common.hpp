@@ -80,6 +80,25 @@ inline int allow_large_lds(const void *kernel, std::atomic<uint64_t> &done, hipS
     return LSK_OK;
 }
 
+// Whether `s` is recording a trace (a query that fails itself means a spoiled recording: still one).
+inline bool stream_recording(hipStream_t s) {
+    hipStreamCaptureStatus status = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &status) != hipSuccess) {
+        (void)hipGetLastError();
+        return true;
+    }
+    return status != hipStreamCaptureStatusNone;
+}
+
+// For the calls that wait for the device (timing, results read on the host): refused while the stream
+// records, BEFORE anything is enqueued, so that the recording stays whole.
+#define LSK_NOT_WHILE_RECORDING(name, stream)                                                                         \
+    do {                                                                                                              \
+        if (::lsk::stream_recording(::lsk::as_stream(stream)))                                                        \
+            return ::lsk::fail(LSK_ERR_UNSUPPORTED, "%s: the stream is recording a trace and this call waits for "    \
+                                                    "the device; nothing was enqueued", name);                       \
+    } while (false)
+
 // Per-device library state: the partial-sum scratch of the reductions.
 struct DeviceState {
     void *scratch = nullptr; // kScratchBytes of HBM

@@ -225,11 +225,13 @@ int lsk_stream_destroy(lsk_stream_t stream) {
 }
 
 int lsk_stream_synchronize(lsk_stream_t stream) {
+    LSK_NOT_WHILE_RECORDING("lsk_stream_synchronize", stream);
     LSK_HIP(hipStreamSynchronize(lsk::as_stream(stream)));
     return LSK_OK;
 }
 
 int lsk_stream_check(lsk_stream_t stream) {
+    LSK_NOT_WHILE_RECORDING("lsk_stream_check", stream);
     LSK_HIP(hipStreamSynchronize(lsk::as_stream(stream)));
     LSK_HIP(hipPeekAtLastError());
     return LSK_OK;
@@ -259,6 +261,12 @@ int lsk_stream_begin_capture(lsk_stream_t stream) {
         return lsk::fail(LSK_ERR_ARG, "lsk_stream_begin_capture: the stream is recording already");
     // thread-local mode: only this thread's unsafe calls (allocation, synchronisation) spoil the recording
     LSK_HIP(hipStreamBeginCapture(lsk::as_stream(stream), hipStreamCaptureModeThreadLocal));
+    return LSK_OK;
+}
+
+int lsk_stream_is_recording(lsk_stream_t stream, int *recording) {
+    if (!recording) return lsk::fail(LSK_ERR_ARG, "lsk_stream_is_recording: null output");
+    *recording = (stream && lsk::stream_recording(lsk::as_stream(stream))) ? 1 : 0;
     return LSK_OK;
 }
 

@@ -1876,6 +1876,7 @@ int tune(const char *name, const lsk_csr_sliced *m, const T *x, T *y, lsk_stream
     };
     constexpr int kWarm = 1, kTimed = 3;
     if (!m) return lsk::fail(LSK_ERR_ARG, "%s: null structure", name);
+    LSK_NOT_WHILE_RECORDING(name, stream);
     int &placement = lsk::xcd_remap_option();
     const int saved = placement;
     hipStream_t s = lsk::as_stream(stream);

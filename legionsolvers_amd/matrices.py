@@ -723,7 +723,10 @@ class CSRMatrix(AbstractMatrix, _SlicedCopies):
             sliced = self.sliced[c]
             ys = [d._piece(i) for d in dsts]
             ws = [w._piece(i) for w in dot_with] if fused else None
-            if c not in self.pair_placement:
+            recording = ys[0].is_cuda and torch.cuda.is_current_stream_capturing()
+            if c not in self.pair_placement and recording:
+                place = self.sliced_placement.get(c, 0) or 64   # timing waits for the device: after the recording
+            elif c not in self.pair_placement:
                 # Two windows of x compete for each XCD's L2, so the pair has a placement of its own, timed
                 # once on the vectors at hand (every row of ys is about to be overwritten anyway).
                 # (untimed: runs of 64 blocks per XCD -- only the round-robin placement is slow for the pair)
@@ -734,7 +737,8 @@ class CSRMatrix(AbstractMatrix, _SlicedCopies):
                         tuned = tune2(sliced, xs, ys)
                     if tuned is not None:
                         self.pair_placement[c] = tuned[0]
-            place = self.pair_placement[c]
+            if c in self.pair_placement:
+                place = self.pair_placement[c]
             if split is not None and i in split:
                 runs = split[i]
                 slots = [be.csr_sliced_dot_slots(sliced, rb, ra) for _, ra, rb, _, _ in runs] if fused else []

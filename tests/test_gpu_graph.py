@@ -194,6 +194,12 @@ def test_c_abi_trace_records_and_replays(gpu_ctx):
         _lib.call("lsk_axpy_dev_f64", n, 1, P(alpha), None, None, None, P(x), P(y), stream)
         _lib.call("lsk_dot_f64", n, P(y), P(x), P(out), P(ws), ws.numel(), stream)
 
+    def recording():
+        flag = ctypes.c_int(-1)
+        _lib.call("lsk_stream_is_recording", stream, ctypes.byref(flag))
+        return flag.value
+
+    assert recording() == 0
     leaves()                                   # once eagerly: first launches are not recordable
     _lib.call("lsk_stream_synchronize", stream)
     y.zero_()
@@ -202,9 +208,16 @@ def test_c_abi_trace_records_and_replays(gpu_ctx):
     _lib.call("lsk_stream_begin_capture", stream)
     with pytest.raises(_lib.LskError):          # (the stream is recording already)
         _lib.call("lsk_stream_begin_capture", stream)
+    assert recording() == 1
+    # calls that wait for the device are refused before they enqueue anything: the recording stays whole
+    host = ctypes.c_double(-1.0)
+    for name, args in (("lsk_stream_synchronize", (stream,)), ("lsk_stream_check", (stream,)),
+                       ("lsk_dot_host_f64", (n, P(y), P(x), ctypes.byref(host), stream))):
+        with pytest.raises(_lib.LskError, match="recording"):
+            _lib.call(name, *args)
     leaves()
     _lib.call("lsk_stream_end_capture", stream, ctypes.byref(trace))
-    assert trace.value
+    assert trace.value and recording() == 0
     _lib.call("lsk_stream_synchronize", stream)
     assert float(y.abs().max()) == 0.0          # recording executed nothing
     info = (ctypes.c_int64 * 2)()
