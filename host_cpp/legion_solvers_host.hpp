@@ -525,8 +525,8 @@ private:
 
 // CSRMatrix<T> (src/CSRMatrix.hpp) in the reference's layout: per row a {lo, hi} rect of global
 // entry indices, int64 global columns, T entries.  The kernel piece of a row block is the image of
-// its rects (src/CSRMatrix.cpp:89-109).  At construction a 32-bit copy of the structure is made
-// per piece when the library accepts it (bit-identical products, fewer bytes).
+// its rects (src/CSRMatrix.cpp:89-109).  At construction the matrix gets the sliced-pattern copy where
+// the library accepts it, else a 32-bit copy of the structure per piece (bit-identical products, fewer bytes).
 template <typename T> class CSRMatrix : public AbstractMatrix<T> {
 public:
     CSRMatrix(const Context &ctx, const EqualPartition &range, int64_t domain_size, DeviceArray<int64_t> rects,
@@ -543,8 +543,10 @@ public:
             }
             pieces_.push_back(std::move(p));
         }
-        if (compress && col_.size() > 0 && domain_ > 0) try_compress();
+        // (the sliced-pattern copy first; a matrix that gets it gets no 32-bit copy of the structure as well: no
+        // product would read it, and it is 4 bytes per entry that a larger problem can use)
         if (slice && col_.size() > 0 && domain_ > 0 && try_slice(redraws)) return;
+        if (compress && col_.size() > 0 && domain_ > 0) try_compress();
         float best = tune();
         // Where the driver puts the arrays in HBM moves the product's time by several per cent, and
         // user code cannot steer it; so the arrays are copied into fresh allocations a few times

@@ -117,13 +117,17 @@ class SquarePlanner:
         # The window of x every product of this matrix will be given (see _gather_ghost).
         own = domain_partition.rank_interval(rank, world)
         window = (own[0] - plan.pad_lo, own[1] + plan.pad_hi) if (plan.recvs or plan.sends) else own
-        compress = getattr(matrix, "compress", None)
-        if compress is not None and getattr(matrix, "col32", None) is None:
-            compress(window[0], window[1], kernel_partition, range_partition)
+        # Set-up-time copies, the best first: the sliced-pattern copy (CSR matrices whose rows repeat a few column
+        # patterns), else the 32-bit copy of the structure.  A matrix that got the first does not get the second
+        # as well: its products would never read it, and it is 4 bytes per entry of HBM (a sixth of what a CSR
+        # matrix of fp64 entries takes with its sliced copy) that a larger problem can use.
         slicer = getattr(matrix, "slice_structure", None)
         if slicer is not None and not getattr(matrix, "_slice_tried", False):
             slicer(window[0], window[1], kernel_partition, range_partition)
             matrix._slice_tried = True
+        compress = getattr(matrix, "compress", None)
+        if compress is not None and getattr(matrix, "col32", None) is None and not getattr(matrix, "sliced", None):
+            compress(window[0], window[1], kernel_partition, range_partition)
         tune = getattr(matrix, "tune", None)
         if tune is not None and not getattr(matrix, "_tuned", False) and not getattr(matrix, "sliced", None):
             tune(window[0], window[1], kernel_partition, range_partition)
