@@ -120,10 +120,14 @@ def main(argv=None):
     ap.add_argument("-graph", type=int, default=0,
                     help="1: after the first trace the -pt steps of a trace are recorded once as a HIP graph and every "
                          "further trace is one replay (one rank), as the reference replays its Legion traces")
+    ap.add_argument("-systems", type=int, default=2, choices=(1, 2),
+                    help="systems stepped per iteration on the one matrix: 2 as the reference's program does "
+                         "(test/BenchmarkStencil.cpp:181-199), 1 for a single system (same flag in host_cpp/BenchmarkStencil)")
     args = ap.parse_args(argv)
     world, local_rank = init_distributed()
     ctx = Context(torch.device("cuda", local_rank))
-    _, _, solver = build_problem(ctx, args.dim, args.nx, args.ny, args.nz, args.vp, args.solver)
+    _, _, solver = build_problem(ctx, args.dim, args.nx, args.ny, args.nz, args.vp, args.solver,
+                                 num_systems=args.systems)
     num_warmup_traces = 5
     num_traces = (args.it + args.pt - 1) // args.pt
     warm = num_warmup_traces * args.pt
