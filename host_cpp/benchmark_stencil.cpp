@@ -136,8 +136,9 @@ template <typename T> int main_typed(const Args &a) {
             throw std::runtime_error("the binned copy was declined");
         matrix = std::move(coo);
     } else {
-        auto csr = std::make_unique<CSRMatrix<T>>(create_linearized_csr_stencil_matrix<T>(
-            ctx, extent, st, partition, a.compress != 0, static_cast<int>(a.redraws), a.sliced != 0));
+        // (constructed in place: a CSRMatrix is registered by address as an owner of optional memory and does not move)
+        std::unique_ptr<CSRMatrix<T>> csr(new CSRMatrix<T>(create_linearized_csr_stencil_matrix<T>(
+            ctx, extent, st, partition, a.compress != 0, static_cast<int>(a.redraws), a.sliced != 0)));
         if (a.adjoint > 1) csr->transpose_chunk = a.adjoint;
         matrix = std::move(csr);
     }

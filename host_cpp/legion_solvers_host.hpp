@@ -13,6 +13,9 @@
 #include <algorithm>
 #include <chrono>
 #include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <functional>
 #include <memory>
 #include <optional>
 #include <stdexcept>
@@ -27,6 +30,32 @@ namespace LegionSolversHost {
 inline void check(int status) {
     if (status != LSK_OK) throw std::runtime_error(std::string("lsk: ") + lsk_last_error());
 }
+
+// Whether a failed call failed for lack of device memory: the set-up-time copies are optional, a matrix
+// that fills the GPU is multiplied on the arrays it came in.
+inline bool no_room(const std::exception &e) { return std::strstr(e.what(), "OutOfMemory") != nullptr; }
+
+// Device memory a program can work without: the set-up-time copies of the matrices.  Their owners register a
+// function that frees some of it and says whether it did; an allocation that finds no room calls them, one at
+// a time, and tries again (DeviceArray).  Nothing is given up while a recorded trace may still refer to it.
+struct OptionalMemory {
+    std::vector<std::pair<const void *, std::function<bool()>>> owners;
+    int recordings = 0; // Trace objects alive
+    static OptionalMemory &get() {
+        static OptionalMemory registry;
+        return registry;
+    }
+    bool release() {
+        if (recordings > 0) return false;
+        for (auto &owner : owners)
+            if (owner.second()) return true;
+        return false;
+    }
+    void forget(const void *who) {
+        owners.erase(std::remove_if(owners.begin(), owners.end(), [who](const auto &o) { return o.first == who; }),
+                     owners.end());
+    }
+};
 
 // The typed entry points of the ABI, selected by the entry type.
 template <typename T> struct Abi;
@@ -134,7 +163,14 @@ public:
     DeviceArray() = default;
     explicit DeviceArray(int64_t n) : n_(n) {
         void *p = nullptr;
-        check(lsk_malloc(&p, static_cast<size_t>(std::max<int64_t>(n, 1)) * sizeof(E)));
+        for (;;) {
+            const int status = lsk_malloc(&p, static_cast<size_t>(std::max<int64_t>(n, 1)) * sizeof(E));
+            if (status == LSK_OK) break;
+            // no room: the matrices' set-up-time copies go before an allocation fails (OptionalMemory)
+            const bool no_room_for_it = std::strstr(lsk_last_error(), "OutOfMemory") != nullptr;
+            const std::string message = std::string("lsk: ") + lsk_last_error();
+            if (!no_room_for_it || !OptionalMemory::get().release()) throw std::runtime_error(message);
+        }
         p_ = static_cast<E *>(p);
     }
     DeviceArray(DeviceArray &&o) noexcept : p_(o.p_), n_(o.n_) { o.p_ = nullptr; o.n_ = 0; }
@@ -543,6 +579,7 @@ public:
             }
             pieces_.push_back(std::move(p));
         }
+        OptionalMemory::get().owners.emplace_back(this, [this] { return release_optional_memory(); });
         // (the sliced-pattern copy first; a matrix that gets it gets no 32-bit copy of the structure as well: no
         // product would read it, and it is 4 bytes per entry that a larger problem can use)
         if (slice && col_.size() > 0 && domain_ > 0 && try_slice(redraws)) return;
@@ -584,6 +621,30 @@ public:
                 break;
             }
         }
+    }
+    ~CSRMatrix() override { OptionalMemory::get().forget(this); }
+    CSRMatrix(const CSRMatrix &) = delete;
+    CSRMatrix &operator=(const CSRMatrix &) = delete;
+    // Called when an allocation found no room: the sliced-pattern copies go first (a copy of all values) and
+    // the 32-bit copy of the structure is made in their place where that fits (half the bytes); asked again,
+    // that one goes as well and the products read the arrays as they were handed over.
+    bool release_optional_memory() {
+        if (sliced()) {
+            std::fprintf(stderr, "[LegionSolversHost] an allocation found no room: sliced-pattern copy of the matrix given up\n");
+            sliced_.clear();
+            if (col_.size() > 0 && domain_ > 0) try_compress();
+            return true;
+        }
+        if (compressed()) {
+            std::fprintf(stderr, "[LegionSolversHost] an allocation found no room: 32-bit copy of the matrix structure given up\n");
+            col32_ = DeviceArray<uint32_t>();
+            for (auto &p : pieces_) {
+                p.rowoff = DeviceArray<uint32_t>();
+                p.long_rows.reset();
+            }
+            return true;
+        }
+        return false;
     }
     bool compressed() const { return col32_.size() > 0; }
     bool sliced() const { return !sliced_.empty(); }
@@ -736,7 +797,14 @@ private:
         float total = 0.0f;
         for (int c = 0; c < range_.colors(); ++c) most = std::max(most, range_.volume(c));
         if (most < kTuneMinRows || domain_ <= 0) return total;
-        DeviceArray<T> x(domain_), y(most);
+        DeviceArray<T> x, y;
+        try {
+            x = DeviceArray<T>(domain_);
+            y = DeviceArray<T>(most);
+        } catch (const std::runtime_error &e) {
+            if (!no_room(e)) throw;
+            return total; // no room for the timing's two temporary vectors: no timing
+        }
         check(Abi<T>::fill(domain_, T(0), x.get(), ctx_->stream()));
         for (int c = 0; c < range_.colors(); ++c) {
             const int64_t rows = range_.volume(c);
@@ -815,12 +883,27 @@ private:
         int64_t most = 0;
         for (int c = 0; c < range_.colors(); ++c) {
             if (range_.volume(c) <= 0 || pieces_[c].nnz <= 0) continue;
-            if (!make_slice(c, made[c])) return false;
+            try {
+                if (!make_slice(c, made[c])) return false;
+            } catch (const std::runtime_error &e) {
+                if (!no_room(e)) throw;
+                std::fprintf(stderr, "[LegionSolversHost] no room for the sliced-pattern copy of the matrix: left out\n");
+                return false; // the copy does not fit beside the matrix: the products go on without it
+            }
             most = std::max(most, range_.volume(c));
         }
         if (most == 0) return false;
-        if (most >= kTuneMinRows) {
-            DeviceArray<T> x(domain_), y(most);
+        DeviceArray<T> x, y; // (the timing's two temporary vectors: without room for them, no timing)
+        try {
+            if (most >= kTuneMinRows) {
+                x = DeviceArray<T>(domain_);
+                y = DeviceArray<T>(most);
+            }
+        } catch (const std::runtime_error &e) {
+            if (!no_room(e)) throw;
+            x = DeviceArray<T>();
+        }
+        if (x.size() > 0 && y.size() > 0) {
             check(Abi<T>::fill(domain_, T(0), x.get(), ctx_->stream()));
             for (int c = 0; c < range_.colors(); ++c) {
                 if (!made[c].handle || range_.volume(c) < kTuneMinRows) continue;
@@ -856,6 +939,19 @@ private:
         return true;
     }
     void try_compress() {
+        try {
+            compress_or_throw();
+        } catch (const std::runtime_error &e) {
+            if (!no_room(e)) throw;
+            std::fprintf(stderr, "[LegionSolversHost] no room for the 32-bit copy of the matrix structure: left out\n");
+            col32_ = DeviceArray<uint32_t>(); // no room for the copy: products on the arrays as handed over
+            for (auto &p : pieces_) {
+                p.rowoff = DeviceArray<uint32_t>();
+                p.long_rows.reset();
+            }
+        }
+    }
+    void compress_or_throw() {
         DeviceArray<uint32_t> col32(col_.size());
         if (lsk_csr_compress_cols_u32(col_.size(), col_.get(), 0, domain_ - 1, col32.get(), ctx_->stream()) != LSK_OK)
             return;
@@ -1341,6 +1437,7 @@ template <typename T> std::vector<std::vector<Scalar<T>> *> carried_scalars(GMRE
 template <typename T, typename Solver> class Trace {
 public:
     Trace(const Context &ctx, SquarePlanner<T> &planner, Solver &solver, long steps = 1) : ctx_(&ctx) {
+        OptionalMemory::get().recordings += 1; // (the recording refers to the matrices' copies: they stay)
         planner.settle();
         ctx.synchronize();
         const auto carried = carried_scalars<T>(solver);
@@ -1371,6 +1468,7 @@ public:
     Trace(const Trace &) = delete;
     Trace &operator=(const Trace &) = delete;
     ~Trace() {
+        OptionalMemory::get().recordings -= 1;
         lsk_stream_synchronize(ctx_->stream());
         lsk_trace_destroy(trace_);
         ctx_->return_slots(parked_);

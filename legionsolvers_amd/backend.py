@@ -10,6 +10,7 @@ from __future__ import annotations
 import ctypes
 import os
 import threading
+import weakref
 from typing import Optional, Sequence, Tuple
 
 import torch
@@ -53,7 +54,31 @@ class HipBackend:
         return ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(self.device.index))
 
     def empty(self, n: int, dtype: torch.dtype) -> torch.Tensor:
-        return torch.empty(int(n), dtype=dtype, device=self.device)
+        """Uninitialised device memory for n elements.  When the device has no room for it, the matrices that
+        keep set-up-time copies are asked to give them up, one at a time (register_releasable), and the
+        allocation is tried again: the copies only make products faster, a vector that cannot be allocated
+        ends the solve."""
+        while True:
+            try:
+                return torch.empty(int(n), dtype=dtype, device=self.device)
+            except torch.cuda.OutOfMemoryError:
+                if not self.release_optional_memory():
+                    raise
+
+    def register_releasable(self, owner) -> None:
+        """`owner.release_optional_memory() -> bool` frees some device memory its owner can work without and
+        says whether it did; called when an allocation of this backend fails.  Held weakly."""
+        if getattr(self, "_releasable", None) is None:
+            self._releasable = weakref.WeakSet()
+        self._releasable.add(owner)
+
+    def release_optional_memory(self) -> bool:
+        if getattr(self, "recordings_alive", 0) > 0:
+            return False   # (a recorded step refers to the copies its products read: they stay)
+        for owner in list(getattr(self, "_releasable", None) or ()):
+            if owner.release_optional_memory():
+                return True
+        return False
 
     def new_scalar(self, value, dtype: torch.dtype) -> torch.Tensor:
         return torch.full((1,), value, dtype=dtype, device=self.device)

@@ -15,6 +15,7 @@ from __future__ import annotations
 
 import argparse
 import os
+import sys
 import time
 
 import torch
@@ -144,6 +145,8 @@ def main(argv=None):
         seconds = time.perf_counter() - t0
     else:
         seconds = timed_steps(ctx, solver, warm, timed)
+    for note in getattr(solver.planner.row_partitioned_matrices[0].matrix, "setup_notes", ()):
+        print(f"[LegionSolvers] rank {ctx.rank}: {note[:200]}", file=sys.stderr, flush=True)
     if ctx.rank == 0:
         print(f"Performed {num_warmup_traces} warmup traces.")
         print(f"Performed {max(num_traces - num_warmup_traces, 0)} timed traces.")

@@ -41,6 +41,11 @@ int decline(int code, const char *fmt, ...) {
 }
 
 int hip_fail(hipError_t status, const char *expr, const char *file, int line) {
+    // The failure is reported here, once: what HIP keeps as the thread's last error is taken away, or the launch
+    // check of some later, successful call would report it a second time (an allocation that did not fit, which
+    // a caller may well survive by going on without the copy it wanted).  A fault of the device is not
+    // forgotten this way: every later call fails with it again.
+    (void)hipGetLastError();
     // Same fields the reference prints in check_cuda (src/CUDAUtilities.cpp:13-27).
     return fail(LSK_ERR_HIP, "HIP failure with status code %d (%s: %s) in %s at %s:%d",
                 static_cast<int>(status), hipGetErrorName(status), hipGetErrorString(status),

@@ -137,6 +137,34 @@ class _SlicedCopies:
         self._sliced_refill = {}  # piece colour -> refill(copy): the piece's current values into that copy
         self._sliced_make = None
         self.setup_seconds = {}   # wall-clock seconds of the set-up stages run on this matrix
+        self.setup_notes = []     # what set-up had to leave out (a copy that did not fit in memory)
+        register = getattr(self.ctx.backend, "register_releasable", None)
+        if register is not None:
+            register(self)        # (release_optional_memory: the copies go when a vector finds no room)
+
+    def release_optional_memory(self) -> bool:
+        """Called when an allocation on this device found no room: the set-up-time copies are what the matrix can
+        work without.  The sliced-pattern copies go first (a copy of all values), the 32-bit copy of the
+        structure is made in their place where that fits (half the bytes); asked again, that one goes as well
+        and the products read the arrays as they were handed over.  Returns whether anything was freed."""
+        if self.sliced:
+            window, made_with = self.sliced_window, self._sliced_make
+            for s in self.sliced.values():
+                s.close()
+            self.sliced, self.sliced_window, self._sliced_make = {}, None, None
+            self.sliced_placement, self.pair_placement, self._sliced_refill = {}, {}, {}
+            self.__dict__.pop("_placed_on_vectors", None)
+            self.setup_notes.append("sliced-pattern copies given up: an allocation found no room")
+            compress = getattr(self, "compress", None)
+            if compress is not None and made_with is not None and getattr(self, "col32", None) is None:
+                compress(window[0], window[1], made_with[1], made_with[2])
+            return True
+        if getattr(self, "col32", None) is not None and getattr(self, "rowoff", None):
+            self.col32, self.col32_window, self.rowoff, self.long_rows = None, None, {}, {}
+            torch.cuda.empty_cache()
+            self.setup_notes.append("32-bit copy of the structure given up: an allocation found no room")
+            return True
+        return False
 
     def _refill_sliced_copies(self) -> None:
         """The sliced-pattern copies hold a copy of the entry values: bring them up to date."""
@@ -172,15 +200,29 @@ class _SlicedCopies:
                 k_lo, k_hi = kernel_partition.intervals[i]
                 if range_partition.pieces[c].volume == 0 or k_hi < k_lo:
                     continue
-                made[c] = make(i, c)
+                try:
+                    made[c] = make(i, c)
+                except RuntimeError as exc:
+                    if not _no_room(exc):
+                        raise
+                    made[c] = None   # the copy does not fit beside the matrix: the products go on without it
+                    self.setup_notes.append(f"no room for the sliced-pattern copy of piece {c}: {exc}")
                 if made[c] is None:
+                    for s in made.values():
+                        if s is not None:
+                            s.close()
                     return False
         if not made:
             return False
         self.sliced, self.sliced_window = made, (int(x_lo), int(x_hi))
         self._sliced_make = (make, kernel_partition, range_partition)
         if os.environ.get("LSK_TUNE", "1") != "0":
-            self.tune_sliced_copies()
+            try:
+                self.tune_sliced_copies()
+            except RuntimeError as exc:   # (its two temporary vectors)
+                if not _no_room(exc):
+                    raise
+                self.setup_notes.append(f"no room to time the placements: {exc}")
         return True
 
     def tune_sliced_copies(self, redraws: int = None) -> None:
@@ -298,6 +340,12 @@ class _SlicedCopies:
 
 
 
+def _no_room(exc: BaseException) -> bool:
+    """Whether a set-up step failed for lack of device memory (the library's hipMalloc or torch's allocator): the
+    set-up-time copies are optional, a matrix that fills the GPU is multiplied on the arrays it came in."""
+    return isinstance(exc, torch.cuda.OutOfMemoryError) or "OutOfMemory" in str(exc) or "out of memory" in str(exc)
+
+
 def _redraws_asked_for() -> bool:
     """Re-making set-up-time copies to draw a better place in HBM is opt-in: LSK_TUNE=2."""
     return os.environ.get("LSK_TUNE", "1") == "2"
@@ -381,6 +429,16 @@ class CSRMatrix(AbstractMatrix, _SlicedCopies):
         if (cols is None or rows_of is None or os.environ.get("LSK_COMPRESS", "1") == "0" or x_hi < x_lo
                 or self.nnz == 0 or x_hi - x_lo + 1 > be.COMPRESS_MAX_EXTENT):
             return False
+        try:
+            return self._compress(be, cols, rows_of, x_lo, x_hi, kernel_partition, range_partition)
+        except RuntimeError as exc:
+            if not _no_room(exc):
+                raise
+            self.rowoff, self.long_rows, self.col32, self.col32_window = {}, {}, None, None
+            self.setup_notes.append(f"no room for the 32-bit copy of the structure: {exc}")
+            return False
+
+    def _compress(self, be, cols, rows_of, x_lo, x_hi, kernel_partition, range_partition) -> bool:
         rowoff, long_rows = {}, {}
         with self._stage("compress_32bit"):
             for i, c in enumerate(kernel_partition.colors):
@@ -449,9 +507,15 @@ class CSRMatrix(AbstractMatrix, _SlicedCopies):
                and kernel_partition.intervals[i][1] >= kernel_partition.intervals[i][0]]
         if not big:
             return
-        x = torch.zeros(x_hi - x_lo + 1, dtype=self.dtype, device=self.val.device)
-        y = torch.empty(max(range_partition.pieces[kernel_partition.colors[i]].volume for i in big),
-                        dtype=self.dtype, device=self.val.device)
+        try:
+            x = torch.zeros(x_hi - x_lo + 1, dtype=self.dtype, device=self.val.device)
+            y = torch.empty(max(range_partition.pieces[kernel_partition.colors[i]].volume for i in big),
+                            dtype=self.dtype, device=self.val.device)
+        except RuntimeError as exc:
+            if not _no_room(exc):
+                raise
+            self.setup_notes.append(f"no room to time the placements: {exc}")
+            return
         with self._stage("placement_redraws"):
             self._redraw_arrays(x, x_lo, x_hi, y, kernel_partition, range_partition, big)
         self._tune_placement(tuner, x, x_lo, x_hi, y, kernel_partition, range_partition, big)

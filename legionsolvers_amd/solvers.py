@@ -63,6 +63,15 @@ class CapturedStep:
             for old, scalars in zip(before, carried):
                 ctx.backend.copy(old.get_future(), scalars[-1].get_future())
         self.replays = 0
+        # (the recording refers to the set-up-time copies its products read: while it lives, no allocation
+        # that finds no room may have them given up)
+        self._backend = ctx.backend
+        self._backend.recordings_alive = getattr(self._backend, "recordings_alive", 0) + 1
+
+    def __del__(self):
+        backend = getattr(self, "_backend", None)
+        if backend is not None:
+            backend.recordings_alive = max(getattr(backend, "recordings_alive", 1) - 1, 0)
 
     def replay(self, times: int = 1) -> None:
         for _ in range(times):

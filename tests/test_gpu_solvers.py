@@ -422,6 +422,129 @@ def test_compressed_structure_gives_the_same_history(gpu_ctx, monkeypatch, dtype
         assert torch.equal(histories[0], histories[1])
 
 
+def hold_device_memory_except(keep: int):
+    """Tensors that hold all of the device's free memory except about `keep` bytes (what the driver reports as
+    free is not what one allocation gets: asked again until the report is down to `keep`)."""
+    import gc
+    held = []
+    gc.collect()   # (what earlier tests left for the collector holds device memory that an allocation in need would find)
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    for _ in range(24):
+        free, _ = torch.cuda.mem_get_info()
+        if free <= keep + (4 << 20):
+            break
+        want = free - keep
+        try:
+            held.append(torch.empty(want, dtype=torch.uint8, device="cuda"))
+        except torch.cuda.OutOfMemoryError:
+            try:
+                held.append(torch.empty(max(want // 2, 1 << 20), dtype=torch.uint8, device="cuda"))
+            except torch.cuda.OutOfMemoryError:
+                break
+    # torch's allocator keeps memory of its own that it has reserved and not handed out (parts of segments that
+    # live tensors sit in), a gigabyte after a long test session: taken as well, or it serves what is asked next
+    for size in (256 << 20, 64 << 20, 16 << 20, 4 << 20, 1 << 20):
+        for _ in range(2048):
+            reserved = torch.cuda.memory_reserved()
+            try:
+                t = torch.empty(size, dtype=torch.uint8, device="cuda")
+            except torch.cuda.OutOfMemoryError:
+                break
+            if torch.cuda.memory_reserved() > reserved:   # that one came from the driver: back it goes
+                del t
+                torch.cuda.empty_cache()
+                break
+            held.append(t)
+    return held
+
+
+def test_a_set_up_time_copy_that_does_not_fit_is_left_out(gpu_ctx, monkeypatch):
+    """The set-up-time copies are optional: when the device has no room for the sliced-pattern copy (here: all
+    but 64 MiB of the free memory is held while the library makes it, and the copy needs 190 MB), the library
+    reports the failed allocation, leaks nothing and leaves no error behind for later launches; the planner
+    notes it, gives the matrix the 32-bit copy of its structure instead, and CG follows the oracle."""
+    be = gpu_ctx.backend
+    rects, row, col, val, n = hc.stencil_problem(4, (96, 96, 96), np.float64)
+    rhs = np.random.default_rng(35).standard_normal(n)
+    real = be.csr_sliced_create
+    seen = {}
+
+    def with_the_memory_held(*args, **kwargs):
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        seen["free_before"], _ = torch.cuda.mem_get_info()
+        held = hold_device_memory_except(64 << 20)
+        seen["free_while_held"], _ = torch.cuda.mem_get_info()
+        try:
+            return real(*args, **kwargs)
+        finally:
+            del held
+            torch.cuda.empty_cache()
+            seen["free_after"], _ = torch.cuda.mem_get_info()
+
+    monkeypatch.setattr(be, "csr_sliced_create", with_the_memory_held)
+    print("case sliced-pattern copy with the device's memory held", flush=True)
+    mpl = hc.mirror_planner(gpu_ctx, "csr", rects, row, col, val, n, 1, np.float64, rhs)
+    matrix = mpl.row_partitioned_matrices[0].matrix
+    assert seen["free_while_held"] <= (80 << 20)
+    assert not matrix.sliced and matrix.col32 is not None
+    assert any("no room for the sliced-pattern copy" in note and "OutOfMemory" in note for note in matrix.setup_notes)
+    assert seen["free_after"] >= seen["free_before"] - (8 << 20)        # what the failed create had allocated is back
+    opl = hc.oracle_planner("csr", rects, row, col, val, n, 1, np.float64, rhs)
+    so, sm = S.CGSolver(opl), CGSolver(mpl)
+    for _ in range(5):
+        so.step()
+        sm.step()
+    np.testing.assert_allclose([s.get_value() for s in sm.residual_norm_squared],
+                               [float(v) for v in so.residual_norm_squared], rtol=1e-10)
+
+
+def test_set_up_time_copies_are_given_up_when_a_vector_finds_no_room(gpu_ctx):
+    """The copies only make products faster; a vector that cannot be allocated ends the solve.  With all but
+    100 MB of the device held, a vector of 150 MB is asked for: the matrix gives up its sliced-pattern copy
+    (190 MB), takes the 32-bit copy of its structure instead (99 MB), the vector is allocated, and CG goes on
+    following the oracle -- unless a recorded step still refers to the copy, then the allocation fails."""
+    be = gpu_ctx.backend
+    rects, row, col, val, n = hc.stencil_problem(4, (96, 96, 96), np.float64)
+    rhs = np.random.default_rng(36).standard_normal(n)
+    opl = hc.oracle_planner("csr", rects, row, col, val, n, 1, np.float64, rhs)
+    mpl = hc.mirror_planner(gpu_ctx, "csr", rects, row, col, val, n, 1, np.float64, rhs)
+    matrix = mpl.row_partitioned_matrices[0].matrix
+    assert matrix.sliced and matrix.col32 is None
+    so, sm = S.CGSolver(opl), CGSolver(mpl)
+    for _ in range(3):
+        so.step()
+        sm.step()
+    recorded = sm.capture()
+    recorded.replay()          # the fourth step
+    so.step()
+    print("case a vector allocated with the device's memory held", flush=True)
+    held = hold_device_memory_except(100 << 20)
+    try:
+        assert torch.cuda.mem_get_info()[0] <= (120 << 20)
+        with pytest.raises(torch.cuda.OutOfMemoryError):   # the recording keeps the copy
+            be.empty(150 << 17, torch.float64)
+        assert matrix.sliced
+        del recorded
+        held += hold_device_memory_except(100 << 20)       # (what the recording itself had held)
+        vector = be.empty(150 << 17, torch.float64)        # 150 MiB
+        assert vector.numel() == 150 << 17
+        assert not matrix.sliced and matrix.col32 is not None
+        assert any("given up" in note for note in matrix.setup_notes)
+    finally:
+        del held
+        torch.cuda.empty_cache()
+    for _ in range(3):
+        so.step()
+        sm.step()
+    got = [s.get_value() for s in sm.residual_norm_squared]
+    want = [float(v) for v in so.residual_norm_squared]
+    assert len(got) == len(want) == 8
+    want[3] = want[4]          # (the entry the recording started from holds what its replay left there)
+    np.testing.assert_allclose(got, want, rtol=1e-10)
+
+
 def test_structure_that_cannot_be_compressed_falls_back(gpu_ctx):
     """Rects with a gap (every row ignores its last entry): no 32-bit copy is made, products take
     the reference arrays, CG still follows the oracle."""
