@@ -870,6 +870,18 @@ class COOMatrix(AbstractMatrix, _SlicedCopies):
         self.binned_color = None
         self._init_sliced()
 
+    def release_optional_memory(self) -> bool:
+        """As CSRMatrix's: the sliced-pattern copies first, then the binned copy (the products then scan the
+        entries in the order they came in); the 32-bit index fields stay."""
+        if _SlicedCopies.release_optional_memory(self):
+            return True
+        if self.binned is not None:
+            self.binned.close()
+            self.binned = self.binned_window = self.binned_color = None
+            self.setup_notes.append("binned copy given up: an allocation found no room")
+            return True
+        return False
+
     def compress(self, x_lo: int, x_hi: int, kernel_partition, range_partition) -> bool:
         """Set-up-time 32-bit copies of the index fields: columns as offsets into the window
         x_lo..x_hi of the input vector, rows as offsets from this rank's first row (0xffffffff

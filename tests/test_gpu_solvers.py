@@ -545,6 +545,41 @@ def test_set_up_time_copies_are_given_up_when_a_vector_finds_no_room(gpu_ctx):
     np.testing.assert_allclose(got, want, rtol=1e-10)
 
 
+def test_a_coo_matrix_gives_up_its_binned_copy(gpu_ctx, monkeypatch):
+    """The binned copy of an unstructured COO matrix is optional memory as well: asked to release it in the middle
+    of a BiCGStab run (what an allocation that finds no room does), the matrix goes on scanning its entries and
+    the solver goes on following the oracle."""
+    from legionsolvers_amd import COOMatrix
+    monkeypatch.setenv("LSK_COO_BLOCK", "1")
+    monkeypatch.setenv("LSK_COO_BINNED", "2")
+    monkeypatch.setattr(COOMatrix, "BLOCK_MIN_WINDOW", 0)
+    monkeypatch.setattr(COOMatrix, "BINNED_BLOCK_COLS", 256)
+    monkeypatch.setattr(COOMatrix, "BINNED_TILE_ROWS", 512)
+    rng = np.random.default_rng(41)
+    n, per = 6000, 12
+    row = np.repeat(np.arange(n), per).astype(np.int64)
+    col = rng.integers(0, n, size=n * per).astype(np.int64)
+    col[::per] = np.arange(n)
+    val = rng.uniform(-1, 1, size=n * per)
+    val[::per] = 2.0 * per
+    rhs = rng.standard_normal(n)
+    so = S.BiCGStabSolver(hc.oracle_planner("coo", None, row, col, val, n, 1, np.float64, rhs))
+    mpl = hc.mirror_planner(gpu_ctx, "coo", None, row, col, val, n, 1, np.float64, rhs)
+    matrix = mpl.row_partitioned_matrices[0].matrix
+    assert matrix.binned is not None
+    sm = BiCGStabSolver(mpl)
+    for step in range(6):
+        if step == 3:
+            assert matrix.release_optional_memory() and matrix.binned is None
+            assert not matrix.release_optional_memory()      # nothing else it can work without
+        so.step()
+        sm.step()
+    np.testing.assert_allclose([s.get_value() for s in sm.rho], [float(v) for v in so.rho], rtol=1e-9)
+    want = so.planner.get_vector(0, 0)
+    got = mpl.get_vector(0, 0).to_host().numpy()
+    assert np.abs(got - want).max() <= 1e-9 * np.abs(want).max()
+
+
 def test_structure_that_cannot_be_compressed_falls_back(gpu_ctx):
     """Rects with a gap (every row ignores its last entry): no 32-bit copy is made, products take
     the reference arrays, CG still follows the oracle."""
