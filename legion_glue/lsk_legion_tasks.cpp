@@ -322,7 +322,8 @@ void COOMatvecTask<LEGION_SOLVERS_KDR_TEMPLATE_ARGS>::cuda_task_body(LEGION_SOLV
 // The transposed products are registered (src/Initialize.cpp:464-479) and never launched; their
 // bodies stay what the reference's are (src/CSRMatrixTasks.cu:159-164, src/COOMatrixTasks.cu:149-154).
 // (liblsk has transposed products -- a set-up-time transposition onto lsk_csr_spmv_c32_* -- for the day a
-// solver launches these tasks; a task body has no place to keep that set-up, see INTEGRATION.md.)
+// solver launches these tasks; a task body has no place to keep that set-up between calls: it belongs to the
+// matrix object, which would make the transposed structure when it is built and hand it to the task.)
 LEGION_SOLVERS_KDR_TEMPLATE
 void CSRRmatvecTask<LEGION_SOLVERS_KDR_TEMPLATE_ARGS>::cuda_task_body(LEGION_SOLVERS_TASK_ARGS) { assert(false); }
 
