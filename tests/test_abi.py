@@ -120,3 +120,21 @@ def test_header_is_plain_c_and_the_native_callers_compile():
                  "-I", os.path.join(repo, "host_cpp"), os.path.join(repo, "host_cpp", "benchmark_stencil.cpp")]):
         res = subprocess.run(cmd, capture_output=True, text=True)
         assert res.returncode == 0, " ".join(cmd) + "\n" + res.stderr[-3000:]
+
+
+def test_callers_above_the_boundary_use_only_declared_entry_points():
+    """The Legion task bodies (never compiled here: no Legion in this image), the C example and the C++ host name
+    no library symbol that include/lsk.h does not declare: the text cannot drift from the ABI unnoticed."""
+    import re
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    header = open(os.path.join(repo, "include", "lsk.h")).read()
+    declared = set(_lib.declared_symbols()) | set(re.findall(r"\b(lsk_\w+_t)\b", header))
+    own = {"lsk_legion", "lsk_legion_tasks", "lsk_legion_matrix_values_changed", "lsk_common"}   # the glue's own names
+    for path in ("legion_glue/lsk_legion_tasks.cpp", "legion_glue/lsk_legion.h", "examples/cg_c_abi.c",
+                 "host_cpp/legion_solvers_host.hpp", "host_cpp/benchmark_stencil.cpp", "host_cpp/stencil_generator.hpp"):
+        text = open(os.path.join(repo, path)).read()
+        for name in sorted(set(re.findall(r"\b(lsk_\w+)\b", text)) - own):
+            if name.endswith("_"):   # a macro pastes the rest of the name (the entry type) behind it
+                assert any(d.startswith(name) for d in declared), f"{path}: nothing declared begins with {name}"
+            else:
+                assert name in declared or (name + "_f32" in declared and name + "_f64" in declared), f"{path}: {name}"
