@@ -26,6 +26,7 @@
 // Everything else (accessors, get_bounds, task->futures, preregister_task) is what the reference's
 // CPU and CUDA bodies already use.
 #include <cstdlib>
+#include <cstring>
 #include <map>
 #include <mutex>
 #include <utility>
@@ -120,8 +121,15 @@ const Structure32 &structure32(const int64_t *rects, int64_t rows, int64_t k_bas
     if (s.col) check(lsk_free(s.col));
     s = Structure32{rects, rows, nnz, x_lo, x_hi, nullptr, nullptr};
     void *rowoff = nullptr, *col32 = nullptr;
-    check(lsk_malloc(&rowoff, static_cast<size_t>(rows + 1) * sizeof(uint32_t)));
-    check(lsk_malloc(&col32, static_cast<size_t>(nnz) * sizeof(uint32_t)));
+    // (the copies are optional memory: without room for them in the framebuffer the product reads the region's own arrays)
+    const int ra = lsk_malloc(&rowoff, static_cast<size_t>(rows + 1) * sizeof(uint32_t));
+    const int rb = ra == LSK_OK ? lsk_malloc(&col32, static_cast<size_t>(nnz) * sizeof(uint32_t)) : ra;
+    if (rb != LSK_OK) {
+        const bool no_room = std::strstr(lsk_last_error(), "OutOfMemory") != nullptr;
+        if (rowoff) check(lsk_free(rowoff));
+        if (!no_room) check(rb);
+        return s;
+    }
     const int a = lsk_csr_compress_rows_u32(rows, nnz, rects, k_base, static_cast<uint32_t *>(rowoff), stream);
     const int b = a == LSK_OK
                       ? lsk_csr_compress_cols_u32(nnz, col, x_lo, x_hi, static_cast<uint32_t *>(col32), stream)
@@ -175,7 +183,8 @@ const lsk_csr_sliced_t *sliced_structure(const int64_t *rects, int64_t rows, int
     if (s.handle) check(lsk_csr_sliced_destroy(s.handle));
     s = Sliced{rects, val, rows, nnz, x_lo, x_hi, true, false, nullptr};
     const int rc = Abi<T>::csr_sliced_create(rows, nnz, rects, k_base, col, val, row_first, x_lo, x_hi, stream, &s.handle);
-    if (rc != LSK_OK && rc != LSK_ERR_UNSUPPORTED) check(rc);
+    // (declined, or no room for the copy in the framebuffer: the product goes on with the next form)
+    if (rc != LSK_OK && rc != LSK_ERR_UNSUPPORTED && std::strstr(lsk_last_error(), "OutOfMemory") == nullptr) check(rc);
     return s.handle;
 }
 
