@@ -580,6 +580,97 @@ def test_a_coo_matrix_gives_up_its_binned_copy(gpu_ctx, monkeypatch):
     assert np.abs(got - want).max() <= 1e-9 * np.abs(want).max()
 
 
+@pytest.mark.parametrize("kind,env", [("csr", {}), ("csr", {"LSK_SLICED": "0"}),
+                                      ("csr", {"LSK_SLICED": "0", "LSK_COMPRESS": "0"}), ("coo", {}),
+                                      ("coo", {"LSK_SLICED": "0"})])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_non_finite_elements_of_x_reach_only_the_rows_that_read_them(gpu_ctx, monkeypatch, kind, env, dtype):
+    """A NaN and an infinity in x: the rows whose entries multiply them become non-finite exactly where the CPU
+    loop's do, every other row keeps its value -- the padding of the set-up-time copies (zeros in the sliced
+    copy, clamped gathers in the general kernels) must never multiply an element its row does not read
+    (src/CSRMatrixTasks.cpp:73-91, src/COOMatrixTasks.cpp:67-74 touch x only through the entries)."""
+    for key, value in env.items():
+        monkeypatch.setenv(key, value)
+    rects, row, col, val, n = hc.stencil_problem(4, (14, 9, 11), dtype)
+    x = np.random.default_rng(37).standard_normal(n).astype(dtype)
+    x[[5, n // 2]] = np.nan
+    x[[n // 3, n - 2]] = np.inf
+    x[0] = -np.inf
+    opl = hc.oracle_planner(kind, rects, row, col, val, n, 3, dtype, x)
+    mpl = hc.mirror_planner(gpu_ctx, kind, rects, row, col, val, n, 3, dtype, x)
+    opl.allocate_workspace(1)
+    mpl.allocate_workspace(1)
+    opl.matvec(2, 1)
+    mpl.matvec(2, 1)
+    want = np.asarray(opl.get_vector(2, 0))
+    got = mpl.get_vector(2, 0).to_host().numpy()
+    assert 20 < int((~np.isfinite(want)).sum()) < n // 2
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    assert np.array_equal(np.isposinf(got), np.isposinf(want)) and np.array_equal(np.isneginf(got), np.isneginf(want))
+    fine = np.isfinite(want)
+    tol = 1e-12 if dtype == np.float64 else 1e-4
+    assert np.abs(got[fine] - want[fine]).max() <= tol * np.abs(want[fine]).max()
+
+
+def test_non_finite_elements_of_x_through_the_binned_copy_and_long_rows(gpu_ctx, monkeypatch):
+    """The same for the binned COO copy (whose bins are padded to whole units) and for a CSR matrix with rows
+    on the long-row plan (whose chunks are padded to whole waves)."""
+    from legionsolvers_amd import COOMatrix
+    monkeypatch.setenv("LSK_COO_BLOCK", "1")
+    monkeypatch.setenv("LSK_COO_BINNED", "2")
+    monkeypatch.setattr(COOMatrix, "BLOCK_MIN_WINDOW", 0)
+    monkeypatch.setattr(COOMatrix, "BINNED_BLOCK_COLS", 256)
+    monkeypatch.setattr(COOMatrix, "BINNED_TILE_ROWS", 512)
+    rng = np.random.default_rng(43)
+    n, per = 6000, 12
+    row = np.repeat(np.arange(n), per).astype(np.int64)
+    col = rng.integers(0, n, size=n * per).astype(np.int64)
+    col[::per] = np.arange(n)
+    val = rng.uniform(-1, 1, size=n * per)
+    x = rng.standard_normal(n)
+    x[[7, n // 2]] = np.nan
+    x[n - 3] = np.inf
+    opl = hc.oracle_planner("coo", None, row, col, val, n, 1, np.float64, x)
+    mpl = hc.mirror_planner(gpu_ctx, "coo", None, row, col, val, n, 1, np.float64, x)
+    assert mpl.row_partitioned_matrices[0].matrix.binned is not None
+    opl.allocate_workspace(1)
+    mpl.allocate_workspace(1)
+    opl.matvec(2, 1)
+    mpl.matvec(2, 1)
+    want = np.asarray(opl.get_vector(2, 0))
+    got = mpl.get_vector(2, 0).to_host().numpy()
+    assert 10 < int((~np.isfinite(want)).sum()) < n // 2
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    assert np.array_equal(np.isinf(got), np.isinf(want))
+    fine = np.isfinite(want)
+    assert np.abs(got[fine] - want[fine]).max() <= 1e-12 * np.abs(want[fine]).max()
+    # CSR: 300 short rows and two rows of 20 000 and 9 000 entries (beyond the plan's 8192)
+    lens = np.full(300, 5, dtype=np.int64)
+    lens[[40, 211]] = (20000, 9000)
+    n = 24000
+    offs = np.concatenate(([0], np.cumsum(lens)))
+    rects = np.stack([offs[:-1], offs[1:] - 1], axis=1).astype(np.int64)
+    col = np.concatenate([np.sort(rng.choice(n, size=int(k), replace=False)) for k in lens]).astype(np.int64)
+    val = rng.uniform(-1, 1, size=col.size)
+    x = rng.standard_normal(n)
+    x[[11, n // 2, n - 1]] = (np.nan, np.inf, -np.inf)
+    rows = lens.size
+    be = gpu_ctx.backend
+    d = lambda a: hc.to_dev(gpu_ctx, a)  # noqa: E731
+    rowoff = be.csr_compress_rows(d(rects), 0, col.size)
+    col32 = be.csr_compress_cols(d(col), 0, n - 1)
+    plan = be.csr_long_rows_create(rowoff)
+    assert plan is not None
+    y = torch.zeros(rows, dtype=torch.float64, device="cuda")
+    be.csr_spmv_split(plan, 0, rows, col.size, rowoff, col32, d(val), d(x), 0, n - 1, y, 0)
+    want = np.zeros(rows)
+    oracle.csr_matvec(rects, 0, col, val, x, 0, n - 1, want, beta=1)
+    got = y.cpu().numpy()
+    assert np.array_equal(np.isnan(got), np.isnan(want)) and np.array_equal(np.isinf(got), np.isinf(want))
+    fine = np.isfinite(want)
+    assert fine.sum() > 250 and np.abs(got[fine] - want[fine]).max() <= 1e-12 * np.abs(want[fine]).max()
+
+
 def test_structure_that_cannot_be_compressed_falls_back(gpu_ctx):
     """Rects with a gap (every row ignores its last entry): no 32-bit copy is made, products take
     the reference arrays, CG still follows the oracle."""
