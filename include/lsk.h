@@ -123,7 +123,8 @@ int lsk_stream_end_capture(lsk_stream_t stream, lsk_trace_t **trace);
 /* *recording = 1 while `stream` is between the two calls above (0 for the default stream).  The calls of this
  * library that wait for the device (lsk_stream_synchronize, lsk_stream_check, lsk_dot_host_*, the tune calls)
  * ask the same question and answer LSK_ERR_UNSUPPORTED before enqueueing anything, which leaves the recording
- * whole; a caller that times or reads results lazily (a placement timed on the first product) asks here first. */
+ * whole; a caller that times or reads results lazily (a placement timed on the first product) asks here first.
+ * No counterpart in the reference: Legion itself knows when it is recording a trace. */
 int lsk_stream_is_recording(lsk_stream_t stream, int *recording);
 int lsk_trace_replay(const lsk_trace_t *trace, lsk_stream_t stream);
 /* out2[0] = kernel and copy nodes of the recording, out2[1] = replays so far. */
