@@ -15,7 +15,10 @@ per-step traffic:
            default when the ranks own one GPU each (process group backend "nccl").
   "torch"  torch.distributed itself: backend "nccl" is RCCL as well, "gloo" runs the same code
            on CPU tensors for tests.  LSK_TRANSPORT=torch selects it, and it is what a failed
-           bootstrap of the first falls back to (every rank together).
+           bootstrap of the first falls back to (every rank together) -- also one that is not up
+           after LSK_COMM_TIMEOUT seconds (default 180), whose thread is then left behind.
+           LSK_TRANSPORT=lsk insists on the first (a failure is raised); prefer-lsk tries it and
+           falls back, which is also what happens by default where the process group is nccl.
 
 Set-up-time traffic (host objects, barriers, timing brackets) always goes through
 torch.distributed.  The plan arithmetic (who sends which interval to whom) is pure host code.
@@ -215,8 +218,8 @@ class Communicator:
             self.rank, self.world_size = 0, 1
         self.backend = dist.get_backend(group) if self.world_size > 1 else None
         asked = transport if transport is not None else os.environ.get("LSK_TRANSPORT")
-        if asked not in (None, "", "lsk", "torch"):
-            raise ValueError(f"transport {asked!r}: 'lsk' or 'torch'")
+        if asked not in (None, "", "lsk", "torch", "prefer-lsk"):
+            raise ValueError(f"transport {asked!r}: 'lsk', 'prefer-lsk' or 'torch'")
         self._asked = asked or None
         self.transport = "torch"      # until bind_device has made the RCCL communicator
         self.transport_note = None    # why the transport is not the one asked for / the default
@@ -227,29 +230,39 @@ class Communicator:
         asked for or the default.  The decision is taken by all ranks together: when the bootstrap
         or its self-check fails on any of them, every rank falls back to "torch" -- unless "lsk" was
         asked for explicitly, then the failure is raised."""
-        want = self._asked or ("lsk" if (self.world_size > 1 and self.backend is not None
-                                         and "nccl" in str(self.backend)) else "torch")
-        if want != "lsk" or self.lsk is not None or torch.device(device).type != "cuda":
+        want = self._asked or ("prefer-lsk" if (self.world_size > 1 and self.backend is not None
+                                                and "nccl" in str(self.backend)) else "torch")
+        if want == "torch" or self.lsk is not None or torch.device(device).type != "cuda":
             return
-        error = None
-        limit = float(os.environ.get("LSK_COMM_TIMEOUT", "300"))
-        watchdog = threading.Timer(limit, _bootstrap_overdue, args=(self.rank, limit))
-        watchdog.daemon = True
-        watchdog.start()
-        try:
-            store = None
-            if self.world_size > 1:
-                from torch.distributed.distributed_c10d import _get_default_store
-                store = _get_default_store()
-            # (a key every rank of the group forms alike: its members' global ranks)
-            tag = "world" if self.group is None else "ranks" + "-".join(
-                str(r) for r in dist.get_process_group_ranks(self.group))
-            self.lsk = LskTransport(self.rank, self.world_size, device, store, tag)
-            self.lsk.self_check()
-        except Exception as exc:  # noqa: BLE001
-            error = f"rank {self.rank}: {type(exc).__name__}: {exc}"
-        finally:
-            watchdog.cancel()
+        limit = float(os.environ.get("LSK_COMM_TIMEOUT", "180"))
+        made = {}
+
+        def make_and_check():
+            # (in a thread of its own: a peer that never arrives leaves ncclCommInitRank, or the first
+            # collective, waiting for good, and nothing can interrupt that call)
+            try:
+                store = None
+                if self.world_size > 1:
+                    from torch.distributed.distributed_c10d import _get_default_store
+                    store = _get_default_store()
+                # (a key every rank of the group forms alike: its members' global ranks)
+                tag = "world" if self.group is None else "ranks" + "-".join(
+                    str(r) for r in dist.get_process_group_ranks(self.group))
+                made["transport"] = LskTransport(self.rank, self.world_size, device, store, tag)
+                made["transport"].self_check()
+                torch.cuda.synchronize(device)
+            except Exception as exc:  # noqa: BLE001
+                made["error"] = f"rank {self.rank}: {type(exc).__name__}: {exc}"
+
+        worker = threading.Thread(target=make_and_check, name="lsk-comm-bootstrap", daemon=True)
+        worker.start()
+        worker.join(limit)
+        if worker.is_alive():   # left behind: whatever it holds is not touched again
+            error = (f"rank {self.rank}: the RCCL communicator was not up after {limit:.0f} s (LSK_COMM_TIMEOUT)")
+            made = {}
+        else:
+            error = made.get("error")
+            self.lsk = made.get("transport")
         errors = [e for e in self.all_gather_object(error) if e]
         if errors:
             if self.lsk is not None:
@@ -367,10 +380,3 @@ class Communicator:
         return dist.get_global_rank(self.group, group_rank)
 
 
-def _bootstrap_overdue(rank: int, limit: float) -> None:
-    """Watchdog of bind_device: a peer that never arrives leaves ncclCommInitRank (or the first
-    collective) waiting for good; say so and end the process instead of hanging the job."""
-    import sys
-    print(f"[lsk] rank {rank}: the RCCL communicator was not up after {limit:.0f} s (LSK_COMM_TIMEOUT); "
-          "LSK_TRANSPORT=torch selects torch.distributed's own", file=sys.stderr, flush=True)
-    os._exit(17)

@@ -6,6 +6,8 @@ than one rank here.  install() replaces exactly those entry points, in this proc
 same bytes between the ranks over gloo through host memory, synchronously on the stream they were given.  Test
 infrastructure only: enabled by LSK_TEST_STANDIN_RCCL=1 from tests/, never by the package."""
 import ctypes
+import os
+import time
 
 import numpy as np
 import torch
@@ -40,6 +42,8 @@ def _unique_id(buf):
 
 
 def _init_rank(handle_ref, world, rank, uid):
+    if os.environ.get("LSK_TEST_STANDIN_INIT_HANGS") == "1":   # a communicator that never comes up
+        time.sleep(10 ** 6)
     assert bytes(uid.raw[:8]) == b"stand-in", "every rank must present the id rank 0 published"
     _state.update(rank=int(rank), world=int(world))
     assert dist.get_world_size() == _state["world"] and dist.get_rank() == _state["rank"]

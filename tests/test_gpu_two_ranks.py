@@ -29,14 +29,18 @@ def _env(extra):
     return env
 
 
-@pytest.mark.parametrize("transport,ranks", [("torch", 2), ("lsk-over-stand-in", 2), ("lsk-over-stand-in", 4)])
+@pytest.mark.parametrize("transport,ranks", [("torch", 2), ("lsk-over-stand-in", 2), ("lsk-over-stand-in", 4),
+                                             ("a-communicator-that-never-comes-up", 2)])
 def test_solvers_two_ranks_one_gpu(transport, ranks):
     """transport "lsk-over-stand-in": the library's own transport (comm.LskTransport: id bootstrap over the store,
     self-check, halo exchange on its second stream ordered with events) with two ranks, above a stand-in for the
     six RCCL entry points that moves the bytes over gloo (tests/standin/standin_rccl.py): everything of the
-    N > 1 path but RCCL itself."""
+    N > 1 path but RCCL itself.  "a-communicator-that-never-comes-up": the stand-in's lsk_comm_init_rank never
+    returns; after LSK_COMM_TIMEOUT seconds every rank goes on with torch.distributed and says so."""
     port = str(_free_port())
     extra = {"LSK_TEST_STANDIN_RCCL": "1", "LSK_TRANSPORT": "lsk"} if transport != "torch" else {}
+    if transport == "a-communicator-that-never-comes-up":
+        extra.update({"LSK_TRANSPORT": "prefer-lsk", "LSK_COMM_TIMEOUT": "3", "LSK_TEST_STANDIN_INIT_HANGS": "1"})
     procs = [subprocess.Popen([sys.executable, "-u", os.path.join(HERE, "two_rank_worker.py")],
                               env=_env({"MASTER_PORT": port, "WORLD_SIZE": str(ranks), "RANK": str(r), "LOCAL_RANK": str(r), **extra}),
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(ranks)]
