@@ -487,7 +487,7 @@ def test_a_set_up_time_copy_that_does_not_fit_is_left_out(gpu_ctx, monkeypatch):
     print("case sliced-pattern copy with the device's memory held", flush=True)
     mpl = hc.mirror_planner(gpu_ctx, "csr", rects, row, col, val, n, 1, np.float64, rhs)
     matrix = mpl.row_partitioned_matrices[0].matrix
-    assert seen["free_while_held"] <= (80 << 20)
+    assert seen["free_while_held"] <= (150 << 20)    # (the copy needs 190 MB)
     assert not matrix.sliced and matrix.col32 is not None
     assert any("no room for the sliced-pattern copy" in note and "OutOfMemory" in note for note in matrix.setup_notes)
     assert seen["free_after"] >= seen["free_before"] - (8 << 20)        # what the failed create had allocated is back
