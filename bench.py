@@ -468,6 +468,7 @@ def main():
         "transport": ctx.comm.transport if world > 1 else None,
         "rccl_ranks": ctx.comm.rccl_ranks,
         "transport_note": ctx.comm.transport_note,
+        "setup_notes": list(getattr(matrix, "setup_notes", [])) or None,   # a set-up-time copy left out or given up for lack of memory
         "value_reference_layout": iters_reference_layout,
         "setup_s": {k: round(v, 3) for k, v in setup_s.items()},
         "host_ms_per_step": host_ms,
