@@ -241,6 +241,7 @@ class Communicator:
             # (in a thread of its own: a peer that never arrives leaves ncclCommInitRank, or the first
             # collective, waiting for good, and nothing can interrupt that call)
             try:
+                torch.cuda.set_device(device)   # (a new thread starts on device 0: RCCL and the library go by the thread's device)
                 store = None
                 if self.world_size > 1:
                     from torch.distributed.distributed_c10d import _get_default_store
