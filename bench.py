@@ -132,12 +132,14 @@ def spmv_kernel_time_inner(ctx, matrix, entry, dst, x, x_lo, x_hi, reps: int, do
     return start.elapsed_time(stop) * 1e-3 / reps
 
 
-def cpu_baseline(matrix, n1: int):
+def cpu_baseline(matrix, n1: int, gpu_history=None):
     """CG iterations/s of the CPU oracle on this box's host cores, on the SAME matrix: the device
     arrays (bit-identical to what the oracle's own generator builds) are copied to the host, then a few
     CG steps run with one OpenMP thread per row block, and one step on a single thread.  When the host
     lacks the memory for the whole matrix, a 256^3 sample of the same operator is timed instead and
-    scaled by rows (named in `sample`)."""
+    scaled by rows (named in `sample`).  gpu_history: r.r after each of the GPU solver's first steps (from
+    the same right-hand side and starting vector); on the whole matrix the oracle's own r.r after each of
+    its steps is set beside it (`parity`): the checker used as the checker, at the benchmark's size."""
     import numpy as np
     import oracle
     affinity = len(os.sched_getaffinity(0))
@@ -168,18 +170,32 @@ def cpu_baseline(matrix, n1: int):
     t_copy = time.perf_counter() - t_copy
     sol, r, p, q = np.zeros(rows), np.ones(rows), np.ones(rows), np.zeros(rows)
     rr = float(rows)
+    history = [rr]
     rr = oracle.cg_step_mt(rects, col, val, sol, p, q, r, rr, cores)  # warm-up (first touch of the vectors)
+    history.append(float(rr))
     steps = 3
     t0 = time.perf_counter()
     for _ in range(steps):
         rr = oracle.cg_step_mt(rects, col, val, sol, p, q, r, rr, cores)
+        history.append(float(rr))
     dt = (time.perf_counter() - t0) / steps
     oracle.set_threads(1)
     t0 = time.perf_counter()
     rr = oracle.cg_step_mt(rects, col, val, sol, p, q, r, rr, 1)
+    history.append(float(rr))
     dt1 = time.perf_counter() - t0
     oracle.set_threads(cores)
+    parity = None
+    if scale == 1.0 and gpu_history is not None and len(gpu_history) >= len(history):
+        worst = max(abs(g - c) / abs(c) for g, c in zip(gpu_history, history))
+        parity = {"what": "r.r after each of the first CG steps, GPU solver against the CPU oracle on the same matrix, "
+                          "right-hand side and starting vector (sums taken in different orders: 1e-10 is the bar)",
+                  "steps": len(history) - 1, "max_rel_diff": worst, "within_1e-10": bool(worst <= 1e-10),
+                  "cpu_r2": history, "gpu_r2": list(gpu_history[:len(history)])}
+        if worst > 1e-10:
+            print(f"[bench] PARITY: the GPU's residual history differs from the CPU oracle's by {worst:.3e}", file=sys.stderr, flush=True)
     return {
+        "parity": parity,
         "value": scale / dt,
         "unit": "iters/s",
         "cores": cores,
@@ -310,6 +326,8 @@ def main():
     seconds = bs.timed_steps(ctx, solver, args.warmup, args.steps)
     iters_per_s = args.steps / seconds
     rr = solver.residual_norm_squared[-1].get_value()
+    # (r.r after the first steps, for the CPU oracle to be set beside at the end: cpu_baseline's parity)
+    gpu_history = [s.get_value() for s in solver.residual_norm_squared[:min(6, len(solver.residual_norm_squared))]]
     # the same steps replayed from a HIP graph of one step (one rank; reported beside the headline)
     graph_rate = None
     if world == 1:
@@ -532,7 +550,7 @@ def main():
             matrix.sliced[c].close()
         matrix.sliced, matrix.col32, matrix.rowoff = {}, None, {}
         torch.cuda.empty_cache()
-        line["cpu_baseline"] = cpu_baseline(matrix, n1)
+        line["cpu_baseline"] = cpu_baseline(matrix, n1, gpu_history)
     if ctx.rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:
