@@ -132,14 +132,16 @@ def spmv_kernel_time_inner(ctx, matrix, entry, dst, x, x_lo, x_hi, reps: int, do
     return start.elapsed_time(stop) * 1e-3 / reps
 
 
-def cpu_baseline(matrix, n1: int, gpu_history=None):
+def cpu_baseline(matrix, n1: int, gpu_history=None, gpu_product=None):
     """CG iterations/s of the CPU oracle on this box's host cores, on the SAME matrix: the device
     arrays (bit-identical to what the oracle's own generator builds) are copied to the host, then a few
     CG steps run with one OpenMP thread per row block, and one step on a single thread.  When the host
     lacks the memory for the whole matrix, a 256^3 sample of the same operator is timed instead and
     scaled by rows (named in `sample`).  gpu_history: r.r after each of the GPU solver's first steps (from
     the same right-hand side and starting vector); on the whole matrix the oracle's own r.r after each of
-    its steps is set beside it (`parity`): the checker used as the checker, at the benchmark's size."""
+    its steps is set beside it (`parity`): the checker used as the checker, at the benchmark's size.
+    gpu_product: (x, y, sliced) of one GPU product y = A x; the oracle's CSR loop repeats it on the host and the
+    two are compared bit by bit (the sliced-pattern product sums every row in the CPU loop's order)."""
     import numpy as np
     import oracle
     affinity = len(os.sched_getaffinity(0))
@@ -194,6 +196,21 @@ def cpu_baseline(matrix, n1: int, gpu_history=None):
                   "cpu_r2": history, "gpu_r2": list(gpu_history[:len(history)])}
         if worst > 1e-10:
             print(f"[bench] PARITY: the GPU's residual history differs from the CPU oracle's by {worst:.3e}", file=sys.stderr, flush=True)
+        if gpu_product is not None:
+            x, y, was_sliced = gpu_product
+            want = np.zeros(rows)
+            t0 = time.perf_counter()
+            oracle.csr_matvec(rects, int(matrix.k_base), col, val, x, 0, rows - 1, want, beta=1, mt=True)   # (rows over the threads; each row's own order)
+            differing = int((want.view(np.uint64) != y.view(np.uint64)).sum())
+            scale_y = float(np.abs(want).max())
+            parity["product"] = {
+                "what": "one product of a random vector, every row of the GPU's result against the CPU loop's, bit by bit"
+                        + ("" if was_sliced else " (the general kernel adds in another order: equal to rounding, not bit by bit)"),
+                "rows": int(rows), "rows_differing_in_any_bit": differing,
+                "max_abs_diff_over_max_abs": float(np.abs(want - y).max()) / scale_y if scale_y else 0.0,
+                "oracle_seconds": time.perf_counter() - t0}
+            if was_sliced and differing:
+                print(f"[bench] PARITY: {differing} rows of the sliced product differ from the CPU loop's bits", file=sys.stderr, flush=True)
     return {
         "parity": parity,
         "value": scale / dt,
@@ -546,11 +563,18 @@ def main():
         },
     }
     if ctx.rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # one product of a random vector as the planner launches it, for the oracle to repeat on the host
+        # (cpu_baseline's parity: the sliced-pattern product claims the CPU loop's bits)
+        gen = torch.Generator(device=ctx.device).manual_seed(20250310)
+        p_vec._own.copy_(torch.randn(p_vec._own.numel(), dtype=torch.float64, device=ctx.device, generator=gen))
+        matrix.matvec(q_vec, p_vec._own, p_vec.own_lo, p_vec.own_hi, entry0.kernel_partition, 0)
+        ctx.synchronize()
+        gpu_product = (p_vec._own.cpu().numpy(), q_vec._own.cpu().numpy(), bool(matrix.sliced))
         for c in list(matrix.sliced):
             matrix.sliced[c].close()
         matrix.sliced, matrix.col32, matrix.rowoff = {}, None, {}
         torch.cuda.empty_cache()
-        line["cpu_baseline"] = cpu_baseline(matrix, n1, gpu_history)
+        line["cpu_baseline"] = cpu_baseline(matrix, n1, gpu_history, gpu_product)
     if ctx.rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:
