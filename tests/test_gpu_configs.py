@@ -94,6 +94,18 @@ def test_cg_csr_laplacian_2d_4096_full_size(gpu_ctx):
     np.testing.assert_allclose(got, [float(v) for v in hist], rtol=1e-10)
     xs = sol.to_host().numpy()
     assert np.abs(xs - x).max() <= 1e-10 * np.abs(x).max()
+    # one product as the planner launches it (the sliced-pattern copy) against the CPU loop, bit by bit, every row
+    matrix = planner.row_partitioned_matrices[0].matrix
+    assert matrix.sliced
+    xv = np.random.default_rng(62).standard_normal(n)
+    src, dst = planner.get_vector(CGSolver.P, 0), planner.get_vector(CGSolver.Q, 0)
+    src.owned.copy_(hc.to_dev(gpu_ctx, xv))
+    planner.matvec(CGSolver.Q, CGSolver.P)
+    want = np.zeros(n)
+    oracle.csr_matvec(rects, 0, col, val, xv, 0, n - 1, want, beta=1)
+    differing = int((want.view(np.uint64) != dst.to_host().numpy().view(np.uint64)).sum())
+    print(f"full size: the sliced 2-D 5-point product against the CPU loop at {nx}^2: {differing} of {n} rows differ in any bit")
+    assert differing == 0
 
 
 def _random_rowsorted_coo(rows, per_row, seed=20250310):
@@ -281,8 +293,20 @@ def test_spmv_properties_7pt_fp32_768(gpu_ctx, monkeypatch, n1):
     assert A.slice_structure(0, n - 1, kp, ip)
     s = A.sliced[0]
     assert (s.patterns, s.mixed_blocks) == (27, 0) and A.nnz < s.padded_entries <= 1.01 * A.nnz  # rows padded to their block's longest
-    diff = float((matvec(x, "Axs").owned - Ax.owned).abs().max())
+    Axs = matvec(x, "Axs").owned
+    diff = float((Axs - Ax.owned).abs().max())
     assert diff <= 2e-6 * float(Ax.owned.abs().max())
+    # ... and the sliced product against the CPU loop itself (src/CSRMatrixTasks.cpp:73-91: every row summed in
+    # entry order), bit by bit, all 453 million rows: the matrix goes to the host for it (45 GB)
+    got = Axs.cpu().numpy()
+    x_host = x.owned.cpu().numpy()
+    del Axs, Ax
+    rects_h, col_h, val_h = A.rects.cpu().numpy(), A.col.cpu().numpy(), A.val.cpu().numpy()
+    want = np.zeros(n, dtype=np.float32)
+    oracle.csr_matvec(rects_h, int(A.k_base), col_h, val_h, x_host, 0, n - 1, want, beta=1, mt=True)
+    differing = int((want.view(np.uint32) != got.view(np.uint32)).sum())
+    print(f"full size: the sliced 7-point fp32 product against the CPU loop at {n1}^3: {differing} of {n} rows differ in any bit")
+    assert differing == 0
 
 
 @pytest.mark.parametrize("graph", [0, 1])
