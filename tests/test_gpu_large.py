@@ -79,20 +79,22 @@ def test_csr_spmv_beyond_2_31_rows(gpu_ctx):
     assert bool((y == val * x).all())
 
 
-def test_fused_updates_on_vectors_beyond_the_grid_caps(gpu_ctx):
-    """The fused updates on vectors of 2 GiB (fp64, 2^28 + 12 345 elements): more 16 KiB chunks than the 65 536
+@pytest.mark.parametrize("npdt,n,tol", [(np.float64, (1 << 28) + 12345, 1e-13), (np.float32, (1 << 29) + 777, 2e-6)],
+                         ids=["f64", "f32"])
+def test_fused_updates_on_vectors_beyond_the_grid_caps(gpu_ctx, npdt, n, tol):
+    """The fused updates on vectors of 2 GiB (2^28 + 12 345 fp64 / 2^29 + 777 fp32 elements): more 16 KiB chunks than the 65 536
     workgroups the streaming form launches at most, so every workgroup takes several; with 2048 (the least), the
     host layers' and the most partial sums on offer.  Every element against the oracle's loops bit by bit, the sums
     against fp64 sums of the oracle's results."""
     _need(30)
     be = gpu_ctx.backend
-    n = (1 << 28) + 12345
-    print(f"case fused updates n={n} fp64", flush=True)
+    tdt = torch.float64 if npdt == np.float64 else torch.float32
+    print(f"case fused updates n={n} {np.dtype(npdt).name}", flush=True)
     g = torch.Generator(device="cuda").manual_seed(5)
-    x, p, r = (torch.randn(n, generator=g, device="cuda", dtype=torch.float64) for _ in range(3))
+    x, p, r = (torch.randn(n, generator=g, device="cuda", dtype=tdt) for _ in range(3))
     xh, ph, rh = (t.cpu().numpy() for t in (x, p, r))
-    a, b = np.float64(0.37), np.float64(-1.3)
-    ad, bd = (torch.tensor([v], dtype=torch.float64, device="cuda") for v in (a, b))
+    a, b = npdt(0.37), npdt(-1.3)
+    ad, bd = (torch.tensor([v], dtype=tdt, device="cuda") for v in (a, b))
     # z <- fma(a, p, z) and p <- fma(b, p, r) in one pass (CG's closing updates, src/CGSolver.hpp:49-54)
     be.axpy_xpay(x, [ad], p, [bd], r)
     oracle.axpy(a, ph, xh)
@@ -100,18 +102,20 @@ def test_fused_updates_on_vectors_beyond_the_grid_caps(gpu_ctx):
     assert np.array_equal(x.cpu().numpy(), xh) and np.array_equal(p.cpu().numpy(), ph)
     # y <- fma(a, x, y) with the shares of y . y, and of y . w
     for slots in (2048, be.sqnorm_slots(r), 65536):
-        partials = torch.empty(slots, dtype=torch.float64, device="cuda")
-        out = torch.empty(1, dtype=torch.float64, device="cuda")
+        partials = torch.empty(slots, dtype=tdt, device="cuda")
+        out = torch.empty(1, dtype=tdt, device="cuda")
         count = be.axpy_sqnorm(r, [ad], p, partials)
         assert 1 <= count <= slots
         be.sum_partials(count, partials, out)
         oracle.axpy(a, ph, rh)
         assert np.array_equal(r.cpu().numpy(), rh), slots
-        want = float(np.dot(rh, rh))
-        assert abs(float(out) - want) <= 1e-13 * want, (slots, float(out), want)
+        r64, p64 = rh.astype(np.float64), ph.astype(np.float64)
+        want = float(np.dot(r64, r64))
+        assert abs(float(out) - want) <= tol * want, (slots, float(out), want)
         count = be.axpy_dot(r, [bd], x, p, partials)
         be.sum_partials(count, partials, out)
         oracle.axpy(b, xh, rh)
         assert np.array_equal(r.cpu().numpy(), rh), slots
-        want, bound = float(np.dot(rh, ph)), float(np.dot(np.abs(rh), np.abs(ph)))
-        assert abs(float(out) - want) <= 1e-13 * bound, (slots, float(out), want)
+        r64 = rh.astype(np.float64)
+        want, bound = float(np.dot(r64, p64)), float(np.dot(np.abs(r64), np.abs(p64)))
+        assert abs(float(out) - want) <= tol * bound, (slots, float(out), want)
