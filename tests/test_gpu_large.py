@@ -119,3 +119,37 @@ def test_fused_updates_on_vectors_beyond_the_grid_caps(gpu_ctx, npdt, n, tol):
         r64 = rh.astype(np.float64)
         want, bound = float(np.dot(r64, p64)), float(np.dot(np.abs(r64), np.abs(p64)))
         assert abs(float(out) - want) <= tol * bound, (slots, float(out), want)
+
+
+def test_classical_sweep_leaves_on_large_vectors(gpu_ctx):
+    """lsk_multi_dot_* / lsk_multi_axpy_* (the classical Gram-Schmidt option's two passes) on fp32 vectors of
+    0.6 GiB, eleven basis vectors (two groups of at most eight): the update equals the chain of axpys in ascending
+    order bit by bit, with and without the shares of the new norm; the inner products equal fp64 sums to fp32
+    rounding."""
+    _need(20)
+    be = gpu_ctx.backend
+    n, k = (1 << 27) + (1 << 25) + 333, 11
+    print(f"case classical sweep leaves n={n} k={k} fp32", flush=True)
+    g = torch.Generator(device="cuda").manual_seed(8)
+    basis = [torch.randn(n, generator=g, device="cuda", dtype=torch.float32) for _ in range(k)]
+    w = torch.randn(n, generator=g, device="cuda", dtype=torch.float32)
+    wh = w.cpu().numpy()
+    h = torch.empty(k, dtype=torch.float32, device="cuda")
+    be.multi_dot(basis, w, h)
+    got_h = h.cpu().numpy()
+    w64 = wh.astype(np.float64)
+    for j, v in enumerate(basis):
+        v64 = v.cpu().numpy().astype(np.float64)
+        want, bound = float(np.dot(v64, w64)), float(np.dot(np.abs(v64), np.abs(w64)))
+        assert abs(float(got_h[j]) - want) <= 2e-6 * bound, j
+    for with_norm in (False, True):
+        partials = torch.empty(be.sqnorm_slots(w), dtype=torch.float32, device="cuda") if with_norm else None
+        count = be.multi_axpy(w, h, basis, negate=True, partials=partials)
+        for j, v in enumerate(basis):
+            oracle.axpy(np.float32(-got_h[j]), v.cpu().numpy(), wh)
+        assert np.array_equal(w.cpu().numpy(), wh), with_norm
+        if with_norm:
+            out = torch.empty(1, dtype=torch.float32, device="cuda")
+            be.sum_partials(count, partials, out)
+            want = float(np.dot(wh.astype(np.float64), wh.astype(np.float64)))
+            assert abs(float(out) - want) <= 2e-6 * want
