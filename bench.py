@@ -314,6 +314,7 @@ def main():
     t0 = time.perf_counter()
     _, planner, solver = bs.build_problem(ctx, 4, n1, n1, n1, world, 1, torch.float64, num_systems=1, matrix=matrix)
     stage("vectors_partitions_halo_plan", t0)
+    workspace_placement = getattr(planner, "workspace_placement", None)
     for key in ("compress_32bit", "sliced_copy", "placement_tuner"):
         if key in matrix.setup_seconds:
             setup_s[key] = matrix.setup_seconds[key]
@@ -504,6 +505,7 @@ def main():
         "rccl_ranks": ctx.comm.rccl_ranks,
         "transport_note": ctx.comm.transport_note,
         "setup_notes": list(getattr(matrix, "setup_notes", [])) or None,   # a set-up-time copy left out or given up for lack of memory
+        "workspace_placement": workspace_placement,  # where in HBM the planner put its workspace vectors, by timing
         "value_reference_layout": iters_reference_layout,
         "setup_s": {k: round(v, 3) for k, v in setup_s.items()},
         "host_ms_per_step": host_ms,

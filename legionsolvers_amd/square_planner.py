@@ -156,13 +156,82 @@ class SquarePlanner:
         if self.workspace_vectors:
             raise RuntimeError("workspace already allocated")
         n = self.get_num_spaces()
-        for j in range(num_vectors):
-            row = []
-            for i in range(n):
-                row.append(PartitionedVector(self.ctx, f"workspace_{j}_{i}",
-                                             self.canonical_index_partitions[i], self.dtype,
-                                             pad=self._halo_pad(i)))
-            self.workspace_vectors.append(row)
+        hold = self._room_in_front_of_the_workspace()
+        try:
+            for j in range(num_vectors):
+                row = []
+                for i in range(n):
+                    row.append(PartitionedVector(self.ctx, f"workspace_{j}_{i}",
+                                                 self.canonical_index_partitions[i], self.dtype,
+                                                 pad=self._halo_pad(i)))
+                self.workspace_vectors.append(row)
+        finally:
+            if hold:
+                del hold[:]
+                torch.cuda.empty_cache()
+
+    PLACE_MIN_GAIN = 0.015   # a deeper place for the workspace must beat the nearest by this much to be taken
+
+    def _room_in_front_of_the_workspace(self) -> list:
+        """Where in HBM the workspace vectors go.  The 288 GB of an MI355X answer in three parts of 96 GB (the three
+        ranks of its 12-high stacks): two read streams are fastest inside one part (a dot product of two 8 GiB
+        buffers: 7.1 against 6.7 TB/s), a read and a write stream in two different ones (a copy: 6.2 against 5.7
+        TB/s; tools/exp/hbm_pair_rates.py).  A product reads the matrix values and writes a workspace vector, so
+        the workspace is best kept out of the part the values of a large sliced-pattern copy lie in: CG on the
+        27-point 512^3 matrix 161 -> 171 it/s (tools/exp/rank_region_placement.py).  No interface says where an
+        allocation lands; on these devices memory is handed out from the bottom up, so a block of a third of the
+        device allocated first pushes what follows into the next part.  Nothing is assumed, though: one product
+        is timed into a vector here, into one behind such a block and into one behind two, and the workspace goes
+        where that was fastest by PLACE_MIN_GAIN (else where it would have gone anyway).  Returns the blocks to
+        hold while the workspace is allocated (the caller frees them right after; they are never touched).
+        Skipped without a large sliced copy, with LSK_TUNE=0 or LSK_PLACE_VECTORS=0, and whenever the device
+        has no room for the blocks; the times are kept in self.workspace_placement."""
+        self.workspace_placement = None
+        dev = self.ctx.device
+        if (dev.type != "cuda" or os.environ.get("LSK_TUNE", "1") == "0" or os.environ.get("LSK_PLACE_VECTORS", "1") == "0"
+                or torch.cuda.is_current_stream_capturing() or self.ctx.comm.backend == "gloo"):
+            return []   # (gloo: a rehearsal with several ranks on one card, whose blocks would take each other's memory)
+        target = None
+        for e in self.row_partitioned_matrices:
+            m = e.matrix
+            if not getattr(m, "sliced", None) or getattr(m, "sliced_window", None) is None or not hasattr(m, "time_piece"):
+                continue
+            rp = self.canonical_index_partitions[e.range_index]
+            for i, c in enumerate(e.kernel_partition.colors):
+                if c in m.sliced and rp.pieces[c].volume >= m.TUNE_MIN_ROWS:
+                    target = (m, i, c, rp.pieces[c].volume)
+                    break
+            if target:
+                break
+        if target is None:
+            return []
+        m, i, c, rows = target
+        x_lo, x_hi = m.sliced_window
+        third = torch.cuda.mem_get_info(dev)[1] // 3
+        kept, times = [], []   # kept: vector 0, block 1, vector 1, block 2, vector 2
+        try:
+            x = torch.zeros(x_hi - x_lo + 1, dtype=self.dtype, device=dev)
+            for depth in range(3):
+                if depth:
+                    if torch.cuda.mem_get_info(dev)[0] < third + (4 << 30):
+                        break
+                    kept.append(torch.empty(third, dtype=torch.uint8, device=dev))
+                kept.append(torch.empty(rows, dtype=self.dtype, device=dev))
+                times.append(m.time_piece(i, c, x, kept[-1]))
+        except torch.cuda.OutOfMemoryError:
+            if len(kept) % 2 == 0 and kept:   # a block without its vector
+                kept.pop()
+        if not times:
+            return []
+        best = min(range(len(times)), key=times.__getitem__)
+        if times[best] > (1.0 - self.PLACE_MIN_GAIN) * times[0]:
+            best = 0
+        self.workspace_placement = {"blocks_in_front": best, "product_ms_by_blocks_in_front": [round(t, 4) for t in times]}
+        hold = kept[:2 * best]   # everything in front of the chosen vector stays until the workspace is there
+        del kept, x
+        torch.cuda.synchronize(dev)
+        torch.cuda.empty_cache()   # (what was freed goes back to the device, not into torch's cache, which would hand
+        return hold                #  a vector's block from behind the chosen place to the first workspace vector)
 
     def get_vector(self, vec_idx: int, space_idx: int) -> PartitionedVector:
         if vec_idx == 0:

@@ -31,6 +31,28 @@ def main():
         given = bs.sg.create_linearized_csr_stencil_matrix(ctx, (512, 512, 512), offsets, coeffs, part, torch.float64)
         dummy = torch.empty(gb << 30, dtype=torch.uint8, device="cuda")
         matrix, planner, solver = build(matrix=given)
+    elif mode == "ranks":   # matrix as handed over in the first 96 GiB, the sliced copy in the second, the workspace vectors in the third
+        from legionsolvers_amd import IndexPartition, IndexSpace
+        _, offsets, coeffs = bs.sg.benchmark_stencil(4)
+        part = IndexPartition.equal(IndexSpace(0, 512 ** 3 - 1), 1)
+        given = bs.sg.create_linearized_csr_stencil_matrix(ctx, (512, 512, 512), offsets, coeffs, part, torch.float64)
+        torch.cuda.empty_cache()
+        total = torch.cuda.mem_get_info()[1]
+        used = total - torch.cuda.mem_get_info()[0]
+        region = 96 << 30
+        held = [torch.empty(max(region - used, 1 << 20), dtype=torch.uint8, device="cuda")]   # fills the first region
+        real = bs.CGSolver
+
+        def later(planner):
+            torch.cuda.empty_cache()
+            used_now = total - torch.cuda.mem_get_info()[0]
+            held.append(torch.empty(max(2 * region - used_now, 1 << 20), dtype=torch.uint8, device="cuda"))   # fills the second
+            return real(planner)
+
+        bs.CGSolver = later
+        matrix, planner, solver = build(matrix=given)
+        bs.CGSolver = real
+        dummy = held
     elif mode == "vectors":  # everything but the solver's workspace (p, q, r) first, then N GB, then those three
         real = bs.CGSolver
         held = []
