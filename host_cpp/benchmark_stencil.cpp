@@ -81,6 +81,12 @@ void run(const Context &ctx, const Args &a, Solver &solver, SquarePlanner<T> &pl
     };
     for (long i = 0; i < num_warmup_traces; ++i) one_trace(i);
     ctx.synchronize();
+    if (!planner.workspace_product_ms().empty()) { // (where the planner put its workspace, and by what timings)
+        std::fprintf(stderr, "[LegionSolversHost] workspace vectors behind %d block(s) of a third of the device; product by blocks in front:",
+                     planner.workspace_blocks_in_front());
+        for (const float ms : planner.workspace_product_ms()) std::fprintf(stderr, " %.3f", ms);
+        std::fprintf(stderr, " ms\n");
+    }
     const auto begin = std::chrono::steady_clock::now();
     std::cout << "Performed " << num_warmup_traces << " warmup traces." << std::endl;
     for (long i = num_warmup_traces; i < num_traces; ++i) one_trace(i);

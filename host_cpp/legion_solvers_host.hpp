@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cstdint>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <functional>
@@ -45,8 +46,9 @@ struct OptionalMemory {
         static OptionalMemory registry;
         return registry;
     }
+    int held_back = 0;  // allocations under way that must fail rather than cost a copy (SquarePlanner::allocate_workspace)
     bool release() {
-        if (recordings > 0) return false;
+        if (recordings > 0 || held_back > 0) return false;
         for (auto &owner : owners)
             if (owner.second()) return true;
         return false;
@@ -484,6 +486,9 @@ public:
     // transpose, built on the first call.
     virtual void rmatvec(PartitionedVector<T> &dst, const PartitionedVector<T> &src, int beta) const = 0;
     virtual bool accumulates_only() const = 0;
+    // Milliseconds of one product of the matrix's first LARGE piece (the rows a set-up-time timing is worth) from x
+    // (the whole input vector) into y (that piece's rows), as the planner would launch it; 0: there is no such piece.
+    virtual float time_large_product(const T *, T *) const { return 0.0f; }
     // Optional fused form: dst <- A src and, in `shares` (room for dot_shares() values), partial sums
     // that add up to dot(dst, w).  dot_shares() == 0: the matrix has no such form.
     virtual int64_t dot_shares() const { return 0; }
@@ -675,6 +680,24 @@ public:
                                        col_.get() + p.k_lo, val_.get() + p.k_lo, src.data(), 0, domain_ - 1,
                                        dst.piece(c), beta, ctx_->stream()));
         }
+    }
+    float time_large_product(const T *x, T *y) const override {
+        if (!sliced()) return 0.0f;
+        for (int c = 0; c < range_.colors(); ++c) {
+            const int64_t rows = range_.volume(c);
+            if (rows < kTuneMinRows || !sliced_[c].handle) continue;
+            auto launch = [&] {
+                check(lsk_set_option("xcd_remap", sliced_[c].placement));
+                check(Abi<T>::csr_sliced_spmv(sliced_[c].handle, 0, rows, x, y, 0, ctx_->stream()));
+            };
+            launch();
+            ctx_->synchronize();
+            const auto t0 = std::chrono::steady_clock::now();
+            for (int i = 0; i < 3; ++i) launch();
+            ctx_->synchronize();
+            return std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count() / 3.0f;
+        }
+        return 0.0f;
     }
     // On the sliced-pattern copy a lane owns its rows, so the product can leave the shares of
     // dot(dst, w) for a wave reduction per block: one share per block of every piece.
@@ -1091,17 +1114,49 @@ public:
     }
     void allocate_workspace(int count) {
         const int n = get_num_spaces();
-        for (int i = 0; i < count; ++i) {
-            std::vector<PartitionedVector<T> *> row;
-            for (int s = 0; s < n; ++s) {
-                owned_.push_back(std::make_unique<PartitionedVector<T>>(
-                    *ctx_, "workspace_" + std::to_string(vectors_.size() - 2) + "_" + std::to_string(s),
-                    vectors_[SOL][s]->partition()));
-                row.push_back(owned_.back().get());
+        size_t need = 0;
+        for (int s = 0; s < n; ++s) need += static_cast<size_t>(vectors_[SOL][s]->partition().n) * sizeof(T);
+        std::vector<void *> hold = room_in_front_of_the_workspace(need * static_cast<size_t>(count));
+        // While blocks are held in front of the workspace, a vector that finds no room must not cost a matrix its
+        // set-up-time copy: the blocks go instead, and the vector is tried again.
+        OptionalMemory &optional = OptionalMemory::get();
+        auto let_go = [&hold, &optional]() {
+            if (hold.empty()) return false;
+            for (void *p : hold) (void)lsk_free(p);
+            hold.clear();
+            --optional.held_back;
+            return true;
+        };
+        if (!hold.empty()) ++optional.held_back;
+        try {
+            for (int i = 0; i < count; ++i) {
+                std::vector<PartitionedVector<T> *> row;
+                for (int s = 0; s < n; ++s) {
+                    for (;;) {
+                        try {
+                            owned_.push_back(std::make_unique<PartitionedVector<T>>(
+                                *ctx_, "workspace_" + std::to_string(vectors_.size() - 2) + "_" + std::to_string(s),
+                                vectors_[SOL][s]->partition()));
+                            break;
+                        } catch (const std::exception &e) {
+                            if (!no_room(e) || !let_go()) throw;
+                            workspace_blocks_ = 0; // (the rest of the workspace lies where it would have gone anyway)
+                        }
+                    }
+                    row.push_back(owned_.back().get());
+                }
+                vectors_.push_back(std::move(row));
             }
-            vectors_.push_back(std::move(row));
+        } catch (...) {
+            let_go();
+            throw;
         }
+        let_go();
     }
+    // Where the workspace went (see room_in_front_of_the_workspace): blocks of a third of the device held in front
+    // of it while it was allocated, and the milliseconds of the product timed behind 0, 1 and 2 such blocks.
+    int workspace_blocks_in_front() const { return workspace_blocks_; }
+    const std::vector<float> &workspace_product_ms() const { return workspace_ms_; }
     PartitionedVector<T> &get_vector(int index, int space) const {
         pending_.reset(); // the caller may write through the reference
         return *vectors_.at(index).at(space);
@@ -1296,6 +1351,93 @@ private:
     long paired_products_ = 0;
     std::vector<std::vector<PartitionedVector<T> *>> vectors_;
     std::vector<std::unique_ptr<PartitionedVector<T>>> owned_;
+    // Where in HBM the workspace vectors go.  The 288 GB of an MI355X answer in three parts of 96 GB (the three
+    // ranks of its 12-high stacks): a read and a write stream are faster in two different parts (a copy: 6.2
+    // against 5.7 TB/s), so the vectors a product writes are best kept out of the part the values of a large
+    // sliced-pattern copy lie in (CG on the 27-point 512^3 matrix: 161 -> 170 it/s).  No interface says where an
+    // allocation lands; memory is handed out from the bottom up, so a block of a third of the device allocated
+    // first pushes what follows into the next part.  Nothing is assumed: one product of every such matrix is timed into a vector here,
+    // into one behind such a block and into one behind two, and the workspace goes where that was fastest by
+    // 1.5 % (else where it would have gone anyway).  Returns the allocations to hold while the workspace is
+    // allocated (fewer when the workspace would not fit behind them).  Skipped without a large sliced copy, with
+    // LSK_PLACE_VECTORS=0, or without room for the blocks.
+    std::vector<void *> room_in_front_of_the_workspace(size_t workspace_bytes) {
+        std::vector<void *> hold;
+        workspace_blocks_ = 0;
+        workspace_ms_.clear();
+        const char *off = std::getenv("LSK_PLACE_VECTORS");
+        if (off && off[0] == '0') return hold;
+        auto try_malloc = [](size_t bytes) -> void * {
+            void *p = nullptr;
+            return lsk_malloc(&p, bytes ? bytes : 1) == LSK_OK ? p : nullptr;
+        };
+        // one product of every matrix with a large sliced piece, into the same vector: their sum is what is compared
+        int64_t n_dom = 0, n_rng = 0;
+        for (const auto &e : matrices_) {
+            n_dom = std::max<int64_t>(n_dom, vectors_[SOL][e.domain]->partition().n);
+            n_rng = std::max<int64_t>(n_rng, vectors_[SOL][e.range]->partition().n);
+        }
+        size_t free_b = 0, total_b = 0;
+        if (matrices_.empty() || lsk_mem_info(&free_b, &total_b) != LSK_OK) return hold;
+        const size_t third = total_b / 3;
+        void *x = try_malloc(static_cast<size_t>(n_dom) * sizeof(T));
+        if (!x) return hold;
+        std::vector<void *> kept; // vector 0, block 1, vector 1, block 2, vector 2
+        std::vector<float> times;
+        try {
+            check(Abi<T>::fill(n_dom, T(0), static_cast<T *>(x), ctx_->stream()));
+            for (int depth = 0; depth < 3; ++depth) {
+                if (depth) {
+                    if (lsk_mem_info(&free_b, &total_b) != LSK_OK || free_b < third + (size_t(4) << 30)) break;
+                    void *block = try_malloc(third);
+                    if (!block) break;
+                    kept.push_back(block);
+                }
+                void *y = try_malloc(static_cast<size_t>(n_rng) * sizeof(T));
+                if (!y) {
+                    if (depth) {
+                        (void)lsk_free(kept.back());
+                        kept.pop_back();
+                    }
+                    break;
+                }
+                kept.push_back(y);
+                float ms = 0.0f;
+                for (const auto &e : matrices_) ms += e.matrix->time_large_product(static_cast<const T *>(x), static_cast<T *>(y));
+                if (ms <= 0.0f) break; // no matrix has a large sliced piece: nothing to place by
+                times.push_back(ms);
+            }
+        } catch (...) {
+            for (void *p : kept) (void)lsk_free(p);
+            (void)lsk_free(x);
+            throw;
+        }
+        (void)lsk_free(x);
+        if (times.empty()) {
+            for (void *p : kept) (void)lsk_free(p);
+            return hold;
+        }
+        size_t best = 0;
+        for (size_t d = 1; d < times.size(); ++d)
+            if (times[d] < times[best]) best = d;
+        if (times[best] > 0.985f * times[0]) best = 0;
+        for (size_t k = 2 * best; k < kept.size(); ++k) (void)lsk_free(kept[k]); // the chosen vector and all behind it
+        kept.resize(2 * best);
+        // the workspace itself must fit behind what is held: else the deepest block goes, and the next
+        while (best > 0 && (lsk_mem_info(&free_b, &total_b) != LSK_OK || free_b < workspace_bytes + (size_t(2) << 30))) {
+            for (int k = 0; k < 2; ++k) {
+                (void)lsk_free(kept.back());
+                kept.pop_back();
+            }
+            --best;
+        }
+        workspace_blocks_ = static_cast<int>(best);
+        workspace_ms_ = times;
+        return kept; // what lies in front of the chosen place stays until the workspace is there
+    }
+    int workspace_blocks_ = 0;
+    std::vector<float> workspace_ms_;
+
     std::vector<Entry> matrices_;
     mutable std::optional<Pending> pending_;
     mutable std::vector<DeviceArray<T>> share_buffers_;

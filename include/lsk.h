@@ -92,6 +92,10 @@ int lsk_init(int device);
  * Returned memory is at least 256-byte aligned. */
 int lsk_malloc(void **ptr, size_t bytes);
 int lsk_free(void *ptr);
+/* Free and total bytes of the current device's memory (hipMemGetInfo): what a caller needs to decide whether a
+ * set-up-time copy, or the blocks by which it steers where its vectors land in HBM, still fit.  The reference
+ * leaves that to Legion's memory sizes (-ll:fsize, bench_all_ls.py:171-181). */
+int lsk_mem_info(size_t *free_bytes, size_t *total_bytes);
 
 /* Stream helpers: replace CUDALibraryContext::get_cuda_stream / CUDAStreamView
  * (src/CUDAUtilities.cpp:66-75,110-122).  Streams are created at default priority. */

@@ -61,6 +61,7 @@ PROTOTYPES = {
     "lsk_init": (_i, [_i]),
     "lsk_malloc": (_i, [ctypes.POINTER(_p), _sz]),
     "lsk_free": (_i, [_p]),
+    "lsk_mem_info": (_i, [ctypes.POINTER(_sz), ctypes.POINTER(_sz)]),
     "lsk_stream_create": (_i, [ctypes.POINTER(_p)]),
     "lsk_stream_destroy": (_i, [_p]),
     "lsk_stream_synchronize": (_i, [_p]),

@@ -75,6 +75,8 @@ class HipBackend:
     def release_optional_memory(self) -> bool:
         if getattr(self, "recordings_alive", 0) > 0:
             return False   # (a recorded step refers to the copies its products read: they stay)
+        if getattr(self, "optional_memory_stays", False):
+            return False   # (the caller has something else to give up first: SquarePlanner.allocate_workspace)
         for owner in list(getattr(self, "_releasable", None) or ()):
             if owner.release_optional_memory():
                 return True

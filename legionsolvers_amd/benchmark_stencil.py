@@ -147,6 +147,10 @@ def main(argv=None):
         seconds = timed_steps(ctx, solver, warm, timed)
     for note in getattr(solver.planner.row_partitioned_matrices[0].matrix, "setup_notes", ()):
         print(f"[LegionSolvers] rank {ctx.rank}: {note[:200]}", file=sys.stderr, flush=True)
+    placed = getattr(solver.planner, "workspace_placement", None)
+    if placed:
+        print(f"[LegionSolvers] rank {ctx.rank}: workspace vectors behind {placed['blocks_in_front']} block(s) of a third of "
+              f"the device; product by blocks in front: {placed['product_ms_by_blocks_in_front']} ms", file=sys.stderr, flush=True)
     if ctx.rank == 0:
         print(f"Performed {num_warmup_traces} warmup traces.")
         print(f"Performed {max(num_traces - num_warmup_traces, 0)} timed traces.")

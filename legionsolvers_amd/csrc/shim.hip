@@ -214,6 +214,12 @@ int lsk_free(void *ptr) {
     return LSK_OK;
 }
 
+int lsk_mem_info(size_t *free_bytes, size_t *total_bytes) {
+    if (!free_bytes || !total_bytes) return lsk::fail(LSK_ERR_ARG, "lsk_mem_info: null output");
+    LSK_HIP(hipMemGetInfo(free_bytes, total_bytes));
+    return LSK_OK;
+}
+
 int lsk_stream_create(lsk_stream_t *stream) {
     if (!stream) return lsk::fail(LSK_ERR_ARG, "lsk_stream_create: null output");
     hipStream_t s = nullptr;

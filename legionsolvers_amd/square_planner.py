@@ -156,23 +156,43 @@ class SquarePlanner:
         if self.workspace_vectors:
             raise RuntimeError("workspace already allocated")
         n = self.get_num_spaces()
-        hold = self._room_in_front_of_the_workspace()
+        need = num_vectors * sum((self.canonical_index_partitions[i].space.volume + sum(self._halo_pad(i))) * self.dtype.itemsize
+                                 for i in range(n))
+        hold = self._room_in_front_of_the_workspace(need)
+        backend = self.ctx.backend
+
+        def let_go() -> bool:
+            if not hold:
+                return False
+            del hold[:]
+            torch.cuda.empty_cache()
+            backend.optional_memory_stays = False
+            return True
+
+        # While blocks are held in front of the workspace, a vector that finds no room must not cost a matrix its
+        # set-up-time copy (HipBackend.empty): the blocks go instead, and the vector is tried again.
+        backend.optional_memory_stays = bool(hold)
         try:
             for j in range(num_vectors):
                 row = []
                 for i in range(n):
-                    row.append(PartitionedVector(self.ctx, f"workspace_{j}_{i}",
-                                                 self.canonical_index_partitions[i], self.dtype,
-                                                 pad=self._halo_pad(i)))
+                    while True:
+                        try:
+                            row.append(PartitionedVector(self.ctx, f"workspace_{j}_{i}",
+                                                         self.canonical_index_partitions[i], self.dtype,
+                                                         pad=self._halo_pad(i)))
+                            break
+                        except torch.cuda.OutOfMemoryError:
+                            if not let_go():
+                                raise
+                            self.workspace_placement["blocks_in_front"] = 0   # (the rest lies where it would have anyway)
                 self.workspace_vectors.append(row)
         finally:
-            if hold:
-                del hold[:]
-                torch.cuda.empty_cache()
+            let_go()
 
     PLACE_MIN_GAIN = 0.015   # a deeper place for the workspace must beat the nearest by this much to be taken
 
-    def _room_in_front_of_the_workspace(self) -> list:
+    def _room_in_front_of_the_workspace(self, workspace_bytes: int = 0) -> list:
         """Where in HBM the workspace vectors go.  The 288 GB of an MI355X answer in three parts of 96 GB (the three
         ranks of its 12-high stacks): two read streams are fastest inside one part (a dot product of two 8 GiB
         buffers: 7.1 against 6.7 TB/s), a read and a write stream in two different ones (a copy: 6.2 against 5.7
@@ -181,9 +201,10 @@ class SquarePlanner:
         27-point 512^3 matrix 161 -> 171 it/s (tools/exp/rank_region_placement.py).  No interface says where an
         allocation lands; on these devices memory is handed out from the bottom up, so a block of a third of the
         device allocated first pushes what follows into the next part.  Nothing is assumed, though: one product
-        is timed into a vector here, into one behind such a block and into one behind two, and the workspace goes
+        of every such matrix is timed into a vector here, into one behind such a block and into one behind two, and the workspace goes
         where that was fastest by PLACE_MIN_GAIN (else where it would have gone anyway).  Returns the blocks to
-        hold while the workspace is allocated (the caller frees them right after; they are never touched).
+        hold while the workspace is allocated (fewer when the workspace_bytes would not fit behind them; the caller
+        frees them right after; they are never touched).
         Skipped without a large sliced copy, with LSK_TUNE=0 or LSK_PLACE_VECTORS=0, and whenever the device
         has no room for the blocks; the times are kept in self.workspace_placement."""
         self.workspace_placement = None
@@ -191,7 +212,7 @@ class SquarePlanner:
         if (dev.type != "cuda" or os.environ.get("LSK_TUNE", "1") == "0" or os.environ.get("LSK_PLACE_VECTORS", "1") == "0"
                 or torch.cuda.is_current_stream_capturing() or self.ctx.comm.backend == "gloo"):
             return []   # (gloo: a rehearsal with several ranks on one card, whose blocks would take each other's memory)
-        target = None
+        targets = []   # the first large sliced piece of every matrix: the sum of their products is what is compared
         for e in self.row_partitioned_matrices:
             m = e.matrix
             if not getattr(m, "sliced", None) or getattr(m, "sliced_window", None) is None or not hasattr(m, "time_piece"):
@@ -199,25 +220,22 @@ class SquarePlanner:
             rp = self.canonical_index_partitions[e.range_index]
             for i, c in enumerate(e.kernel_partition.colors):
                 if c in m.sliced and rp.pieces[c].volume >= m.TUNE_MIN_ROWS:
-                    target = (m, i, c, rp.pieces[c].volume)
+                    targets.append((m, i, c, rp.pieces[c].volume, m.sliced_window[1] - m.sliced_window[0] + 1))
                     break
-            if target:
-                break
-        if target is None:
+        if not targets:
             return []
-        m, i, c, rows = target
-        x_lo, x_hi = m.sliced_window
+        rows, window = max(t[3] for t in targets), max(t[4] for t in targets)
         third = torch.cuda.mem_get_info(dev)[1] // 3
         kept, times = [], []   # kept: vector 0, block 1, vector 1, block 2, vector 2
         try:
-            x = torch.zeros(x_hi - x_lo + 1, dtype=self.dtype, device=dev)
+            x = torch.zeros(window, dtype=self.dtype, device=dev)
             for depth in range(3):
                 if depth:
                     if torch.cuda.mem_get_info(dev)[0] < third + (4 << 30):
                         break
                     kept.append(torch.empty(third, dtype=torch.uint8, device=dev))
                 kept.append(torch.empty(rows, dtype=self.dtype, device=dev))
-                times.append(m.time_piece(i, c, x, kept[-1]))
+                times.append(sum(m.time_piece(i, c, x[:w], kept[-1][:r]) for m, i, c, r, w in targets))
         except torch.cuda.OutOfMemoryError:
             if len(kept) % 2 == 0 and kept:   # a block without its vector
                 kept.pop()
@@ -226,12 +244,17 @@ class SquarePlanner:
         best = min(range(len(times)), key=times.__getitem__)
         if times[best] > (1.0 - self.PLACE_MIN_GAIN) * times[0]:
             best = 0
-        self.workspace_placement = {"blocks_in_front": best, "product_ms_by_blocks_in_front": [round(t, 4) for t in times]}
         hold = kept[:2 * best]   # everything in front of the chosen vector stays until the workspace is there
         del kept, x
         torch.cuda.synchronize(dev)
         torch.cuda.empty_cache()   # (what was freed goes back to the device, not into torch's cache, which would hand
-        return hold                #  a vector's block from behind the chosen place to the first workspace vector)
+        #                             a vector's block from behind the chosen place to the first workspace vector)
+        while hold and torch.cuda.mem_get_info(dev)[0] < workspace_bytes + (2 << 30):
+            del hold[-2:]          # the workspace itself must fit behind what is held: else the deepest block goes
+            torch.cuda.empty_cache()
+            best -= 1
+        self.workspace_placement = {"blocks_in_front": best, "product_ms_by_blocks_in_front": [round(t, 4) for t in times]}
+        return hold
 
     def get_vector(self, vec_idx: int, space_idx: int) -> PartitionedVector:
         if vec_idx == 0:

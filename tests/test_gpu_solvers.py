@@ -671,6 +671,38 @@ def test_non_finite_elements_of_x_through_the_binned_copy_and_long_rows(gpu_ctx,
     assert fine.sum() > 250 and np.abs(got[fine] - want[fine]).max() <= 1e-12 * np.abs(want[fine]).max()
 
 
+@pytest.mark.parametrize("switch", ["1", "0"])
+def test_workspace_vectors_are_placed_by_timing(gpu_ctx, monkeypatch, switch):
+    """A matrix with a large sliced-pattern copy: before the planner allocates its workspace it times one product
+    into a vector here, into one behind a block of a third of the device and into one behind two (a read and a
+    write stream are faster in different thirds of HBM), and allocates the workspace where that was fastest; the
+    blocks are gone afterwards, and CG follows the oracle wherever the vectors went.  LSK_PLACE_VECTORS=0: nothing
+    is timed."""
+    monkeypatch.setenv("LSK_PLACE_VECTORS", switch)
+    rects, row, col, val, n = hc.stencil_problem(4, (130, 130, 130), np.float64)
+    rhs = np.random.default_rng(38).standard_normal(n)
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    free_before, _ = torch.cuda.mem_get_info()
+    mpl = hc.mirror_planner(gpu_ctx, "csr", rects, row, col, val, n, 1, np.float64, rhs)
+    sm = CGSolver(mpl)
+    placed = mpl.workspace_placement
+    if switch == "0":
+        assert placed is None
+    else:
+        assert placed["blocks_in_front"] in (0, 1, 2)
+        assert 1 <= len(placed["product_ms_by_blocks_in_front"]) <= 3 and min(placed["product_ms_by_blocks_in_front"]) > 0
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        assert free_before - torch.cuda.mem_get_info()[0] < (8 << 30)    # the blocks (96 GB each) were given back
+    so = S.CGSolver(hc.oracle_planner("csr", rects, row, col, val, n, 1, np.float64, rhs))
+    for _ in range(5):
+        so.step()
+        sm.step()
+    np.testing.assert_allclose([s.get_value() for s in sm.residual_norm_squared],
+                               [float(v) for v in so.residual_norm_squared], rtol=1e-10)
+
+
 def test_structure_that_cannot_be_compressed_falls_back(gpu_ctx):
     """Rects with a gap (every row ignores its last entry): no 32-bit copy is made, products take
     the reference arrays, CG still follows the oracle."""
