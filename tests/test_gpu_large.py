@@ -153,3 +153,35 @@ def test_classical_sweep_leaves_on_large_vectors(gpu_ctx):
             be.sum_partials(count, partials, out)
             want = float(np.dot(wh.astype(np.float64), wh.astype(np.float64)))
             assert abs(float(out) - want) <= 2e-6 * want
+
+
+def test_placing_the_workspace_never_costs_the_matrix_its_copy(gpu_ctx):
+    """The planner holds blocks of a third of the device in front of the workspace while it allocates it
+    (SquarePlanner.allocate_workspace).  With two systems on the 27-point 512^3 matrix the workspace does not fit
+    behind two such blocks: the planner must then hold fewer, and no vector may be served by giving up the
+    matrix's set-up-time copy."""
+    import gc
+    from legionsolvers_amd import Context
+    from legionsolvers_amd import benchmark_stencil as bs
+    gc.collect()
+    torch.cuda.empty_cache()
+    _need(250)
+    print("case two systems 512^3: workspace placement under memory pressure", flush=True)
+    ctx = Context(torch.device("cuda", 0))
+    matrix, planner, solver = bs.build_problem(ctx, 4, 512, 512, 512, 1, 1, torch.float64, num_systems=2)
+    assert not getattr(matrix, "setup_notes", []), matrix.setup_notes
+    assert matrix.sliced, "the sliced-pattern copy was given up"
+    placed = planner.workspace_placement
+    assert placed is not None and 0 <= placed["blocks_in_front"] < len(placed["product_ms_by_blocks_in_front"])
+    assert ctx.backend.optional_memory_stays is False
+    for _ in range(3):
+        solver.step()
+    history = [float(h.get_value()) for h in solver.residual_norm_squared]
+    # (r.r rises at the first step of this problem, on the CPU as well; two equal systems: twice one system's r.r,
+    #  whose first steps on the CPU loop are 134217728, 11387733438.4979, 11234230381.4603, 11083210600.5105)
+    want = [2 * v for v in (134217728.0, 11387733438.497883, 11234230381.460312, 11083210600.510529)]
+    assert all(abs(h - w) <= 1e-10 * w for h, w in zip(history, want)), history
+    assert matrix.sliced and not matrix.setup_notes
+    del solver, planner, matrix
+    gc.collect()
+    torch.cuda.empty_cache()
