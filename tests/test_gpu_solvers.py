@@ -545,6 +545,38 @@ def test_set_up_time_copies_are_given_up_when_a_vector_finds_no_room(gpu_ctx):
     np.testing.assert_allclose(got, want, rtol=1e-10)
 
 
+def test_blocks_held_in_front_of_the_workspace_go_before_any_copy(gpu_ctx):
+    """While the planner holds memory in front of its workspace (to steer where the vectors land), a vector that
+    finds no room must let that memory go, not make a matrix give up a set-up-time copy.  Forced here by a planner
+    whose held memory is all of the device but 10 MB, against a workspace of 21 MB."""
+    rects, row, col, val, n = hc.stencil_problem(4, (96, 96, 96), np.float64)
+    rhs = np.random.default_rng(37).standard_normal(n)
+    opl = hc.oracle_planner("csr", rects, row, col, val, n, 1, np.float64, rhs)
+    mpl = hc.mirror_planner(gpu_ctx, "csr", rects, row, col, val, n, 1, np.float64, rhs)
+    matrix = mpl.row_partitioned_matrices[0].matrix
+    assert matrix.sliced
+    asked = []
+
+    def all_but_10_mb(workspace_bytes=0):
+        asked.append(workspace_bytes)
+        mpl.workspace_placement = {"blocks_in_front": 1, "product_ms_by_blocks_in_front": [2.0, 1.0]}
+        return hold_device_memory_except(10 << 20)
+
+    mpl._room_in_front_of_the_workspace = all_but_10_mb
+    print("case workspace allocated behind memory that leaves it no room", flush=True)
+    so, sm = S.CGSolver(opl), CGSolver(mpl)
+    assert asked == [3 * n * 8]
+    assert matrix.sliced and not any("given up" in note for note in matrix.setup_notes)
+    assert mpl.workspace_placement["blocks_in_front"] == 0
+    assert gpu_ctx.backend.optional_memory_stays is False
+    assert torch.cuda.mem_get_info()[0] > (1 << 30)      # the held memory is back
+    for _ in range(4):
+        so.step()
+        sm.step()
+    np.testing.assert_allclose([s.get_value() for s in sm.residual_norm_squared],
+                               [float(v) for v in so.residual_norm_squared], rtol=1e-10)
+
+
 def test_a_coo_matrix_gives_up_its_binned_copy(gpu_ctx, monkeypatch):
     """The binned copy of an unstructured COO matrix is optional memory as well: asked to release it in the middle
     of a BiCGStab run (what an allocation that finds no room does), the matrix goes on scanning its entries and
