@@ -686,6 +686,9 @@ public:
         for (int c = 0; c < range_.colors(); ++c) {
             const int64_t rows = range_.volume(c);
             if (rows < kTuneMinRows || !sliced_[c].handle) continue;
+            int64_t info[9] = {};
+            check(lsk_csr_sliced_info(sliced_[c].handle, info));
+            if (info[0] * static_cast<int64_t>(sizeof(T)) < kPlaceMinBytes) continue; // (lives in the caches)
             auto launch = [&] {
                 check(lsk_set_option("xcd_remap", sliced_[c].placement));
                 check(Abi<T>::csr_sliced_spmv(sliced_[c].handle, 0, rows, x, y, 0, ctx_->stream()));
@@ -815,6 +818,8 @@ private:
     // Set-up-time choice of the tile placement, per piece of at least kTuneMinRows rows (the
     // library times a few candidates on the piece itself; a speed hint, results do not depend on it).
     static constexpr int64_t kTuneMinRows = int64_t(1) << 21;
+    // a product that streams less than this from HBM says nothing about where its vectors should lie
+    static constexpr int64_t kPlaceMinBytes = int64_t(1) << 30;
     float tune() { // returns the milliseconds of one product over the tuned pieces (0: nothing tuned)
         int64_t most = 0;
         float total = 0.0f;

@@ -703,14 +703,18 @@ def test_non_finite_elements_of_x_through_the_binned_copy_and_long_rows(gpu_ctx,
     assert fine.sum() > 250 and np.abs(got[fine] - want[fine]).max() <= 1e-12 * np.abs(want[fine]).max()
 
 
-@pytest.mark.parametrize("switch", ["1", "0"])
+@pytest.mark.parametrize("switch", ["1", "0", "too-small"])
 def test_workspace_vectors_are_placed_by_timing(gpu_ctx, monkeypatch, switch):
     """A matrix with a large sliced-pattern copy: before the planner allocates its workspace it times one product
     into a vector here, into one behind a block of a third of the device and into one behind two (a read and a
     write stream are faster in different thirds of HBM), and allocates the workspace where that was fastest; the
     blocks are gone afterwards, and CG follows the oracle wherever the vectors went.  LSK_PLACE_VECTORS=0: nothing
-    is timed."""
-    monkeypatch.setenv("LSK_PLACE_VECTORS", switch)
+    is timed; nor is it for a copy of less than PLACE_MIN_BYTES of values (this one has 0.47 GB: the threshold is
+    lowered for the first two cases)."""
+    from legionsolvers_amd.square_planner import SquarePlanner
+    monkeypatch.setenv("LSK_PLACE_VECTORS", "0" if switch == "0" else "1")
+    if switch != "too-small":
+        monkeypatch.setattr(SquarePlanner, "PLACE_MIN_BYTES", 1 << 20)
     rects, row, col, val, n = hc.stencil_problem(4, (130, 130, 130), np.float64)
     rhs = np.random.default_rng(38).standard_normal(n)
     torch.cuda.synchronize()
@@ -719,7 +723,7 @@ def test_workspace_vectors_are_placed_by_timing(gpu_ctx, monkeypatch, switch):
     mpl = hc.mirror_planner(gpu_ctx, "csr", rects, row, col, val, n, 1, np.float64, rhs)
     sm = CGSolver(mpl)
     placed = mpl.workspace_placement
-    if switch == "0":
+    if switch != "1":
         assert placed is None
     else:
         assert placed["blocks_in_front"] in (0, 1, 2)

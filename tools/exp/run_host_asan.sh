@@ -19,4 +19,7 @@ done
 timeout -k 10 120 $B -dim 4 -nx 12 -ny 11 -nz 10 -vp 3 -it 4 -systems 1 -adjoint 1 | tail -2 || exit 1
 timeout -k 10 120 $B -dim 4 -nx 10 -ny 9 -nz 8 -vp 3 -solver 2 -it 6 -history 1 -coo 1 -binned 1 -bincols 64 -binrows 128 | tail -2 || exit 1
 timeout -k 10 120 $B -dim 4 -nx 10 -ny 9 -nz 8 -vp 1 -solver 3 -it 6 -restart 5 -cgs 1 -history 1 | tail -2 || exit 1
+# the workspace placement (a copy of 1.5 GB of values gets it: blocks of a third of the device held while the workspace is allocated)
+timeout -k 10 200 $B -dim 4 -nx 192 -ny 192 -nz 192 -vp 1 -solver 1 -it 12 -pt 1 -systems 1 2>&1 | grep -v amdgpu | tail -4 || exit 1
+timeout -k 10 200 $B -dim 4 -nx 192 -ny 192 -nz 192 -vp 1 -solver 1 -it 12 -pt 1 2>&1 | grep -v amdgpu | tail -4 || exit 1
 echo "host sanitizers: clean"
