@@ -461,8 +461,8 @@ def main():
     finally:
         matrix.sliced_window, matrix.col32_window = held
 
-    # the reference's own set-up: two identical systems per step
     del solver, planner
+    # the reference's own set-up: two identical systems per step
     _, planner2, solver2 = bs.build_problem(ctx, 4, n1, n1, n1, world, 1, torch.float64, num_systems=2,
                                             matrix=matrix)
     steps2 = max(args.steps // 5, 2)
@@ -520,6 +520,13 @@ def main():
                                           "set-up, and the product takes the 27 coefficients as scalars instead of reading "
                                           "the value array; same multiplications and additions in the same order, same bits "
                                           "(roofline_uniform_coefficients: that kernel, not bound by HBM any more)",
+            "workspace_placement": "a planner default, not a bench setting: before allocating its workspace the planner times "
+                                   "one product into a vector here, into one behind a block of a third of the device and "
+                                   "into one behind two (HBM answers in three parts; a product is faster when it writes "
+                                   "into another part than it reads the values from) and allocates where that was fastest "
+                                   "(LSK_PLACE_VECTORS=0: where the allocator puts it; as the first process on a fresh "
+                                   "device that is 161 against 169.6 it/s, profiles/r03_bench_five_fresh_boxes.log and "
+                                   "r03_bench_v7_no_cpu_baseline.json)",
             "value_with_redraws": "only with --redraws: the same steps after the opt-in set-up-time tuning LSK_TUNE=2 (the "
                                   "copy re-made up to 6 times keeping the fastest, then a wait for the driver's scrubbing "
                                   "of freed memory); the headline `value` runs without it",

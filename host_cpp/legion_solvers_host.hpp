@@ -1361,11 +1361,12 @@ private:
     // against 5.7 TB/s), so the vectors a product writes are best kept out of the part the values of a large
     // sliced-pattern copy lie in (CG on the 27-point 512^3 matrix: 161 -> 170 it/s).  No interface says where an
     // allocation lands; memory is handed out from the bottom up, so a block of a third of the device allocated
-    // first pushes what follows into the next part.  Nothing is assumed: one product of every such matrix is timed into a vector here,
-    // into one behind such a block and into one behind two, and the workspace goes where that was fastest by
-    // 1.5 % (else where it would have gone anyway).  Returns the allocations to hold while the workspace is
-    // allocated (fewer when the workspace would not fit behind them).  Skipped without a large sliced copy, with
-    // LSK_PLACE_VECTORS=0, or without room for the blocks.
+    // first pushes what follows into the next part.  Nothing is assumed: one product of every such matrix is
+    // timed into a vector here, into one behind such a block and into one behind two, and the workspace goes one
+    // place deeper for as long as that is faster by 1.5 % (ties go to the nearer place).  Returns the allocations
+    // to hold while the workspace is allocated (fewer when the workspace would not fit behind them).  Skipped
+    // without a sliced copy of at least kPlaceMinBytes of values, with LSK_PLACE_VECTORS=0, or without room for
+    // the blocks.
     std::vector<void *> room_in_front_of_the_workspace(size_t workspace_bytes) {
         std::vector<void *> hold;
         workspace_blocks_ = 0;
@@ -1423,9 +1424,8 @@ private:
             return hold;
         }
         size_t best = 0;
-        for (size_t d = 1; d < times.size(); ++d)
-            if (times[d] < times[best]) best = d;
-        if (times[best] > 0.985f * times[0]) best = 0;
+        for (size_t d = 1; d < times.size(); ++d) // every step deeper must pay 1.5 %: ties go to the nearer place
+            if (times[d] < 0.985f * times[best]) best = d;
         for (size_t k = 2 * best; k < kept.size(); ++k) (void)lsk_free(kept[k]); // the chosen vector and all behind it
         kept.resize(2 * best);
         // the workspace itself must fit behind what is held: else the deepest block goes, and the next

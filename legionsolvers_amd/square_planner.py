@@ -203,12 +203,13 @@ class SquarePlanner:
         27-point 512^3 matrix 161 -> 171 it/s (tools/exp/rank_region_placement.py).  No interface says where an
         allocation lands; on these devices memory is handed out from the bottom up, so a block of a third of the
         device allocated first pushes what follows into the next part.  Nothing is assumed, though: one product
-        of every such matrix is timed into a vector here, into one behind such a block and into one behind two, and the workspace goes
-        where that was fastest by PLACE_MIN_GAIN (else where it would have gone anyway).  Returns the blocks to
-        hold while the workspace is allocated (fewer when the workspace_bytes would not fit behind them; the caller
-        frees them right after; they are never touched).
-        Skipped without a sliced copy of at least PLACE_MIN_BYTES of values, with LSK_TUNE=0 or LSK_PLACE_VECTORS=0, and whenever the device
-        has no room for the blocks; the times are kept in self.workspace_placement."""
+        of every such matrix is timed into a vector here, into one behind such a block and into one behind two,
+        and the workspace goes one place deeper for as long as that is faster by PLACE_MIN_GAIN (ties go to the
+        nearer place; else it stays where it would have gone anyway).  Returns the blocks to hold while the
+        workspace is allocated (fewer when workspace_bytes would not fit behind them; the caller frees them right
+        after; they are never touched).  Skipped without a sliced copy of at least PLACE_MIN_BYTES of values, with
+        LSK_TUNE=0 or LSK_PLACE_VECTORS=0, and whenever the device has no room for the blocks; the times are kept
+        in self.workspace_placement."""
         self.workspace_placement = None
         dev = self.ctx.device
         if (dev.type != "cuda" or os.environ.get("LSK_TUNE", "1") == "0" or os.environ.get("LSK_PLACE_VECTORS", "1") == "0"
@@ -244,9 +245,10 @@ class SquarePlanner:
                 kept.pop()
         if not times:
             return []
-        best = min(range(len(times)), key=times.__getitem__)
-        if times[best] > (1.0 - self.PLACE_MIN_GAIN) * times[0]:
-            best = 0
+        best = 0
+        for depth in range(1, len(times)):   # every step deeper must pay: ties go to the nearer place
+            if times[depth] < (1.0 - self.PLACE_MIN_GAIN) * times[best]:
+                best = depth
         hold = kept[:2 * best]   # everything in front of the chosen vector stays until the workspace is there
         del kept, x
         torch.cuda.synchronize(dev)
