@@ -194,6 +194,16 @@ class SquarePlanner:
     PLACE_MIN_BYTES = 1 << 30   # ... and only products that stream at least this much from HBM are placed by (a smaller
     #                             copy lives in the caches, where its product's time says nothing about HBM)
 
+    @staticmethod
+    def _choose_place(times, min_gain: float) -> int:
+        """Index of the place to take, given the product's time at each (nearest first): every step deeper must be
+        faster than the place chosen so far by min_gain; ties and small gains go to the nearer place."""
+        best = 0
+        for depth in range(1, len(times)):
+            if times[depth] < (1.0 - min_gain) * times[best]:
+                best = depth
+        return best
+
     def _room_in_front_of_the_workspace(self, workspace_bytes: int = 0) -> list:
         """Where in HBM the workspace vectors go.  The 288 GB of an MI355X answer in three parts of 96 GB (the three
         ranks of its 12-high stacks): two read streams are fastest inside one part (a dot product of two 8 GiB
@@ -245,10 +255,7 @@ class SquarePlanner:
                 kept.pop()
         if not times:
             return []
-        best = 0
-        for depth in range(1, len(times)):   # every step deeper must pay: ties go to the nearer place
-            if times[depth] < (1.0 - self.PLACE_MIN_GAIN) * times[best]:
-                best = depth
+        best = self._choose_place(times, self.PLACE_MIN_GAIN)
         hold = kept[:2 * best]   # everything in front of the chosen vector stays until the workspace is there
         del kept, x
         torch.cuda.synchronize(dev)

@@ -612,3 +612,23 @@ def test_held_back_axpy_fuses_with_the_next_dot():
         assert outcomes == [True] and held["z"]._deferred is None and held["p"]._deferred is None
         assert abs(got - want) <= 1e-13 * abs(want)
         assert torch.equal(held["z"].to_host(), plain["z"].to_host())
+
+
+def test_workspace_place_is_chosen_by_gain_not_by_minimum(ctx):
+    """SquarePlanner places its workspace by the product's time behind 0, 1 and 2 blocks of a third of the device:
+    a deeper place is taken only when it beats the place chosen so far by the minimum gain, so that timer noise
+    never moves the vectors; and on the CPU (and with LSK_PLACE_VECTORS=0) nothing is timed at all."""
+    from legionsolvers_amd.square_planner import SquarePlanner
+    choose, gain = SquarePlanner._choose_place, SquarePlanner.PLACE_MIN_GAIN
+    assert choose([4.76], gain) == 0
+    assert choose([4.76, 4.43, 4.42], gain) == 1       # the second block gains nothing over the first
+    assert choose([4.58, 4.60, 4.64], gain) == 0       # all alike
+    assert choose([4.58, 4.54, 4.45], gain) == 2       # only the deepest pays (against the nearest: 2.8 %)
+    assert choose([4.58, 4.57, 4.53], gain) == 0       # 1.1 % in all: stays
+    assert choose([4.76, 4.43, 4.30], gain) == 2       # each step pays
+    assert choose([], gain) == 0
+    rects, row, col, val, n = hc.stencil_problem(1, (100,), np.float64)
+    mpl = hc.mirror_planner(ctx, "csr", rects, row, col, val, n, 2, np.float64, np.ones(n))
+    assert mpl._room_in_front_of_the_workspace(3 * n * 8) == [] and mpl.workspace_placement is None
+    CGSolver(mpl)
+    assert mpl.workspace_placement is None and len(mpl.workspace_vectors) == 3
