@@ -695,10 +695,16 @@ public:
             };
             launch();
             ctx_->synchronize();
-            const auto t0 = std::chrono::steady_clock::now();
-            for (int i = 0; i < 3; ++i) launch();
-            ctx_->synchronize();
-            return std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count() / 3.0f;
+            float ms = 0.0f;
+            for (int reps = 3, round = 0;; ++round) { // (a short product: once more over enough launches for 6 ms)
+                const auto t0 = std::chrono::steady_clock::now();
+                for (int i = 0; i < reps; ++i) launch();
+                ctx_->synchronize();
+                ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count() / float(reps);
+                if (ms * float(reps) >= 5.0f || reps >= 40 || round >= 1) break;
+                reps = std::min(40, static_cast<int>(6.0f / std::max(ms, 0.15f)) + 1);
+            }
+            return ms;
         }
         return 0.0f;
     }
@@ -1386,28 +1392,32 @@ private:
         size_t free_b = 0, total_b = 0;
         if (matrices_.empty() || lsk_mem_info(&free_b, &total_b) != LSK_OK) return hold;
         const size_t third = total_b / 3;
-        void *x = try_malloc(static_cast<size_t>(n_dom) * sizeof(T));
-        if (!x) return hold;
-        std::vector<void *> kept; // vector 0, block 1, vector 1, block 2, vector 2
+        // kept: input 0, output 0, block 1, input 1, output 1, block 2, input 2, output 2 -- at every place the product
+        // runs from a first vector into a second one, as the solver's products will from the first workspace vector
+        // into the second (what is freed here is what the workspace is then allocated from)
+        std::vector<void *> kept;
         std::vector<float> times;
         try {
-            check(Abi<T>::fill(n_dom, T(0), static_cast<T *>(x), ctx_->stream()));
             for (int depth = 0; depth < 3; ++depth) {
+                const size_t before = kept.size();
                 if (depth) {
                     if (lsk_mem_info(&free_b, &total_b) != LSK_OK || free_b < third + (size_t(4) << 30)) break;
                     void *block = try_malloc(third);
                     if (!block) break;
                     kept.push_back(block);
                 }
-                void *y = try_malloc(static_cast<size_t>(n_rng) * sizeof(T));
-                if (!y) {
-                    if (depth) {
+                void *x = try_malloc(static_cast<size_t>(n_dom) * sizeof(T));
+                if (x) kept.push_back(x);
+                void *y = x ? try_malloc(static_cast<size_t>(n_rng) * sizeof(T)) : nullptr;
+                if (!y) { // a place without all of its vectors
+                    while (kept.size() > before) {
                         (void)lsk_free(kept.back());
                         kept.pop_back();
                     }
                     break;
                 }
                 kept.push_back(y);
+                check(Abi<T>::fill(n_dom, T(0), static_cast<T *>(x), ctx_->stream()));
                 float ms = 0.0f;
                 for (const auto &e : matrices_) ms += e.matrix->time_large_product(static_cast<const T *>(x), static_cast<T *>(y));
                 if (ms <= 0.0f) break; // no matrix has a large sliced piece: nothing to place by
@@ -1415,22 +1425,21 @@ private:
             }
         } catch (...) {
             for (void *p : kept) (void)lsk_free(p);
-            (void)lsk_free(x);
             throw;
         }
-        (void)lsk_free(x);
         if (times.empty()) {
+            ctx_->synchronize();
             for (void *p : kept) (void)lsk_free(p);
             return hold;
         }
         size_t best = 0;
         for (size_t d = 1; d < times.size(); ++d) // every step deeper must pay 1.5 %: ties go to the nearer place
             if (times[d] < 0.985f * times[best]) best = d;
-        for (size_t k = 2 * best; k < kept.size(); ++k) (void)lsk_free(kept[k]); // the chosen vector and all behind it
-        kept.resize(2 * best);
+        for (size_t k = 3 * best; k < kept.size(); ++k) (void)lsk_free(kept[k]); // the chosen place and all behind it
+        kept.resize(3 * best);
         // the workspace itself must fit behind what is held: else the deepest block goes, and the next
         while (best > 0 && (lsk_mem_info(&free_b, &total_b) != LSK_OK || free_b < workspace_bytes + (size_t(2) << 30))) {
-            for (int k = 0; k < 2; ++k) {
+            for (int k = 0; k < 3; ++k) {
                 (void)lsk_free(kept.back());
                 kept.pop_back();
             }

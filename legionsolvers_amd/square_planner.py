@@ -240,29 +240,32 @@ class SquarePlanner:
             return []
         rows, window = max(t[3] for t in targets), max(t[4] for t in targets)
         third = torch.cuda.mem_get_info(dev)[1] // 3
-        kept, times = [], []   # kept: vector 0, block 1, vector 1, block 2, vector 2
+        # kept: input 0, output 0, block 1, input 1, output 1, block 2, input 2, output 2 -- at every place the product
+        # runs from a first vector into a second one, as the solver's products will from the first workspace vector
+        # into the second (what is freed here is what the workspace is then allocated from)
+        kept, times = [], []
         try:
-            x = torch.zeros(window, dtype=self.dtype, device=dev)
             for depth in range(3):
                 if depth:
                     if torch.cuda.mem_get_info(dev)[0] < third + (4 << 30):
                         break
                     kept.append(torch.empty(third, dtype=torch.uint8, device=dev))
+                kept.append(torch.zeros(window, dtype=self.dtype, device=dev))
                 kept.append(torch.empty(rows, dtype=self.dtype, device=dev))
-                times.append(sum(m.time_piece(i, c, x[:w], kept[-1][:r]) for m, i, c, r, w in targets))
+                times.append(sum(m.time_piece(i, c, kept[-2][:w], kept[-1][:r]) for m, i, c, r, w in targets))
         except torch.cuda.OutOfMemoryError:
-            if len(kept) % 2 == 0 and kept:   # a block without its vector
+            while kept and (len(kept) < 2 or (len(kept) - 2) % 3):   # a place without all of its vectors
                 kept.pop()
         if not times:
             return []
         best = self._choose_place(times, self.PLACE_MIN_GAIN)
-        hold = kept[:2 * best]   # everything in front of the chosen vector stays until the workspace is there
-        del kept, x
+        hold = kept[:3 * best]   # everything in front of the chosen place stays until the workspace is there
+        del kept
         torch.cuda.synchronize(dev)
         torch.cuda.empty_cache()   # (what was freed goes back to the device, not into torch's cache, which would hand
         #                             a vector's block from behind the chosen place to the first workspace vector)
         while hold and torch.cuda.mem_get_info(dev)[0] < workspace_bytes + (2 << 30):
-            del hold[-2:]          # the workspace itself must fit behind what is held: else the deepest block goes
+            del hold[-3:]          # the workspace itself must fit behind what is held: else the deepest block goes
             torch.cuda.empty_cache()
             best -= 1
         self.workspace_placement = {"blocks_in_front": best, "product_ms_by_blocks_in_front": [round(t, 4) for t in times]}
