@@ -243,6 +243,18 @@ def test_shim_memory_and_streams():
     res = np.zeros(1)
     _lib.check(lib.lsk_dot_host_f64(1000, ptr, ptr, res.ctypes.data, s))
     assert res[0] == float(np.dot(host * 2, host * 2))
+    # lsk_mem_info: what is free goes down by an allocation and comes back with its release
+    free0, free1, total = ctypes.c_size_t(0), ctypes.c_size_t(0), ctypes.c_size_t(0)
+    _lib.check(lib.lsk_mem_info(ctypes.byref(free0), ctypes.byref(total)))
+    assert 0 < free0.value <= total.value and total.value >= (16 << 30)
+    big = ctypes.c_void_p()
+    _lib.check(lib.lsk_malloc(ctypes.byref(big), 1 << 30))
+    _lib.check(lib.lsk_mem_info(ctypes.byref(free1), ctypes.byref(total)))
+    assert free0.value - free1.value >= (1 << 30) - (16 << 20)   # (the driver accounts in pages of its own)
+    _lib.check(lib.lsk_free(big))
+    _lib.check(lib.lsk_mem_info(ctypes.byref(free1), ctypes.byref(total)))
+    assert free0.value - free1.value < (64 << 20)
+    assert lib.lsk_mem_info(None, ctypes.byref(total)) == _lib.LSK_ERR_ARG
     _lib.check(lib.lsk_free(ptr))
     _lib.check(lib.lsk_stream_destroy(s))
 
