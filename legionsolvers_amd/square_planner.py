@@ -10,6 +10,7 @@ room of the source vector.
 from __future__ import annotations
 
 import os
+import time
 from typing import List, Tuple
 
 import torch
@@ -239,6 +240,7 @@ class SquarePlanner:
         if not targets:
             return []
         rows, window = max(t[3] for t in targets), max(t[4] for t in targets)
+        began = time.perf_counter()
         third = torch.cuda.mem_get_info(dev)[1] // 3
         # kept: input 0, output 0, block 1, input 1, output 1, block 2, input 2, output 2 -- at every place the product
         # runs from a first vector into a second one, as the solver's products will from the first workspace vector
@@ -268,7 +270,8 @@ class SquarePlanner:
             del hold[-3:]          # the workspace itself must fit behind what is held: else the deepest block goes
             torch.cuda.empty_cache()
             best -= 1
-        self.workspace_placement = {"blocks_in_front": best, "product_ms_by_blocks_in_front": [round(t, 4) for t in times]}
+        self.workspace_placement = {"blocks_in_front": best, "product_ms_by_blocks_in_front": [round(t, 4) for t in times],
+                                    "seconds": round(time.perf_counter() - began, 3)}
         return hold
 
     def get_vector(self, vec_idx: int, space_idx: int) -> PartitionedVector:
